@@ -1,0 +1,80 @@
+"""ctypes loader for libcream_amd.so — the C-ABI HIP library (include/cream_amd.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing or a
+symbol cannot be resolved this module raises immediately (`CreamLibraryError`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcream_amd.so")
+
+# error codes of include/cream_amd.h
+CREAM_OK = 0
+_ERRORS = {
+    -1: "CREAM_ERR_BAD_ARG (null pointer, negative size or unsupported stride)",
+    -2: "CREAM_ERR_BAD_DTYPE (element type not supported by this entry point)",
+    -3: "CREAM_ERR_LAUNCH (HIP kernel launch failed)",
+    -4: "CREAM_ERR_TOO_LARGE (shape exceeds what the kernel family supports)",
+}
+
+# dtype enum of include/cream_amd.h
+F32, F16, BF16, F64 = 0, 1, 2, 3
+
+
+class CreamLibraryError(RuntimeError):
+    pass
+
+
+_c = ctypes
+_vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> (restype, argtypes).  Must list every symbol include/cream_amd.h declares;
+# tests/test_cabi.py checks header and table against each other.
+SIGNATURES = {
+    "cream_version": (_c.c_char_p, []),
+    "cream_build_info": (_c.c_char_p, []),
+    "cream_rpe_index_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _vp]),
+    "cream_rpe_index_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cream_rpe_index_fwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "cream_rpe_index_bwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once and bind every declared entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CreamLibraryError(
+            f"cream_amd: {LIB_PATH} is missing — build it with `python -m cream_amd.build` "
+            "(or __graft_entry__.build()).  There is no fallback path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise CreamLibraryError(f"cream_amd: cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CreamLibraryError(f"cream_amd: symbol {name} missing from {LIB_PATH}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != CREAM_OK:
+        raise RuntimeError(f"cream_amd: {what} failed with {_ERRORS.get(code, code)}")
+
+
+def version():
+    return load().cream_version().decode()
+
+
+def build_info():
+    return load().cream_build_info().decode()

@@ -1,0 +1,515 @@
+// rpe_index.hip — bucketed relative-position gather (fwd) / scatter-add (bwd) for gfx950.
+//
+// What it computes (reference: iRPE/DeiT-with-iRPE/rpe_ops/rpe_index_cuda.cu:24-52):
+//   fwd  Y[b,h,i,j]   = in[b,h,i, idx[i,j]]
+//   bwd  gin[b,h,i,u] += sum_{j: idx[i,j]==u} gout[b,h,i,j]
+// Both are zero-FLOP, HBM-bound passes over the (B,H,Lq,Lk) tensor.  The design is
+// not a translation of the reference's one-thread-per-element grid-stride loops:
+//
+//   fwd  one WAVE owns one query row i and walks a slice of the (b,h) planes.  The
+//        row's bucket ids idx[i,:] are fetched ONCE into registers; for every plane
+//        the nb-entry lookup row is staged in a wave-private LDS table and each lane
+//        gathers 16 bytes' worth of consecutive keys from LDS and issues one 16-byte
+//        store — no div/mod per element, no index re-reads, full-width HBM writes.
+//
+//   bwd  the reference's global atomics contend on <= nb addresses per 577 adds and
+//        give a run-to-run different fp sum.  Here the observation is that idx[i,j]
+//        does not depend on (b,h): with LANE <-> PLANE the bucket id of step j is
+//        WAVE-UNIFORM.  A wave owns 64 planes; tiles of gout are transposed through
+//        LDS (coalesced 16-byte HBM reads along j, conflict-free ds_read_b128 along
+//        planes), every lane adds its value into its private column of an LDS bin
+//        array with a conflict-free, non-returning ds_add — no cross-lane reduction,
+//        no global atomics, and a FIXED ascending-j summation order (bit-identical to
+//        a sequential CPU loop for f32/f64).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bfloat16.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "cream_amd.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte vector that is only guaranteed 4-/2-/8-byte aligned in memory: rows of an
+// odd Lk (197, 577) start at arbitrary element offsets.  gfx950 global memory accepts
+// element-aligned dwordx4 accesses; HBM traffic is unchanged.
+struct __attribute__((packed, aligned(4))) vec16_a4 { u32x4 v; };
+struct __attribute__((packed, aligned(2))) vec16_a2 { u32x4 v; };
+struct __attribute__((packed, aligned(8))) vec16_a8 { u32x4 v; };
+
+template <int BYTES> struct raw_elem;
+template <> struct raw_elem<2> { using type = uint16_t; using vec = vec16_a2; };
+template <> struct raw_elem<4> { using type = uint32_t; using vec = vec16_a4; };
+template <> struct raw_elem<8> { using type = uint64_t; using vec = vec16_a8; };
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------
+// forward: gather
+// ------------------------------------------------------------------------------------
+// grid.x = ceil(Lq / waves per block), grid.y = number of plane slices.
+// NCHUNK = ceil(Lk / (64 * V)) register-resident index chunks (V = 16 / BYTES).
+// NBT    = ceil(nb / 64) register slots used to prefetch the next plane's lookup row.
+// 16-byte stores go through a per-row buffer descriptor (raw_buffer_store_b128): rows of
+// an odd Lk are only element-aligned and hipcc splits an under-aligned vector store into
+// four dword stores; the buffer form keeps one dwordx4 per lane.
+template <int BYTES, int NCHUNK, int NBT>
+__global__ __launch_bounds__(256) void rpe_gather_rows(
+    typename raw_elem<BYTES>::type* __restrict__ y,
+    const typename raw_elem<BYTES>::type* __restrict__ in,
+    const int32_t* __restrict__ idx,
+    int BH, int H, int Lq, int Lk, int nb,
+    int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+    int planes_per_wave, int nb_pad)
+{
+    using E = typename raw_elem<BYTES>::type;
+    constexpr int V = 16 / BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= Lq) return;                       // whole wave leaves; no block barrier below
+    E* table = reinterpret_cast<E*>(smem) + (size_t)wave * nb_pad;
+
+    // bucket ids of this query row, resident in registers for the whole plane walk
+    int32_t myidx[NCHUNK][V];
+    const int32_t* irow = idx + (int64_t)i * Lk;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int j = (c * WAVE + lane) * V + v;
+            myidx[c][v] = (j < Lk) ? irow[j] : 0;
+        }
+    }
+
+    const int p0 = blockIdx.y * planes_per_wave;
+    const int p1 = min(BH, p0 + planes_per_wave);
+    if (p0 >= p1) return;
+
+    auto row_ptr = [&](int p) -> const E* {
+        const int b = p / H, h = p - b * H;
+        return in + (int64_t)b * s0 + (int64_t)h * s1 + (int64_t)i * s2;
+    };
+    auto fetch_row = [&](E (&dst)[NBT], const E* r) {
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) {
+            const int u = t * WAVE + lane;
+            dst[t] = (u < nb) ? r[(int64_t)u * s3] : E(0);
+        }
+    };
+
+    E pre[NBT];
+    fetch_row(pre, row_ptr(p0));                // prefetch the first lookup row
+
+    // lanes of the last chunk that still hold a full 16-byte vector / a partial one
+    const int jl = ((NCHUNK - 1) * WAVE + lane) * V;
+    const bool last_full = jl + V <= Lk;
+    const bool last_part = !last_full && jl < Lk;
+
+    for (int p = p0; p < p1; ++p) {
+        // stage this plane's lookup row in the wave-private LDS table
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) {
+            const int u = t * WAVE + lane;
+            if (NBT == 1 || u < nb_pad) table[u] = pre[t];
+        }
+        // issue the next plane's loads before consuming this one (latency hiding)
+        if (p + 1 < p1) fetch_row(pre, row_ptr(p + 1));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        E* out = y + ((int64_t)p * Lq + i) * Lk;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            out, 0, Lk * BYTES, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            union { u32x4 vec; E e[V]; } pk;
+#pragma unroll
+            for (int v = 0; v < V; ++v) pk.e[v] = table[myidx[c][v]];
+            const int j0 = (c * WAVE + lane) * V;
+            if (c + 1 < NCHUNK || last_full) {
+                __builtin_amdgcn_raw_buffer_store_b128(pk.vec, rs, j0 * BYTES, 0, 0);
+            } else if (last_part) {
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (j0 + v < Lk) out[j0 + v] = pk.e[v];
+            }
+        }
+        // the table is rewritten next iteration: same-wave LDS ops retire in order
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Shape-generic fallback (very long rows or very many buckets): one thread per output
+// element, index re-read from L2.  Correct for every shape; not the measured path.
+template <int BYTES>
+__global__ __launch_bounds__(256) void rpe_gather_generic(
+    typename raw_elem<BYTES>::type* __restrict__ y,
+    const typename raw_elem<BYTES>::type* __restrict__ in,
+    const int32_t* __restrict__ idx,
+    int64_t rows, int H, int Lq, int Lk,
+    int64_t s0, int64_t s1, int64_t s2, int64_t s3)
+{
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int i = (int)(r % Lq);
+        const int64_t p = r / Lq;
+        const int h = (int)(p % H);
+        const int64_t b = p / H;
+        const auto* src = in + b * s0 + (int64_t)h * s1 + (int64_t)i * s2;
+        const int32_t* irow = idx + (int64_t)i * Lk;
+        auto* out = y + r * Lk;
+        for (int j = threadIdx.x; j < Lk; j += blockDim.x)
+            out[j] = src[(int64_t)irow[j] * s3];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward: deterministic scatter-add, lane <-> (b,h) plane
+// ------------------------------------------------------------------------------------
+template <typename T> struct cvt;
+template <> struct cvt<float> {
+    using acc = float;
+    static __device__ __forceinline__ float load(float x) { return x; }
+    static __device__ __forceinline__ float store(float x) { return x; }
+};
+template <> struct cvt<double> {
+    using acc = double;
+    static __device__ __forceinline__ double load(double x) { return x; }
+    static __device__ __forceinline__ double store(double x) { return x; }
+};
+template <> struct cvt<__half> {
+    using acc = float;
+    static __device__ __forceinline__ float load(__half x) { return __half2float(x); }
+    static __device__ __forceinline__ __half store(float x) { return __float2half_rn(x); }
+};
+template <> struct cvt<hip_bfloat16> {
+    using acc = float;
+    static __device__ __forceinline__ float load(hip_bfloat16 x) { return static_cast<float>(x); }
+    static __device__ __forceinline__ hip_bfloat16 store(float x) { return hip_bfloat16(x); }
+};
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    // non-returning LDS float add: ds_add_f32; every lane owns its own address
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(double* p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// element-sized buffer load/store helpers (bounds-checked by the descriptor)
+template <int BYTES> struct bufop;
+template <> struct bufop<2> {
+    static __device__ __forceinline__ uint16_t ld(__amdgpu_buffer_rsrc_t r, int off) {
+        return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void st(uint16_t v, __amdgpu_buffer_rsrc_t r, int off) {
+        __builtin_amdgcn_raw_buffer_store_b16((short)v, r, off, 0, 0);
+    }
+};
+template <> struct bufop<4> {
+    static __device__ __forceinline__ uint32_t ld(__amdgpu_buffer_rsrc_t r, int off) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void st(uint32_t v, __amdgpu_buffer_rsrc_t r, int off) {
+        __builtin_amdgcn_raw_buffer_store_b32((int)v, r, off, 0, 0);
+    }
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <> struct bufop<8> {
+    static __device__ __forceinline__ uint64_t ld(__amdgpu_buffer_rsrc_t r, int off) {
+        union { u32x2 v; uint64_t x; } c;
+        c.v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return c.x;
+    }
+    static __device__ __forceinline__ void st(uint64_t v, __amdgpu_buffer_rsrc_t r, int off) {
+        union { u32x2 v; uint64_t x; } c;
+        c.x = v;
+        __builtin_amdgcn_raw_buffer_store_b64(c.v, r, off, 0, 0);
+    }
+};
+
+// One 64-thread workgroup = one wave = 64 consecutive planes x a range of query rows.
+// CT = keys per LDS tile (128-byte tile rows).  Tile rows are padded by 16 bytes so that
+// both the row-wise 16-byte writes and the plane-wise 16-byte reads are bank-conflict-free;
+// bins use a 65-column pitch so that the accumulate (lane-contiguous) and the transposed
+// init/flush (bucket-contiguous) are conflict-free too.  The bucket ids of a tile are
+// fetched with ONE coalesced load and broadcast per key with v_readlane (wave-uniform).
+// All HBM traffic goes through two per-(wave,row) buffer descriptors whose extent ends
+// at the last valid plane: planes past BH read as zero / drop their stores in hardware,
+// so the loops carry no per-lane bounds branches.
+template <typename T, int CT>
+__global__ __launch_bounds__(64) void rpe_scatter_planes(
+    T* __restrict__ gin, const T* __restrict__ gout, const int32_t* __restrict__ idx,
+    int BH, int Lq, int Lk, int nb, int rows_per_block)
+{
+    using ACC = typename cvt<T>::acc;
+    constexpr int BYTES = sizeof(T);
+    using E = typename raw_elem<BYTES>::type;
+    constexpr int V = 16 / BYTES;                 // elements per 16-byte vector
+    constexpr int LPR = CT / V;                   // lanes that cover one tile row (8)
+    constexpr int RPI = WAVE / LPR;               // tile rows per wave-instruction (8)
+    constexpr int NLD = WAVE / RPI;               // wave-instructions per tile (8)
+    constexpr int TP = CT + V;                    // tile pitch in elements (16-byte pad)
+    constexpr int BP = WAVE + 1;                  // bin pitch
+    static_assert(CT <= WAVE, "one index load per tile");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                                   // [64][TP]
+    ACC* bins = reinterpret_cast<ACC*>(smem + (size_t)WAVE * TP * BYTES);   // [nb][BP]
+
+    const int lane = threadIdx.x;
+    const int pbase = blockIdx.x * WAVE;           // first plane of this wave
+    const int nplanes = min(WAVE, BH - pbase);
+    const int i0 = blockIdx.y * rows_per_block;
+    const int i1 = min(Lq, i0 + rows_per_block);
+
+    const int lr = lane / LPR;                     // tile row this lane loads (per instruction)
+    const int lc = (lane % LPR) * V;               // first key of this lane's vector
+    const int nchunk = (Lk + CT - 1) / CT;
+    const int64_t plane_go = (int64_t)Lq * Lk;     // plane pitch of gout (elements)
+    const int64_t plane_gi = (int64_t)Lq * nb;     // plane pitch of gin
+
+    union Pack { u32x4 vec; T e[V]; };
+
+    for (int i = i0; i < i1; ++i) {
+        // descriptors: base = (first plane of the wave, row i); extent = up to the end of
+        // row i of the LAST valid plane.
+        const T* go_base = gout + ((int64_t)pbase * Lq + i) * Lk;
+        T* gi_base = gin + ((int64_t)pbase * Lq + i) * nb;
+        const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(go_base), 0,
+            (int)(((int64_t)(nplanes - 1) * plane_go + Lk) * BYTES), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(
+            gi_base, 0, (int)(((int64_t)(nplanes - 1) * plane_gi + nb) * BYTES), 0x00020000);
+
+        auto load_tile = [&](Pack (&st)[NLD], int32_t& ids, int c0) {
+            ids = (lane < CT && c0 + lane < Lk) ? idx[(int64_t)i * Lk + c0 + lane] : 0;
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) {
+                const int r = t * RPI + lr;
+                st[t].vec = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_go, (int)(((int64_t)r * plane_go + c0 + lc) * BYTES), 0, 0);
+            }
+        };
+
+        // bins <- current gin rows (the reference accumulates INTO grad_input).  Columns of
+        // planes beyond BH read as zero and only ever receive zeros.
+        for (int ub = 0; ub < nb; ub += WAVE) {
+            const int u = ub + lane;
+#pragma unroll 8
+            for (int r = 0; r < WAVE; ++r) {
+                union { E raw; T val; } c;
+                c.raw = (u < nb) ? bufop<BYTES>::ld(rs_gi, (int)((r * plane_gi + u) * BYTES)) : E(0);
+                if (u < nb) bins[u * BP + r] = cvt<T>::load(c.val);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        Pack stage[NLD];
+        int32_t ids_next;
+        load_tile(stage, ids_next, 0);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * CT;
+            const int32_t ids = ids_next;
+            // zero the keys past the row end (they belong to the next row), then
+            // registers -> LDS tile (row-wise, 16-byte writes)
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) {
+                const int r = t * RPI + lr;
+                Pack pk = stage[t];
+                if (c0 + CT > Lk) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        if (c0 + lc + v >= Lk) pk.e[v] = T(0);
+                }
+                *reinterpret_cast<u32x4*>(tile + r * TP + lc) = pk.vec;
+            }
+            // next tile's HBM loads fly while this one is consumed
+            if (ch + 1 < nchunk) load_tile(stage, ids_next, c0 + CT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // plane-wise read-back: lane = plane, ascending key order.  Keys past Lk in the
+            // last tile are zero and carry bucket id 0: adding +0.0 is exact.
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                Pack pk;
+                pk.vec = *reinterpret_cast<const u32x4*>(tile + lane * TP + q * V);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int u = __builtin_amdgcn_readlane(ids, q * V + v);
+                    lds_add(bins + u * BP + lane, cvt<T>::load(pk.e[v]));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // flush: one coalesced nb-element row per plane
+        for (int ub = 0; ub < nb; ub += WAVE) {
+            const int u = ub + lane;
+            if (u < nb) {
+#pragma unroll 8
+                for (int r = 0; r < WAVE; ++r) {
+                    union { E raw; T val; } c;
+                    c.val = cvt<T>::store(bins[u * BP + r]);
+                    bufop<BYTES>::st(c.raw, rs_gi, (int)((r * plane_gi + u) * BYTES));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Fallback when nb is too large for the LDS bin array: one thread per (row, bucket),
+// sequential over j (same fixed order).  O(nb*Lk) per row — exotic shapes only.
+template <typename T>
+__global__ __launch_bounds__(256) void rpe_scatter_generic(
+    T* __restrict__ gin, const T* __restrict__ gout, const int32_t* __restrict__ idx,
+    int64_t rows, int Lq, int Lk, int nb)
+{
+    using ACC = typename cvt<T>::acc;
+    const int64_t total = rows * nb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(t % nb);
+        const int64_t r = t / nb;
+        const int i = (int)(r % Lq);
+        const int32_t* irow = idx + (int64_t)i * Lk;
+        const T* g = gout + r * Lk;
+        ACC acc = cvt<T>::load(gin[t]);
+        for (int j = 0; j < Lk; ++j)
+            if (irow[j] == u) acc += cvt<T>::load(g[j]);
+        gin[t] = cvt<T>::store(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+template <int BYTES>
+int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int Lq, int Lk,
+                  int nb, int64_t s0, int64_t s1, int64_t s2, int64_t s3, hipStream_t st)
+{
+    using E = typename raw_elem<BYTES>::type;
+    constexpr int V = 16 / BYTES;
+    const int BH = B * H;
+    const int nchunk = ceil_div(Lk, WAVE * V);
+    const int nbt = ceil_div(nb, WAVE);
+    const int nb_pad = (nb + 7) & ~7;
+    if (nchunk > 4 || nbt > 2) {
+        const int64_t rows = (int64_t)BH * Lq;
+        const int grid = (int)std::min<int64_t>(rows, 256 * 16);
+        hipLaunchKernelGGL((rpe_gather_generic<BYTES>), dim3(grid), dim3(256), 0, st,
+                           (E*)y, (const E*)in, idx, rows, H, Lq, Lk, s0, s1, s2, s3);
+        return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+    }
+    // ~8 waves per SIMD across 256 CUs, but at least 8 planes per wave so that the
+    // index registers are amortised.
+    const int waves_per_block = 4;
+    const int gx = ceil_div(Lq, waves_per_block);
+    int slices = std::max(1, (256 * 32 * 2) / std::max(1, Lq));
+    int ppw = std::max(8, ceil_div(BH, slices));
+    ppw = std::min(ppw, BH);
+    const int gy = ceil_div(BH, ppw);
+    const size_t lds = (size_t)waves_per_block * nb_pad * BYTES;
+    dim3 grid(gx, gy), block(waves_per_block * WAVE);
+#define CREAM_GATHER_CASE(NC, NT)                                                         \
+    hipLaunchKernelGGL((rpe_gather_rows<BYTES, NC, NT>), grid, block, lds, st, (E*)y,       \
+                       (const E*)in, idx, BH, H, Lq, Lk, nb, s0, s1, s2, s3, ppw, nb_pad)
+    if (nbt == 1) {
+        switch (nchunk) {
+            case 1: CREAM_GATHER_CASE(1, 1); break;
+            case 2: CREAM_GATHER_CASE(2, 1); break;
+            case 3: CREAM_GATHER_CASE(3, 1); break;
+            default: CREAM_GATHER_CASE(4, 1); break;
+        }
+    } else {
+        switch (nchunk) {
+            case 1: CREAM_GATHER_CASE(1, 2); break;
+            case 2: CREAM_GATHER_CASE(2, 2); break;
+            case 3: CREAM_GATHER_CASE(3, 2); break;
+            default: CREAM_GATHER_CASE(4, 2); break;
+        }
+    }
+#undef CREAM_GATHER_CASE
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_scatter(void* gin, const void* gout, const int32_t* idx, int B, int H, int Lq,
+                   int Lk, int nb, hipStream_t st)
+{
+    using ACC = typename cvt<T>::acc;
+    constexpr int CT = 128 / (int)sizeof(T);     // 128-byte tile rows for every element size
+    constexpr int V = 16 / (int)sizeof(T);
+    const int BH = B * H;
+    const size_t lds = (size_t)WAVE * (CT + V) * sizeof(T) + (size_t)nb * (WAVE + 1) * sizeof(ACC);
+    // the fast path addresses 64 planes through 32-bit buffer offsets
+    const bool fits32 = (int64_t)WAVE * Lq * std::max(Lk, nb) * (int64_t)sizeof(T) < (int64_t)INT32_MAX;
+    if (lds > 64 * 1024 || !fits32) {
+        const int64_t rows = (int64_t)BH * Lq;
+        const int grid = (int)std::min<int64_t>(ceil_div(rows * nb, 256), 256 * 32);
+        hipLaunchKernelGGL((rpe_scatter_generic<T>), dim3(grid), dim3(256), 0, st, (T*)gin,
+                           (const T*)gout, idx, rows, Lq, Lk, nb);
+        return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+    }
+    const int gx = ceil_div(BH, WAVE);
+    // enough workgroups to give every CU several waves
+    int want_y = std::max(1, (256 * 8) / gx);
+    int rpb = std::max(1, ceil_div(Lq, want_y));
+    const int gy = ceil_div(Lq, rpb);
+    hipLaunchKernelGGL((rpe_scatter_planes<T, CT>), dim3(gx, gy), dim3(WAVE), lds, st, (T*)gin,
+                       (const T*)gout, idx, BH, Lq, Lk, nb, rpb);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cream_rpe_index_fwd(void* y, const void* in, const int32_t* idx, int B, int H, int Lq,
+                        int Lk, int nb, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+                        int dtype, void* stream)
+{
+    if (B < 0 || H < 0 || Lq < 0 || Lk < 0 || nb < 0) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)B * H * Lq * Lk == 0) return CREAM_OK;            // empty output
+    if (!y || !in || !idx || nb == 0) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)B * H > INT32_MAX) return CREAM_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case CREAM_F32: return launch_gather<4>(y, in, idx, B, H, Lq, Lk, nb, s0, s1, s2, s3, st);
+        case CREAM_F16:
+        case CREAM_BF16: return launch_gather<2>(y, in, idx, B, H, Lq, Lk, nb, s0, s1, s2, s3, st);
+        case CREAM_F64: return launch_gather<8>(y, in, idx, B, H, Lq, Lk, nb, s0, s1, s2, s3, st);
+        default: return CREAM_ERR_BAD_DTYPE;
+    }
+}
+
+int cream_rpe_index_bwd(void* gin, const void* gout, const int32_t* idx, int B, int H, int Lq,
+                        int Lk, int nb, int dtype, void* stream)
+{
+    if (B < 0 || H < 0 || Lq < 0 || Lk < 0 || nb < 0) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)B * H * Lq * Lk == 0 || nb == 0) return CREAM_OK; // nothing to add
+    if (!gin || !gout || !idx) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)B * H > INT32_MAX) return CREAM_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case CREAM_F32: return launch_scatter<float>(gin, gout, idx, B, H, Lq, Lk, nb, st);
+        case CREAM_F16: return launch_scatter<__half>(gin, gout, idx, B, H, Lq, Lk, nb, st);
+        case CREAM_BF16: return launch_scatter<hip_bfloat16>(gin, gout, idx, B, H, Lq, Lk, nb, st);
+        case CREAM_F64: return launch_scatter<double>(gin, gout, idx, B, H, Lq, Lk, nb, st);
+        default: return CREAM_ERR_BAD_DTYPE;
+    }
+}
+
+}  // extern "C"

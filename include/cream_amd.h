@@ -1,0 +1,84 @@
+/*
+ * cream_amd.h — C ABI of libcream_amd.so (MI355X / gfx950 hot path of microsoft/Cream).
+ *
+ * Every entry point is `extern "C"`, takes plain device/host pointers, sizes and a
+ * `hipStream_t` passed as `void*`, returns 0 on success or a negative CREAM_ERR_* code,
+ * never throws, never synchronises, never allocates device memory.  No torch types.
+ *
+ * Each declaration cites the reference interface (file:line under the reference
+ * checkout) that it replaces.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add on top of this header.
+ */
+#ifndef CREAM_AMD_H_
+#define CREAM_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define CREAM_OK               0
+#define CREAM_ERR_BAD_ARG     -1  /* null pointer, negative size, unsupported stride    */
+#define CREAM_ERR_BAD_DTYPE   -2  /* dtype enum not supported by this entry point        */
+#define CREAM_ERR_LAUNCH      -3  /* hipLaunchKernel reported an error (see hipGetLastError) */
+#define CREAM_ERR_TOO_LARGE   -4  /* shape exceeds what the kernel family supports       */
+
+/* ---- element types (the "dtype" argument) ------------------------------------------ */
+#define CREAM_F32   0
+#define CREAM_F16   1
+#define CREAM_BF16  2   /* not in the reference (AT_DISPATCH_FLOATING_TYPES_AND_HALF only) */
+#define CREAM_F64   3
+
+/* Version handshake.  Replaces `version()` of the pybind module `rpe_index_cpp`
+ * (iRPE/DeiT-with-iRPE/rpe_ops/rpe_index.cpp:126-128; asserted == "1.2.0" at
+ * rpe_ops/rpe_index.py:5-8).  Returns a static string. */
+const char* cream_version(void);
+
+/* Build tag of this library ("gfx950;hipcc ...") for logs. */
+const char* cream_build_info(void);
+
+/* ---- rpe_index: bucketed relative-position gather / scatter ----------------------- */
+
+/* Y[b,h,i,j] = in[b,h,i, idx[i,j]]          (device pointers)
+ * Replaces rpe_index_forward_gpu + rpe_index_forward_gpu_kernel
+ * (iRPE/DeiT-with-iRPE/rpe_ops/rpe_index_cuda.cu:24-40,54-94).
+ *   y    : (B,H,Lq,Lk) contiguous, caller-allocated
+ *   in   : (B,H,Lq,nb) with ELEMENT strides s0..s3 (the reference passes
+ *          input.strides(), rpe_index_cuda.cu:76,91 — iRPE hands over a transposed
+ *          view, irpe.py:639-642)
+ *   idx  : (Lq,Lk) contiguous int32 in [0,nb)  (not range-checked, as in the reference)
+ * Pure data movement: results are bit-exact for every dtype. */
+int cream_rpe_index_fwd(void* y, const void* in, const int32_t* idx,
+                        int B, int H, int Lq, int Lk, int nb,
+                        int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+                        int dtype, void* stream);
+
+/* gin[b,h,i,u] += sum_{j : idx[i,j]==u} gout[b,h,i,j]     (device pointers)
+ * Replaces rpe_index_backward_gpu + rpe_index_backward_gpu_kernel
+ * (rpe_index_cuda.cu:42-52,96-140).  `gin` is updated in place exactly like the
+ * reference (the caller zero-fills it, rpe_ops/rpe_index.py:51); all three tensors
+ * contiguous.  Unlike the reference's global atomics the summation order is FIXED:
+ * gin_initial + g[j=0] + g[j=1] + ... in ascending j — bit-reproducible, and
+ * bit-identical to a sequential CPU loop for f32/f64.  f16/bf16 accumulate in f32
+ * and round once. */
+int cream_rpe_index_bwd(void* gin, const void* gout, const int32_t* idx,
+                        int B, int H, int Lq, int Lk, int nb,
+                        int dtype, void* stream);
+
+/* Host (CPU-tensor) entry points — the reference module also exports forward_cpu /
+ * backward_cpu (rpe_index.cpp:8-73, 82-124) and BASELINE config 1 runs on them.
+ * These are a separate implementation for HOST pointers, multi-threaded with
+ * std::thread over (b,h,i) rows; they are never used for device tensors.
+ * Same contracts as above (host fwd requires contiguous `in`, like the reference's
+ * input.contiguous() at rpe_index.cpp:28). */
+int cream_rpe_index_fwd_host(void* y, const void* in, const int32_t* idx,
+                             int B, int H, int Lq, int Lk, int nb, int dtype);
+int cream_rpe_index_bwd_host(void* gin, const void* gout, const int32_t* idx,
+                             int B, int H, int Lq, int Lk, int nb, int dtype);
+
+#ifdef __cplusplus
+}  /* extern "C" */
+#endif
+#endif  /* CREAM_AMD_H_ */
