@@ -35,7 +35,7 @@ SIGNATURES = {
     "cream_version": (_c.c_char_p, []),
     "cream_build_info": (_c.c_char_p, []),
     "cream_rpe_index_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _vp]),
-    "cream_rpe_index_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cream_rpe_index_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cream_rpe_index_fwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "cream_rpe_index_bwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
 }
@@ -52,6 +52,10 @@ def load():
         raise CreamLibraryError(
             f"cream_amd: {LIB_PATH} is missing — build it with `python -m cream_amd.build` "
             "(or __graft_entry__.build()).  There is no fallback path.")
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  It must be
+    # mapped FIRST so that this library binds to the runtime that owns torch's streams
+    # and allocations; two HIP runtimes in one process make every launch fail.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host

@@ -18,7 +18,7 @@
 //        WAVE-UNIFORM.  A wave owns 64 planes; tiles of gout are transposed through
 //        LDS (coalesced 16-byte HBM reads along j, conflict-free ds_read_b128 along
 //        planes), every lane adds its value into its private column of an LDS bin
-//        array with a conflict-free, non-returning ds_add — no cross-lane reduction,
+//        array with a conflict-free read-modify-write — no cross-lane reduction,
 //        no global atomics, and a FIXED ascending-j summation order (bit-identical to
 //        a sequential CPU loop for f32/f64).
 #include <hip/hip_runtime.h>
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void rpe_gather_rows(
 #pragma unroll
         for (int t = 0; t < NBT; ++t) {
             const int u = t * WAVE + lane;
-            if (NBT == 1 || u < nb_pad) table[u] = pre[t];
+            table[u] = pre[t];                 // table holds NBT*64 entries per wave
         }
         // issue the next plane's loads before consuming this one (latency hiding)
         if (p + 1 < p1) fetch_row(pre, row_ptr(p + 1));
@@ -193,14 +193,6 @@ template <> struct cvt<hip_bfloat16> {
     static __device__ __forceinline__ hip_bfloat16 store(float x) { return hip_bfloat16(x); }
 };
 
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    // non-returning LDS float add: ds_add_f32; every lane owns its own address
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_add(double* p, double v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // element-sized buffer load/store helpers (bounds-checked by the descriptor)
 template <int BYTES> struct bufop;
 template <> struct bufop<2> {
@@ -241,8 +233,10 @@ template <> struct bufop<8> {
 // fetched with ONE coalesced load and broadcast per key with v_readlane (wave-uniform).
 // All HBM traffic goes through two per-(wave,row) buffer descriptors whose extent ends
 // at the last valid plane: planes past BH read as zero / drop their stores in hardware,
-// so the loops carry no per-lane bounds branches.
-template <typename T, int CT>
+// so the loops carry no per-lane bounds branches.  PF tiles are kept in flight in
+// registers (the wave is the only latency-hiding unit it has: LDS limits a CU to ~7 of
+// these waves).
+template <typename T, int CT, int PF, bool ACCUM>
 __global__ __launch_bounds__(64) void rpe_scatter_planes(
     T* __restrict__ gin, const T* __restrict__ gout, const int32_t* __restrict__ idx,
     int BH, int Lq, int Lk, int nb, int rows_per_block)
@@ -274,80 +268,130 @@ __global__ __launch_bounds__(64) void rpe_scatter_planes(
     const int64_t plane_go = (int64_t)Lq * Lk;     // plane pitch of gout (elements)
     const int64_t plane_gi = (int64_t)Lq * nb;     // plane pitch of gin
 
-    union Pack { u32x4 vec; T e[V]; };
+    union Pack { u32x4 vec; T e[V]; E raw[V]; };
+    struct Stage { Pack p[NLD]; int32_t ids; };
 
     for (int i = i0; i < i1; ++i) {
-        // descriptors: base = (first plane of the wave, row i); extent = up to the end of
-        // row i of the LAST valid plane.
+        // descriptors: base = (first plane of the wave, row i); extent = EXACTLY up to the
+        // end of row i of the last valid plane (never over-reads the tensor).  Planes past
+        // BH are out of range: their loads return 0 and their stores are dropped.
         const T* go_base = gout + ((int64_t)pbase * Lq + i) * Lk;
         T* gi_base = gin + ((int64_t)pbase * Lq + i) * nb;
+        const int go_bytes = (int)(((int64_t)(nplanes - 1) * plane_go + Lk) * BYTES);
+        const int gi_bytes = (int)(((int64_t)(nplanes - 1) * plane_gi + nb) * BYTES);
         const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<T*>(go_base), 0,
-            (int)(((int64_t)(nplanes - 1) * plane_go + Lk) * BYTES), 0x00020000);
+            const_cast<T*>(go_base), 0, go_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(
-            gi_base, 0, (int)(((int64_t)(nplanes - 1) * plane_gi + nb) * BYTES), 0x00020000);
+            gi_base, 0, gi_bytes, 0x00020000);
 
-        auto load_tile = [&](Pack (&st)[NLD], int32_t& ids, int c0) {
-            ids = (lane < CT && c0 + lane < Lk) ? idx[(int64_t)i * Lk + c0 + lane] : 0;
+        auto load_tile = [&](Stage& st, int ch) {
+            const int c0 = ch * CT;
+            st.ids = (lane < CT && c0 + lane < Lk) ? idx[(int64_t)i * Lk + c0 + lane] : 0;
+            if (c0 + CT <= Lk) {
 #pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int r = t * RPI + lr;
-                st[t].vec = __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_go, (int)(((int64_t)r * plane_go + c0 + lc) * BYTES), 0, 0);
+                for (int t = 0; t < NLD; ++t)
+                    st.p[t].vec = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs_go, (int)(((int64_t)(t * RPI + lr) * plane_go + c0 + lc) * BYTES), 0, 0);
+            } else {
+                // tail tile of the row: 16-byte loads only where the whole vector lies inside
+                // the row; the straddling lane reads element-wise.  (The hardware range check
+                // is per dword: a dword crossing the end of the descriptor is dropped whole,
+                // which would lose the last 2-byte element of the last plane.)
+#pragma unroll
+                for (int t = 0; t < NLD; ++t) {
+                    const int off = (int)(((int64_t)(t * RPI + lr) * plane_go + c0 + lc) * BYTES);
+                    if (c0 + lc + V <= Lk) {
+                        st.p[t].vec = __builtin_amdgcn_raw_buffer_load_b128(rs_go, off, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            st.p[t].raw[v] = (c0 + lc + v < Lk)
+                                ? bufop<BYTES>::ld(rs_go, off + v * BYTES) : E(0);
+                    }
+                }
             }
         };
 
-        // bins <- current gin rows (the reference accumulates INTO grad_input).  Columns of
-        // planes beyond BH read as zero and only ever receive zeros.
-        for (int ub = 0; ub < nb; ub += WAVE) {
-            const int u = ub + lane;
-#pragma unroll 8
-            for (int r = 0; r < WAVE; ++r) {
-                union { E raw; T val; } c;
-                c.raw = (u < nb) ? bufop<BYTES>::ld(rs_gi, (int)((r * plane_gi + u) * BYTES)) : E(0);
-                if (u < nb) bins[u * BP + r] = cvt<T>::load(c.val);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        Pack stage[NLD];
-        int32_t ids_next;
-        load_tile(stage, ids_next, 0);
-        for (int ch = 0; ch < nchunk; ++ch) {
+        auto consume = [&](const Stage& st, int ch) {
             const int c0 = ch * CT;
-            const int32_t ids = ids_next;
-            // zero the keys past the row end (they belong to the next row), then
-            // registers -> LDS tile (row-wise, 16-byte writes)
+            // registers -> LDS tile (row-wise, 16-byte writes); keys past the row end were
+            // loaded as zero
 #pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int r = t * RPI + lr;
-                Pack pk = stage[t];
-                if (c0 + CT > Lk) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        if (c0 + lc + v >= Lk) pk.e[v] = T(0);
-                }
-                *reinterpret_cast<u32x4*>(tile + r * TP + lc) = pk.vec;
-            }
-            // next tile's HBM loads fly while this one is consumed
-            if (ch + 1 < nchunk) load_tile(stage, ids_next, c0 + CT);
+            for (int t = 0; t < NLD; ++t)
+                *reinterpret_cast<u32x4*>(tile + (t * RPI + lr) * TP + lc) = st.p[t].vec;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-
-            // plane-wise read-back: lane = plane, ascending key order.  Keys past Lk in the
-            // last tile are zero and carry bucket id 0: adding +0.0 is exact.
+            // plane-wise read-back: lane = plane, ascending key order, G keys per group.
+            // Each lane owns column `lane` of the bins, so a plain read-modify-write is
+            // race-free; the G bin reads of a group are issued together (one LDS round
+            // trip per group) and a key whose bucket already occurred in the group takes
+            // the running sum of that earlier key instead of the stale read — the compare
+            // is wave-uniform.  The writes retire in order, so the last sum of a bucket
+            // wins.  Net effect: exactly bin = ((bin + g[j0]) + g[j1]) + ... in ascending j.
+            // (Keys past Lk in the last tile are zero with bucket id 0; x + 0.0 is exact.)
 #pragma unroll
             for (int q = 0; q < LPR; ++q) {
                 Pack pk;
                 pk.vec = *reinterpret_cast<const u32x4*>(tile + lane * TP + q * V);
+                constexpr int G = V < 4 ? V : 4;       // keys per read-modify-write group
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const int u = __builtin_amdgcn_readlane(ids, q * V + v);
-                    lds_add(bins + u * BP + lane, cvt<T>::load(pk.e[v]));
+                for (int g0 = 0; g0 < V; g0 += G) {
+                    int u[G];
+                    ACC* slot[G];
+                    ACC sum[G];
+#pragma unroll
+                    for (int v = 0; v < G; ++v) {
+                        u[v] = __builtin_amdgcn_readlane(st.ids, q * V + g0 + v);
+                        slot[v] = bins + u[v] * BP + lane;
+                        sum[v] = *slot[v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < G; ++v) {
+                        ACC base = sum[v];
+#pragma unroll
+                        for (int w = 0; w < v; ++w)
+                            base = (u[w] == u[v]) ? sum[w] : base;  // latest earlier match wins
+                        sum[v] = base + (ACC)cvt<T>::load(pk.e[g0 + v]);
+                    }
+#pragma unroll
+                    for (int v = 0; v < G; ++v) *slot[v] = sum[v];
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        };
+
+        // first tiles of this row start flying before the bins are (re)initialised
+        Stage stage[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            if (k < nchunk) load_tile(stage[k], k);
+
+        if (ACCUM) {
+            // bins <- current gin rows (the reference accumulates INTO grad_input).
+            // Columns of planes beyond BH read as zero and only ever receive zeros.
+            for (int ub = 0; ub < nb; ub += WAVE) {
+                const int u = ub + lane;
+#pragma unroll 16
+                for (int r = 0; r < WAVE; ++r) {
+                    union { E raw; T val; } c;
+                    c.raw = (u < nb) ? bufop<BYTES>::ld(rs_gi, (int)((r * plane_gi + u) * BYTES)) : E(0);
+                    if (u < nb) bins[u * BP + r] = cvt<T>::load(c.val);
+                }
+            }
+        } else {
+            for (int u = lane; u < nb * BP; u += WAVE) bins[u] = ACC(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        for (int ch = 0; ch < nchunk; ch += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                if (ch + k < nchunk) {
+                    consume(stage[k], ch + k);
+                    if (ch + k + PF < nchunk) load_tile(stage[k], ch + k + PF);
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -396,22 +440,28 @@ __global__ __launch_bounds__(256) void rpe_scatter_generic(
 // ------------------------------------------------------------------------------------
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipGetLastError() is sticky per host thread: drop whatever an earlier, unrelated HIP
+// call left behind before launching, so that the code we return is about OUR launch.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH; }
+
 template <int BYTES>
 int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int Lq, int Lk,
                   int nb, int64_t s0, int64_t s1, int64_t s2, int64_t s3, hipStream_t st)
 {
     using E = typename raw_elem<BYTES>::type;
     constexpr int V = 16 / BYTES;
+    clear_stale_error();
     const int BH = B * H;
     const int nchunk = ceil_div(Lk, WAVE * V);
     const int nbt = ceil_div(nb, WAVE);
-    const int nb_pad = (nb + 7) & ~7;
+    const int nb_pad = nbt * WAVE;              // every lane stages unconditionally
     if (nchunk > 4 || nbt > 2) {
         const int64_t rows = (int64_t)BH * Lq;
         const int grid = (int)std::min<int64_t>(rows, 256 * 16);
         hipLaunchKernelGGL((rpe_gather_generic<BYTES>), dim3(grid), dim3(256), 0, st,
                            (E*)y, (const E*)in, idx, rows, H, Lq, Lk, s0, s1, s2, s3);
-        return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+        return launch_status();
     }
     // ~8 waves per SIMD across 256 CUs, but at least 8 planes per wave so that the
     // index registers are amortised.
@@ -442,15 +492,16 @@ int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int
         }
     }
 #undef CREAM_GATHER_CASE
-    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+    return launch_status();
 }
 
 template <typename T>
 int launch_scatter(void* gin, const void* gout, const int32_t* idx, int B, int H, int Lq,
-                   int Lk, int nb, hipStream_t st)
+                   int Lk, int nb, bool accumulate, hipStream_t st)
 {
     using ACC = typename cvt<T>::acc;
     constexpr int CT = 128 / (int)sizeof(T);     // 128-byte tile rows for every element size
+    clear_stale_error();
     constexpr int V = 16 / (int)sizeof(T);
     const int BH = B * H;
     const size_t lds = (size_t)WAVE * (CT + V) * sizeof(T) + (size_t)nb * (WAVE + 1) * sizeof(ACC);
@@ -459,18 +510,27 @@ int launch_scatter(void* gin, const void* gout, const int32_t* idx, int B, int H
     if (lds > 64 * 1024 || !fits32) {
         const int64_t rows = (int64_t)BH * Lq;
         const int grid = (int)std::min<int64_t>(ceil_div(rows * nb, 256), 256 * 32);
+        if (!accumulate) {
+            if (hipMemsetAsync(gin, 0, (size_t)rows * nb * sizeof(T), st) != hipSuccess)
+                return CREAM_ERR_LAUNCH;
+        }
         hipLaunchKernelGGL((rpe_scatter_generic<T>), dim3(grid), dim3(256), 0, st, (T*)gin,
                            (const T*)gout, idx, rows, Lq, Lk, nb);
-        return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+        return launch_status();
     }
     const int gx = ceil_div(BH, WAVE);
     // enough workgroups to give every CU several waves
     int want_y = std::max(1, (256 * 8) / gx);
     int rpb = std::max(1, ceil_div(Lq, want_y));
     const int gy = ceil_div(Lq, rpb);
-    hipLaunchKernelGGL((rpe_scatter_planes<T, CT>), dim3(gx, gy), dim3(WAVE), lds, st, (T*)gin,
-                       (const T*)gout, idx, BH, Lq, Lk, nb, rpb);
-    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+    constexpr int PF = 2;
+    if (accumulate)
+        hipLaunchKernelGGL((rpe_scatter_planes<T, CT, PF, true>), dim3(gx, gy), dim3(WAVE), lds, st,
+                           (T*)gin, (const T*)gout, idx, BH, Lq, Lk, nb, rpb);
+    else
+        hipLaunchKernelGGL((rpe_scatter_planes<T, CT, PF, false>), dim3(gx, gy), dim3(WAVE), lds, st,
+                           (T*)gin, (const T*)gout, idx, BH, Lq, Lk, nb, rpb);
+    return launch_status();
 }
 
 }  // namespace
@@ -496,18 +556,28 @@ int cream_rpe_index_fwd(void* y, const void* in, const int32_t* idx, int B, int 
 }
 
 int cream_rpe_index_bwd(void* gin, const void* gout, const int32_t* idx, int B, int H, int Lq,
-                        int Lk, int nb, int dtype, void* stream)
+                        int Lk, int nb, int dtype, int accumulate, void* stream)
 {
     if (B < 0 || H < 0 || Lq < 0 || Lk < 0 || nb < 0) return CREAM_ERR_BAD_ARG;
-    if ((int64_t)B * H * Lq * Lk == 0 || nb == 0) return CREAM_OK; // nothing to add
-    if (!gin || !gout || !idx) return CREAM_ERR_BAD_ARG;
-    if ((int64_t)B * H > INT32_MAX) return CREAM_ERR_TOO_LARGE;
+    if ((int64_t)B * H * Lq * nb == 0) return CREAM_OK;            // empty grad_input
+    if (!gin) return CREAM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if ((int64_t)Lk == 0) {                                         // nothing to add
+        if (!accumulate) {
+            const size_t es = dtype == CREAM_F64 ? 8 : dtype == CREAM_F32 ? 4 : 2;
+            if (hipMemsetAsync(gin, 0, (size_t)B * H * Lq * nb * es, st) != hipSuccess)
+                return CREAM_ERR_LAUNCH;
+        }
+        return CREAM_OK;
+    }
+    if (!gout || !idx) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)B * H > INT32_MAX) return CREAM_ERR_TOO_LARGE;
+    const bool acc = accumulate != 0;
     switch (dtype) {
-        case CREAM_F32: return launch_scatter<float>(gin, gout, idx, B, H, Lq, Lk, nb, st);
-        case CREAM_F16: return launch_scatter<__half>(gin, gout, idx, B, H, Lq, Lk, nb, st);
-        case CREAM_BF16: return launch_scatter<hip_bfloat16>(gin, gout, idx, B, H, Lq, Lk, nb, st);
-        case CREAM_F64: return launch_scatter<double>(gin, gout, idx, B, H, Lq, Lk, nb, st);
+        case CREAM_F32: return launch_scatter<float>(gin, gout, idx, B, H, Lq, Lk, nb, acc, st);
+        case CREAM_F16: return launch_scatter<__half>(gin, gout, idx, B, H, Lq, Lk, nb, acc, st);
+        case CREAM_BF16: return launch_scatter<hip_bfloat16>(gin, gout, idx, B, H, Lq, Lk, nb, acc, st);
+        case CREAM_F64: return launch_scatter<double>(gin, gout, idx, B, H, Lq, Lk, nb, acc, st);
         default: return CREAM_ERR_BAD_DTYPE;
     }
 }

@@ -82,8 +82,9 @@ def forward_gpu(input, index):
     return y
 
 
-def backward_gpu(grad_input, grad_output, index):
-    """rpe_index_backward_gpu (rpe_index_cuda.cu:96-140): accumulates INTO grad_input."""
+def backward_gpu(grad_input, grad_output, index, accumulate=True):
+    """rpe_index_backward_gpu (rpe_index_cuda.cu:96-140): accumulates INTO grad_input.
+    `accumulate=False` (extension) overwrites instead, for callers that own the buffer."""
     _check_bwd(grad_input, grad_output, index, gpu=True)
     code = _dtype_code(grad_output, "rpe_index_backward_gpu")
     nb = grad_input.size(3)
@@ -95,7 +96,7 @@ def backward_gpu(grad_input, grad_output, index):
     with torch.cuda.device(gout.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _lib.load().cream_rpe_index_bwd(grad_input.data_ptr(), gout.data_ptr(), idx.data_ptr(),
-                                             B, H, Lq, Lk, nb, code, stream)
+                                             B, H, Lq, Lk, nb, code, int(bool(accumulate)), stream)
     _lib.check(rc, "cream_rpe_index_bwd")
 
 
@@ -140,8 +141,13 @@ class RPEIndexFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         index = ctx.saved_tensors[0]
         if ctx.needs_input_grad[0]:
-            grad_input = grad_output.new_zeros(ctx.input_shape)
-            fn = backward_cpu if grad_output.device.type == "cpu" else backward_gpu
-            fn(grad_input, grad_output, index)
+            if grad_output.device.type == "cpu":
+                grad_input = grad_output.new_zeros(ctx.input_shape)
+                backward_cpu(grad_input, grad_output, index)
+            else:
+                # same result as new_zeros + accumulate (rpe_ops/rpe_index.py:51-54)
+                # without the memset and the re-read of grad_input
+                grad_input = grad_output.new_empty(ctx.input_shape)
+                backward_gpu(grad_input, grad_output, index, accumulate=False)
             return grad_input, None
         return None, None

@@ -55,17 +55,18 @@ int cream_rpe_index_fwd(void* y, const void* in, const int32_t* idx,
                         int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                         int dtype, void* stream);
 
-/* gin[b,h,i,u] += sum_{j : idx[i,j]==u} gout[b,h,i,j]     (device pointers)
+/* gin[b,h,i,u] (+)= sum_{j : idx[i,j]==u} gout[b,h,i,j]     (device pointers)
  * Replaces rpe_index_backward_gpu + rpe_index_backward_gpu_kernel
- * (rpe_index_cuda.cu:42-52,96-140).  `gin` is updated in place exactly like the
- * reference (the caller zero-fills it, rpe_ops/rpe_index.py:51); all three tensors
- * contiguous.  Unlike the reference's global atomics the summation order is FIXED:
+ * (rpe_index_cuda.cu:42-52,96-140).  accumulate != 0: `gin` is updated in place exactly
+ * like the reference (whose caller zero-fills it, rpe_ops/rpe_index.py:51);
+ * accumulate == 0: `gin` is overwritten and need not be initialised (saves the memset
+ * and one read of gin).  All three tensors contiguous.  Unlike the reference's global atomics the summation order is FIXED:
  * gin_initial + g[j=0] + g[j=1] + ... in ascending j — bit-reproducible, and
  * bit-identical to a sequential CPU loop for f32/f64.  f16/bf16 accumulate in f32
  * and round once. */
 int cream_rpe_index_bwd(void* gin, const void* gout, const int32_t* idx,
                         int B, int H, int Lq, int Lk, int nb,
-                        int dtype, void* stream);
+                        int dtype, int accumulate, void* stream);
 
 /* Host (CPU-tensor) entry points — the reference module also exports forward_cpu /
  * backward_cpu (rpe_index.cpp:8-73, 82-124) and BASELINE config 1 runs on them.

@@ -98,6 +98,20 @@ def test_bwd_16bit_accumulates_in_f32(shape, dt):
     np.testing.assert_array_equal(gin.cpu().float().numpy(), want.float().numpy())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_bwd_overwrite_mode_ignores_garbage(dt):
+    """accumulate=0 (C-ABI extension): grad_input need not be initialised."""
+    from cream_amd import rpe_index as R
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    gout = torch.randn(3, 5, 197, 197, generator=g).to(dt)
+    index = torch.randint(0, 50, (197, 197), generator=g, dtype=torch.int32)
+    gin = torch.full((3, 5, 197, 50), float("nan"), dtype=dt, device=dev)
+    R.backward_gpu(gin, gout.to(dev), index.to(dev), accumulate=False)
+    want = torch.from_numpy(O.bwd(gout.float().numpy(), index.numpy(), 50)).to(dt)
+    np.testing.assert_array_equal(gin.cpu().float().numpy(), want.float().numpy())
+
+
 def test_bwd_is_reproducible():
     from cream_amd import rpe_index as R
     dev = _dev()
@@ -154,7 +168,7 @@ def test_full_size_properties_config4():
     R.backward_gpu(gin, g, index)
     lhs = (y.double() * g.double()).sum().item()
     rhs = (x.double() * gin.double()).sum().item()
-    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))   # gin is f32-rounded
     del y, g
     ones = torch.ones(2, 1, L, L, device=dev)
     cnt = torch.zeros(2, 1, L, nb, device=dev)

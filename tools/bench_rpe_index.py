@@ -7,6 +7,10 @@ Prints achieved GB/s against the ALGORITHMIC bytes of SURVEY §8(d):
 """
 import argparse
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
@@ -51,9 +55,18 @@ def main():
         med, best = time_kernel(lambda: R.forward_gpu(x, index), a.iters, a.warmup)
         out.append(dict(kernel="rpe_index_fwd", dtype=str(dt), ms=med, ms_best=best,
                         bytes=bytes_alg, GBps=bytes_alg / med / 1e6, frac=bytes_alg / med / 1e6 / PEAK_HBM_GBS))
-        med, best = time_kernel(lambda: R.backward_gpu(gin, g, index), a.iters, a.warmup)
+        med, best = time_kernel(lambda: R.backward_gpu(gin, g, index, accumulate=False), a.iters, a.warmup)
         out.append(dict(kernel="rpe_index_bwd", dtype=str(dt), ms=med, ms_best=best,
                         bytes=bytes_alg, GBps=bytes_alg / med / 1e6, frac=bytes_alg / med / 1e6 / PEAK_HBM_GBS))
+        # calibration on the same buffers: what this box sustains for a pure write / a copy
+        y = torch.empty(B, H, L, L, device=dev, dtype=dt)
+        med, _ = time_kernel(lambda: y.fill_(1.0), a.iters, a.warmup)
+        out.append(dict(kernel="calib_fill", dtype=str(dt), ms=med, bytes=y.numel() * s, GBps=y.numel() * s / med / 1e6))
+        med, _ = time_kernel(lambda: y.copy_(g), a.iters, a.warmup)
+        out.append(dict(kernel="calib_copy", dtype=str(dt), ms=med, bytes=2 * y.numel() * s, GBps=2 * y.numel() * s / med / 1e6))
+        med, _ = time_kernel(lambda: g.sum(), a.iters, a.warmup)
+        out.append(dict(kernel="calib_read_sum", dtype=str(dt), ms=med, bytes=y.numel() * s, GBps=y.numel() * s / med / 1e6))
+        del y
         del x, g, gin
     for o in out:
         print(json.dumps(o))
