@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the AutoFormer-S supernet train step @224^2 on N MI355X.
+
+    python bench.py --gpus 1 --steps 40 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 40 --warmup 10
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in
+HBM: sample a random sub-network (random.seed(epoch) discipline, identical on all ranks),
+set_sample_config, forward (bf16 autocast), soft-target cross entropy, backward with the
+bucketed gradient all-reduce overlapped on a side stream, AdamW over the full supernet.
+Per-GPU batch 128 (AutoFormer/README.md:73-75) => weak scaling.  W untimed warm-up steps,
+then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks; rank 0
+prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     — the dominant hand-written kernel of the step, timed live with HIP events on
+                 its launch stream (cream_amd.timing) during the timed region
+  cpu_baseline — the oracle (CPU fp32 restatement of the reference step, oracle/) timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (README recipe: 128)")
+    ap.add_argument("--supernet", default="S", choices=["T", "S", "B"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "fused", "bucketed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, seconds):
+    """Reference step restated on the CPU (oracle/autoformer_oracle.py), fp32, all host
+    cores torch gives us, B=16, random sub-networks from the same draw sequence, AdamW over
+    the full supernet.  Bounded: warm-up 1 step, then steps until `seconds` have elapsed."""
+    import random
+    from oracle import autoformer_oracle as AO
+    from cream_amd.autoformer import engine
+    space = engine.SEARCH_SPACES[size]
+    B = 16
+    torch.manual_seed(0)
+    model = engine.build_supernet(size, drop_path_rate=0.0).float()      # parameter container
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    opt = torch.optim.AdamW(list(params.values()), lr=5e-4 * B / 512, weight_decay=0.05)
+    images = torch.randn(B, 3, 224, 224)
+    target = torch.zeros(B, 1000).scatter_(1, torch.randint(0, 1000, (B, 1)), 1.0)
+    random.seed(0)
+    n, t0, elapsed = 0, None, 0.0
+    while True:
+        cfg = AO.sample_configs(space["choices"])
+        opt.zero_grad(set_to_none=False)
+        loss = AO.soft_target_cross_entropy(AO.forward(params, cfg, images), target)
+        loss.backward()
+        opt.step()
+        if t0 is None:
+            t0 = time.perf_counter()         # first step = warm-up
+            continue
+        n += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= seconds or n >= 50:
+            break
+    return dict(value=round(n * B / elapsed, 2), unit="images/sec", cores=torch.get_num_threads(),
+                kind="port", sample=f"{n} AutoFormer-{size} supernet steps of batch {B} (fp32, oracle/autoformer_oracle.py)")
+
+
+def main():
+    a = parse()
+    from cream_amd import comm, timing
+    from cream_amd.autoformer import engine
+    rank, local, world = comm.init_distributed()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    # CPU baseline first (rank 0, N=1 only) so that it does not overlap GPU timing
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.supernet, a.cpu_seconds)
+
+    torch.manual_seed(0 + rank)                               # supernet_train.py:196-198
+    model = engine.build_supernet(a.supernet, drop_path_rate=0.1).to(dev)
+    for m in model.modules():
+        if hasattr(m, "attention_impl"):
+            m.attention_impl = a.impl
+    if world > 1:                                             # same initial weights everywhere
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    opt = engine.build_optimizer(model, lr=5e-4, batch_size=a.batch, world_size=world)
+    reducer = comm.GradReducer(model)
+    amp = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    trainer = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES[a.supernet]["choices"], reducer, amp_dtype=amp)
+
+    # synthetic ImageNet-shaped batch, generated on the device, resident before timing
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g)
+    labels = torch.randint(0, 1000, (a.batch,), device=dev, generator=g)
+    target = torch.full((a.batch, 1000), 0.1 / 1000, device=dev)
+    target[torch.arange(a.batch, device=dev), labels] += 0.9
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    trainer.start_epoch(0)
+    for _ in range(a.warmup):
+        loss = trainer.step(images, target)
+    sync()
+    timing.reset()
+    timing.enable(not a.no_kernel_timing)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(images, target)
+    sync()
+    dt = time.perf_counter() - t0
+    timing.enable(False)
+    assert torch.isfinite(loss).item(), "loss is not finite"     # supernet_engine.py:87-89
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        ksum = timing.summary() if not a.no_kernel_timing else {}
+        roof = None
+        if ksum:
+            # dominant hand-written kernel by total time in the timed region
+            name, st = max(ksum.items(), key=lambda kv: kv[1]["total_ms"])
+            if st["flops"] and not st["bytes"]:
+                peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+                ach = st["flops"] / (st["total_ms"] * 1e-3) / 1e12
+                roof = dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=None)
+            else:
+                ach = st["bytes"] / (st["total_ms"] * 1e-3) / 1e9
+                roof = dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+            roof["launches"] = st["launches"]
+            roof["avg_us"] = round(st["avg_ms"] * 1e3, 2)
+            roof["kernels"] = {k: dict(launches=v["launches"], avg_us=round(v["avg_ms"] * 1e3, 2),
+                                       total_ms=round(v["total_ms"], 3)) for k, v in sorted(ksum.items())}
+        line = {
+            "metric": f"images/sec (whole node) AutoFormer-{a.supernet} supernet step @224^2",
+            "value": round(a.steps * a.batch * world / dt, 1),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"AutoFormer-{a.supernet} supernet train step, random-path sampling "
+                                   f"(random.seed(epoch)), per-GPU batch {a.batch}, 224x224, AdamW, "
+                                   f"grad all-reduce RCCL", "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}", "attention_impl": a.impl},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""Supernet step driver — host-side mirror of AutoFormer/supernet_engine.py:13-107 and of
+the model / optimizer construction in AutoFormer/supernet_train.py:255-298.
+
+Per step (supernet_engine.py:49-102): draw a random sub-network with CPython's `random`
+(seeded per epoch with `random.seed(epoch)`, so every rank draws the SAME architecture),
+`set_sample_config`, forward under autocast, soft-target cross entropy, zero_grad,
+backward, optimizer step.  The reference trains under fp16 autocast + loss scaling;
+here the compute dtype is bf16 (no scaler needed), or fp32 for parity runs.
+
+timm (Mixup, SoftTargetCrossEntropy, create_optimizer, NativeScaler) is a third-party
+dependency of the reference that is not vendored; the pieces used by the step are
+restated from their published definitions (soft-target CE, AdamW with timm's
+no-weight-decay rule) — their parity is unpinned, see DESIGN.md.
+"""
+import random
+
+import torch
+import torch.nn.functional as F
+
+from .supernet import Vision_TransformerSuper
+
+# AutoFormer/experiments/supernet/supernet-{T,S,B}.yaml
+SEARCH_SPACES = {
+    'T': dict(embed_dim=256, depth=14, num_heads=4, mlp_ratio=4.0,
+              choices=dict(mlp_ratio=[3.5, 4], num_heads=[3, 4], depth=[12, 13, 14], embed_dim=[192, 216, 240])),
+    'S': dict(embed_dim=448, depth=14, num_heads=7, mlp_ratio=4.0,
+              choices=dict(mlp_ratio=[3.0, 3.5, 4.0], num_heads=[5, 6, 7], depth=[12, 13, 14],
+                           embed_dim=[320, 384, 448])),
+    'B': dict(embed_dim=640, depth=16, num_heads=10, mlp_ratio=4.0,
+              choices=dict(mlp_ratio=[3.0, 3.5, 4.0], num_heads=[8, 9, 10], depth=[14, 15, 16],
+                           embed_dim=[528, 576, 624])),
+}
+
+
+def sample_configs(choices):
+    """supernet_engine.py:13-24.  Draw order: depth, mlp_ratio x depth, num_heads x depth,
+    then ONE embed_dim shared by all layers."""
+    depth = random.choice(choices['depth'])
+    config = {dim: [random.choice(choices[dim]) for _ in range(depth)] for dim in ('mlp_ratio', 'num_heads')}
+    config['embed_dim'] = [random.choice(choices['embed_dim'])] * depth
+    config['layer_num'] = depth
+    return config
+
+
+def build_supernet(size='S', drop_path_rate=0.1, num_classes=1000, img_size=224, **overrides):
+    """Vision_TransformerSuper as constructed by supernet_train.py:255-265 with the README
+    recipe flags (--gp --change_qkv --relative_position, drop-path 0.1, drop 0.0)."""
+    s = SEARCH_SPACES[size]
+    kw = dict(img_size=img_size, patch_size=16, embed_dim=s['embed_dim'], depth=s['depth'],
+              num_heads=s['num_heads'], mlp_ratio=s['mlp_ratio'], qkv_bias=True, drop_rate=0.0,
+              drop_path_rate=drop_path_rate, gp=True, num_classes=num_classes, max_relative_position=14,
+              relative_position=True, change_qkv=True, abs_pos=True)
+    kw.update(overrides)
+    return Vision_TransformerSuper(**kw)
+
+
+def soft_target_cross_entropy(logits, target):
+    """timm.loss.SoftTargetCrossEntropy: mean_b sum_c -t[b,c] log_softmax(x)[b,c] (fp32)."""
+    return torch.sum(-target * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()
+
+
+def param_groups(model, weight_decay=0.05):
+    """timm.optim.optim_factory.add_weight_decay as called by create_optimizer: 1-D tensors,
+    biases and the names in model.no_weight_decay() get no decay.  (The reference's skip
+    list contains 'rel_pos_embed', which matches no parameter name exactly, so the
+    relative-position tables ARE decayed — reproduced.)"""
+    skip = model.no_weight_decay() if hasattr(model, 'no_weight_decay') else set()
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.dim() <= 1 or name.endswith('.bias') or name in skip) else decay).append(p)
+    return [{'params': no_decay, 'weight_decay': 0.0}, {'params': decay, 'weight_decay': weight_decay}]
+
+
+def build_optimizer(model, lr=5e-4, batch_size=128, world_size=1, weight_decay=0.05):
+    """AdamW with the linear lr scaling of supernet_train.py:294: lr * batch * world / 512."""
+    scaled = lr * batch_size * world_size / 512.0
+    fused = next(model.parameters()).is_cuda
+    return torch.optim.AdamW(param_groups(model, weight_decay), lr=scaled, betas=(0.9, 0.999), eps=1e-8,
+                             fused=fused)
+
+
+class SupernetTrainer:
+    """One process = one GPU.  `step(images, target)` is the body of the reference's hot
+    loop; gradient averaging across ranks goes through `reducer` (cream_amd.comm)."""
+
+    def __init__(self, model, optimizer, choices, reducer=None, amp_dtype=torch.bfloat16, max_norm=0.0):
+        self.model = model
+        self.optimizer = optimizer
+        self.choices = choices
+        self.reducer = reducer
+        self.amp_dtype = amp_dtype
+        self.max_norm = max_norm
+        self.config = None
+
+    def start_epoch(self, epoch):
+        # supernet_engine.py:36 — identical seed on every rank => identical sub-networks
+        random.seed(epoch)
+        self.model.train()
+
+    def sample(self):
+        self.config = sample_configs(self.choices)
+        self.model.set_sample_config(self.config)
+        return self.config
+
+    def forward_backward(self, images, target):
+        dev = images.device.type
+        use_amp = self.amp_dtype is not None and self.amp_dtype != torch.float32
+        # zero-fill rather than None: under torch 1.7 (the reference's pin) zero_grad()
+        # keeps the tensors, so every parameter that was active once keeps receiving
+        # weight decay and moment decay
+        if self.reducer is not None:
+            self.reducer.zero_grad()                 # one memset per bucket
+            self.reducer.prepare(self.config)
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+        with torch.autocast(device_type=dev, dtype=self.amp_dtype, enabled=use_amp):
+            logits = self.model(images)
+            loss = soft_target_cross_entropy(logits, target)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        return loss
+
+    def step(self, images, target):
+        self.sample()
+        loss = self.forward_backward(images, target)
+        if self.max_norm and self.max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        self.optimizer.step()
+        return loss

@@ -1,0 +1,148 @@
+"""Per-step gradient averaging across the GPUs of one node — the data-parallel exchange of
+the supernet step (reference: implicit in torch DistributedDataParallel,
+AutoFormer/supernet_train.py:286-289, `find_unused_parameters=True`).
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
+for the CPU tests).  Design points, MI355X-first rather than DDP-reducer-first:
+
+  * gradients live in flat fp32 bucket buffers from the start (`p.grad` are views), one
+    bucket per transformer block plus stem and tail — a bucket is a single large,
+    contiguous RCCL message (supernet-S: ~10 MB per block) and its completion is a
+    per-layer event, not a 25 MB size threshold;
+  * a bucket's all-reduce is launched from a post-accumulate-grad hook the moment its last
+    gradient has been written, on a dedicated side stream that waits on an event of the
+    compute stream — communication of block i overlaps backward of blocks i-1..0;
+  * every rank samples the SAME sub-network (random.seed(epoch), supernet_engine.py:36),
+    so the set of parameters that receive gradients is known up front: blocks beyond the
+    sampled depth are not "unused parameters" to be discovered, their buckets are simply
+    not sent (their gradients stay exactly zero on every rank).  No dead bytes on xGMI.
+  * averaging = SUM all-reduce followed by an in-place 1/world scale of the flat buffer
+    (DDP semantics; lr is already scaled by the world size, supernet_train.py:294).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, process_group=None, bucket_of=None):
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.device = self.params[0][1].device
+        self.on_gpu = self.device.type == "cuda"
+        bucket_of = bucket_of or self._default_bucket_of
+        names = []
+        for n, _ in self.params:
+            b = bucket_of(n)
+            if b not in names:
+                names.append(b)
+        self.bucket_names = names
+        self.members = {b: [] for b in names}
+        for n, p in self.params:
+            self.members[bucket_of(n)].append((n, p))
+        # flat buffers; p.grad become views (zero-filled)
+        self.flat = {}
+        for b, mem in self.members.items():
+            total = sum(p.numel() for _, p in mem)
+            buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+            off = 0
+            for _, p in mem:
+                p.grad = buf[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat[b] = buf
+        self.bucket_index = {id(p): b for b, mem in self.members.items() for _, p in mem}
+        self.pending = {}
+        self.works = []
+        self.active = set()
+        self.bytes_sent = 0
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        if self.world > 1:
+            for _, p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    @staticmethod
+    def _default_bucket_of(name):
+        parts = name.split(".")
+        if parts[0] == "blocks":
+            return f"block{int(parts[1]):02d}"
+        if parts[0] in ("norm", "head"):
+            return "tail"
+        return "stem"
+
+    # ------------------------------------------------------------------ per step
+    def zero_grad(self):
+        """Zero-fill (not None, see engine.SupernetTrainer) — one memset per bucket."""
+        for buf in self.flat.values():
+            buf.zero_()
+
+    def prepare(self, config=None):
+        """Call after zero_grad and before forward.  `config` is the sampled architecture
+        (same on all ranks); blocks >= layer_num will not produce gradients."""
+        self.works = []
+        self.bytes_sent = 0
+        depth = config["layer_num"] if config is not None else None
+        self.active = set()
+        self.pending = {}
+        for b, mem in self.members.items():
+            if depth is not None and b.startswith("block") and int(b[5:]) >= depth:
+                continue
+            self.active.add(b)
+            self.pending[b] = len(mem)
+
+    def _hook(self, p):
+        b = self.bucket_index[id(p)]
+        if b not in self.pending:
+            return
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        buf = self.flat[b]
+        self.bytes_sent += buf.numel() * 4
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+                buf.mul_(1.0 / self.world)
+        else:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.works.append((w, buf))
+
+    def finish(self):
+        """Call after backward, before the optimizer step."""
+        if self.world == 1:
+            return
+        # buckets whose hooks did not all fire (should not happen) are flushed here so that
+        # ranks can never diverge silently
+        for b, left in list(self.pending.items()):
+            if left > 0:
+                self.pending[b] = 0
+                self._launch(b)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        else:
+            for w, buf in self.works:
+                w.wait()
+                buf.mul_(1.0 / self.world)
+        self.works = []
+
+
+def init_distributed(backend=None):
+    """torch.distributed bootstrap from the torchrun environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), as AutoFormer/lib/utils.py:209-235 does for the reference.
+    Returns (rank, local_rank, world)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.barrier()
+    return rank, local, world

@@ -14,7 +14,7 @@ bf16 is supported in addition to the reference's float/double/half.
 """
 import torch
 
-from . import _lib
+from . import _lib, timing
 
 _DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16,
            torch.bfloat16: _lib.BF16, torch.float64: _lib.F64}
@@ -74,7 +74,9 @@ def forward_gpu(input, index):
     Lq, Lk = index.size(0), index.size(1)
     y = torch.empty((B, H, Lq, Lk), dtype=input.dtype, device=input.device)
     s0, s1, s2, s3 = input.stride()
-    with torch.cuda.device(input.device):
+    es = input.element_size()
+    nbytes = B * H * Lq * (nb + Lk) * es + Lq * Lk * 4       # SURVEY §8(d) algorithmic bytes
+    with torch.cuda.device(input.device), timing.region("rpe_index_fwd", nbytes):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _lib.load().cream_rpe_index_fwd(y.data_ptr(), input.data_ptr(), index.data_ptr(),
                                              B, H, Lq, Lk, nb, s0, s1, s2, s3, code, stream)
@@ -93,7 +95,9 @@ def backward_gpu(grad_input, grad_output, index, accumulate=True):
     _assert(tuple(index.shape) == (Lq, Lk), "index shape mismatch")
     gout = grad_output.contiguous()
     idx = index.contiguous()
-    with torch.cuda.device(gout.device):
+    es = gout.element_size()
+    nbytes = B * H * Lq * (nb + Lk) * es + Lq * Lk * 4
+    with torch.cuda.device(gout.device), timing.region("rpe_index_bwd", nbytes):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _lib.load().cream_rpe_index_bwd(grad_input.data_ptr(), gout.data_ptr(), idx.data_ptr(),
                                              B, H, Lq, Lk, nb, code, int(bool(accumulate)), stream)

@@ -1,0 +1,203 @@
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF
+(imported read-only from /root/reference through tests/refshim.py) on seeded inputs.
+
+    python tests/golden/make_golden.py            # needs /root/reference; CPU, ~2 min
+
+The fixtures are small (digests, a few full tensors) and are committed; /root/reference
+does not exist on the GPU box, so `-m gpu` tests, smoke() and bench.py only ever read
+these files.  Weights are not stored: fixture_utils.fill_params regenerates them from
+seeds on both sides.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import refshim  # noqa: E402
+from fixture_utils import (SUBNET_S, SUBNET_T, SUPERNETS, fill_params, grad_digest, make_batch,  # noqa: E402
+                           model_kwargs)
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"wrote {name}: {sum(a.nbytes for a in out.values()) / 1e3:.1f} kB")
+
+
+def autoformer():
+    ref = refshim.load_autoformer_reference()
+    sample_configs = refshim.reference_sample_configs()
+    kat = {}
+    # --- parameter-count KATs (README 5.8M / 22.9M / 53.7M) and supernet totals
+    for size, sub in (('T', SUBNET_T), ('S', SUBNET_S)):
+        m = ref.Vision_TransformerSuper(**model_kwargs(size))
+        kat[f'subnet_{size}_params'] = int(m.get_sampled_params_numel(sub))
+        kat[f'supernet_{size}_params'] = int(sum(p.numel() for p in m.parameters()))
+        kat[f'supernet_{size}_state_keys'] = sorted(m.state_dict().keys())
+        kat[f'supernet_{size}_complexity'] = float(m.get_complexity(196))
+        # golden sample_configs draws: random.seed(epoch) discipline of supernet_engine.py:36
+        for epoch in (0, 1, 7):
+            random.seed(epoch)
+            kat[f'draws_{size}_epoch{epoch}'] = [sample_configs(SUPERNETS[size]['choices']) for _ in range(3)]
+    mB = ref.Vision_TransformerSuper(**model_kwargs('B'))
+    kat['supernet_B_params'] = int(sum(p.numel() for p in mB.parameters()))
+    # --- relative index tables of RelativePosition2D_super at N=197
+    rp = ref.RelativePosition2D_super(64, 14)
+    rp.set_sample_config(64)
+    with torch.no_grad():
+        rp.embeddings_table_v.copy_(torch.arange(30).float().view(30, 1).expand(30, 64))
+        rp.embeddings_table_h.zero_()
+        fv = rp(197, 197)[..., 0].long()
+        rp.embeddings_table_h.copy_(torch.arange(30).float().view(30, 1).expand(30, 64))
+        rp.embeddings_table_v.zero_()
+        fh = rp(197, 197)[..., 0].long()
+    kat['rel_index_sum_v'] = int(fv.sum())
+    kat['rel_index_sum_h'] = int(fh.sum())
+    save('autoformer_rel_index.npz', iv=fv.to(torch.uint8), ih=fh.to(torch.uint8))
+    json.dump(kat, open(os.path.join(HERE, 'autoformer_kat.json'), 'w'), indent=1)
+    print("wrote autoformer_kat.json")
+
+    # --- one full step (fwd + bwd, fp32, dropout/drop-path 0) per supernet size
+    for size, batch, cfg in (('T', 2, None), ('S', 1, SUBNET_S)):
+        torch.manual_seed(0)
+        m = ref.Vision_TransformerSuper(**model_kwargs(size))
+        fill_params(m, seed=3)
+        if cfg is None:
+            random.seed(0)
+            cfg = sample_configs(SUPERNETS[size]['choices'])     # supernet-T: depth 13, E=216
+        m.set_sample_config(cfg)
+        m.train()
+        images, target = make_batch(batch, seed=5)
+        logits = m(images)
+        loss = torch.sum(-target * torch.log_softmax(logits, dim=-1), dim=-1).mean()
+        loss.backward()
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+        full = {}
+        for k in ('cls_token', 'head.bias', 'norm.weight', 'blocks.0.attn.qkv.bias',
+                  'blocks.0.attn.rel_pos_embed_k.embeddings_table_v', 'blocks.0.attn.rel_pos_embed_k.embeddings_table_h',
+                  'blocks.0.attn.rel_pos_embed_v.embeddings_table_v', 'blocks.0.attn.rel_pos_embed_v.embeddings_table_h',
+                  f'blocks.{cfg["layer_num"] - 1}.attn.rel_pos_embed_k.embeddings_table_h',
+                  f'blocks.{cfg["layer_num"] - 1}.fc1.bias'):
+            full['full|' + k] = grads[k]
+        save(f'autoformer_{size}_step.npz', logits=logits, loss=loss.reshape(1),
+             config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **grad_digest(grads), **full)
+
+    # --- AttentionSuper alone (awkward widths: in 216, 3 heads of the super 4)
+    torch.manual_seed(0)
+    att = ref.AttentionSuper(256, num_heads=4, qkv_bias=True, relative_position=True, change_qkv=True,
+                             max_relative_position=14)
+    fill_params(att, seed=11)
+    att.set_sample_config(sample_q_embed_dim=192, sample_num_heads=3, sample_in_embed_dim=216)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 197, 216, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 216, generator=g)
+    y = att(x)
+    y.backward(gy)
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in att.named_parameters()}
+    save('autoformer_attention.npz', y=y, dx=x.grad,
+         **{'full|' + k: v for k, v in grads.items() if 'embeddings_table' in k or k.endswith('bias')},
+         **grad_digest(grads))
+
+
+def irpe():
+    irpe = refshim.load_irpe_reference(with_dropin=False)
+    # --- bucket id tables (int, must be bit-exact).  (method, ratio, H, W, skip)
+    cases = [('product', 1.9, 14, 14, 1), ('product', 1.9, 24, 24, 1), ('product', 1.9, 7, 10, 0),
+             ('euc', 20, 14, 14, 1), ('euc', 1.9, 9, 5, 2), ('quant', 51, 14, 14, 1), ('quant', 1.9, 6, 6, 0),
+             ('cross_rows', 56, 14, 14, 1), ('cross_cols', 56, 14, 14, 1), ('cross_rows', 1.9, 5, 8, 0),
+             ('product', 3.0, 12, 12, 1), ('euc', 7.5, 24, 24, 1)]
+    meth = dict(product=irpe.METHOD.PRODUCT, euc=irpe.METHOD.EUCLIDEAN, quant=irpe.METHOD.QUANT,
+                cross_rows=irpe.METHOD.CROSS_ROWS, cross_cols=irpe.METHOD.CROSS_COLS)
+    out, meta = {}, []
+    for (name, ratio, h, w, skip) in cases:
+        alpha, beta, gamma = 1 * ratio, 2 * ratio, 8 * ratio
+        ids, nb = irpe.get_bucket_ids_2d(meth[name], h, w, skip, alpha, beta, gamma, dtype=torch.long)
+        key = f'{name}_{ratio}_{h}x{w}_s{skip}'
+        ids = ids.numpy()
+        meta.append(dict(key=key, method=name, ratio=ratio, h=h, w=w, skip=skip, num_buckets=int(nb),
+                         sum=int(ids.sum()), shape=list(ids.shape)))
+        if ids.shape[0] <= 200:
+            out[key] = ids.astype(np.uint8 if nb < 256 else np.int16)
+        else:   # 577x577: keep the checksum plus every 16th row
+            out[key + '|rows16'] = ids[::16].astype(np.uint8)
+    # piecewise_index on a dense integer and float grid (rounding-sensitive: half-to-even, float beta clip)
+    xs = torch.arange(-64, 65)
+    for ratio in (1.9, 3.0, 7.5, 20, 51):
+        out[f'piecewise_int_{ratio}'] = irpe.piecewise_index(xs, ratio, 2 * ratio, 8 * ratio, torch.long).numpy().astype(np.int16)
+        xf = torch.arange(0, 400).float().sqrt().round()
+        out[f'piecewise_flt_{ratio}'] = irpe.piecewise_index(xf, ratio, 2 * ratio, 8 * ratio, torch.long).numpy().astype(np.int16)
+    json.dump(meta, open(os.path.join(HERE, 'irpe_buckets.json'), 'w'), indent=1)
+    save('irpe_buckets.npz', **out)
+
+    # --- iRPE modules: forward + grads, contextual {q,k}:transposed, v:non-transposed, bias mode
+    outs = {}
+    for tag, kw in (('ctx_shared', dict(mode='ctx', shared_head=True)), ('ctx_perhead', dict(mode='ctx', shared_head=False)),
+                    ('bias_perhead', dict(mode='bias', shared_head=False))):
+        rpe_on = 'qkv' if kw['mode'] == 'ctx' else 'qk'
+        cfg = irpe.get_rpe_config(ratio=1.9, method='product', skip=1, rpe_on=rpe_on, **kw)
+        mods = irpe.build_rpe(cfg, head_dim=64, num_heads=3)
+        g = torch.Generator().manual_seed(31)
+        for which, mod in zip('qkv', mods):
+            if mod is None:
+                continue
+            with torch.no_grad():
+                for p in mod.parameters():
+                    p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            if which == 'v':
+                x = torch.randn(2, 3, 197, 197, generator=g).softmax(-1).requires_grad_()
+            else:
+                x = torch.randn(2, 3, 197, 64, generator=g, requires_grad=True)
+            y = mod(x)
+            gy = torch.randn(y.shape, generator=g)
+            grads = torch.autograd.grad(y, [x] + list(mod.parameters()), gy, allow_unused=True)
+            outs[f'{tag}|{which}|y'] = y[:, :, ::7, ::5] if y.shape[-1] == 197 else y[:, :, ::7]
+            outs[f'{tag}|{which}|ysum'] = y.double().sum().reshape(1)
+            if grads[0] is not None:
+                outs[f'{tag}|{which}|dx'] = grads[0][:, :, ::7, ::5] if grads[0].shape[-1] == 197 else grads[0][:, :, ::7]
+                outs[f'{tag}|{which}|dxsum'] = grads[0].double().sum().reshape(1)
+            outs[f'{tag}|{which}|dw'] = grads[1]
+    save('irpe_modules.npz', **outs)
+
+    # --- RPEAttention + DeiT-tiny iRPE-K (BASELINE config 1): single image forward on CPU
+    irpe2, rvt, models, rpe_models = refshim.load_irpe_models()
+    torch.manual_seed(0)
+    model = rpe_models.deit_tiny_patch16_224_ctx_product_50_shared_k()
+    fill_params(model, seed=17)
+    model.eval()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        logits = model(x)
+    save('deit_tiny_irpe_k.npz', logits=logits, n_params=np.array([sum(p.numel() for p in model.parameters())]))
+    # RPEAttention fwd/bwd, rpe on q, k and v
+    cfg = irpe2.get_rpe_config(ratio=1.9, method='product', mode='ctx', shared_head=True, skip=1, rpe_on='qkv')
+    att = rvt.RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg)
+    fill_params(att, seed=19)
+    with torch.no_grad():
+        for n, p in att.named_parameters():
+            if 'lookup_table' in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))))
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 197, 192, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 192, generator=g)
+    y = att(x)
+    y.backward(gy)
+    grads = {k: p.grad for k, p in att.named_parameters()}
+    save('irpe_attention.npz', y=y, dx=x.grad, **{'full|' + k: v for k, v in grads.items() if 'lookup' in k or k.endswith('bias')},
+         **grad_digest(grads))
+
+
+if __name__ == '__main__':
+    assert refshim.have_reference(), "needs the reference checkout at /root/reference"
+    which = sys.argv[1:] or ['autoformer', 'irpe']
+    if 'autoformer' in which:
+        autoformer()
+    if 'irpe' in which:
+        irpe()

@@ -1,0 +1,177 @@
+"""AutoFormer hot path on the CPU: (1) the oracle is pinned against golden vectors that the
+reference itself produced; (2) the product's host-side modules (same classes that run on
+the GPU, here on host tensors through the C ABI's *_host entry points) reproduce them."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import check_against_fixture, config_of, load_json, load_npz, max_rel
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from fixture_utils import SUBNET_S, SUBNET_T, SUPERNETS, fill_params, make_batch, model_kwargs  # noqa: E402
+
+from oracle import autoformer_oracle as AO  # noqa: E402
+
+KAT = load_json("autoformer_kat.json")
+
+
+# ---------------------------------------------------------------- oracle pinned to the reference
+def test_oracle_sample_configs_golden_draws():
+    for size in ("T", "S"):
+        for epoch in (0, 1, 7):
+            random.seed(epoch)
+            got = [AO.sample_configs(SUPERNETS[size]["choices"]) for _ in range(3)]
+            assert got == KAT[f"draws_{size}_epoch{epoch}"]
+    # SURVEY Appendix C.1
+    random.seed(0)
+    c = AO.sample_configs(SUPERNETS["S"]["choices"])
+    assert c["layer_num"] == 13 and c["embed_dim"][0] == 448
+    assert c["num_heads"] == [6, 5, 5, 7, 6, 7, 7, 7, 5, 6, 5, 7, 5]
+
+
+def test_oracle_rel_index_tables():
+    fix = load_npz("autoformer_rel_index.npz")
+    _, fv, fh = AO.rel_pos_embeddings(torch.zeros(30, 4), torch.zeros(30, 4), 197, 14)
+    assert np.array_equal(fv.numpy(), fix["iv"]) and np.array_equal(fh.numpy(), fix["ih"])
+    assert int(fv.sum()) == KAT["rel_index_sum_v"] == 576240
+    assert int(fh.sum()) == KAT["rel_index_sum_h"] == 576240
+
+
+@pytest.mark.parametrize("size,batch", [("T", 2), ("S", 1)])
+def test_oracle_step_matches_reference(size, batch):
+    fix = load_npz(f"autoformer_{size}_step.npz")
+    cfg = config_of(fix)
+    from cream_amd.autoformer import Vision_TransformerSuper
+    m = Vision_TransformerSuper(**model_kwargs(size))       # only used as a named-parameter container
+    fill_params(m, seed=3)
+    sd = {k: v.detach() for k, v in m.named_parameters()}
+    images, target = make_batch(batch, seed=5)
+    loss, grads = AO.train_step(sd, cfg, images, target)
+    with torch.no_grad():
+        logits = AO.forward(sd, cfg, images)
+    worst = check_against_fixture(fix, logits, loss, grads, tol=2e-5)
+    assert worst < 2e-5
+
+
+def test_oracle_attention_matches_reference():
+    fix = load_npz("autoformer_attention.npz")
+    from cream_amd.autoformer import AttentionSuper
+    att = AttentionSuper(256, num_heads=4, qkv_bias=True, relative_position=True, change_qkv=True)
+    fill_params(att, seed=11)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in att.named_parameters()}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 197, 216, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 216, generator=g)
+    y = AO.attention(sd, "", x, 216, 3)
+    y.backward(gy)
+    assert max_rel(y.detach(), fix["y"]) < 1e-5
+    assert max_rel(x.grad, fix["dx"]) < 1e-5
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(sd[k[5:]].grad, v) < 1e-5, k
+
+
+# ---------------------------------------------------------------- product host logic
+def test_param_count_kats():
+    """README sizes 5.8M / 22.9M / 53.7M (AutoFormer/README.md:60-62) and supernet totals."""
+    from cream_amd.autoformer import Vision_TransformerSuper
+    for size, sub, want in (("T", SUBNET_T, 5867944), ("S", SUBNET_S, 22891432)):
+        m = Vision_TransformerSuper(**model_kwargs(size))
+        assert m.get_sampled_params_numel(sub) == want == KAT[f"subnet_{size}_params"]
+        assert sum(p.numel() for p in m.parameters()) == KAT[f"supernet_{size}_params"]
+        assert sorted(m.state_dict().keys()) == KAT[f"supernet_{size}_state_keys"]     # checkpoint compatible
+        assert abs(m.get_complexity(196) - KAT[f"supernet_{size}_complexity"]) < 1e-3 * KAT[f"supernet_{size}_complexity"]
+    mB = Vision_TransformerSuper(**model_kwargs("B"))
+    assert sum(p.numel() for p in mB.parameters()) == KAT["supernet_B_params"] == 80160360
+
+
+def test_engine_sample_configs_golden_draws():
+    from cream_amd.autoformer import engine
+    for size in ("T", "S"):
+        for epoch in (0, 1, 7):
+            random.seed(epoch)
+            got = [engine.sample_configs(engine.SEARCH_SPACES[size]["choices"]) for _ in range(3)]
+            assert got == KAT[f"draws_{size}_epoch{epoch}"]
+
+
+def test_relative_index_tables_bit_exact():
+    from cream_amd.autoformer.modules import relative_index_tables
+    fix = load_npz("autoformer_rel_index.npz")
+    iv, ih = relative_index_tables(197, 14)
+    assert iv.dtype == torch.int32 and iv.is_contiguous()
+    assert np.array_equal(iv.numpy(), fix["iv"]) and np.array_equal(ih.numpy(), fix["ih"])
+    # rows 1 and 29 of each table are never used with a 14x14 grid
+    used = set(iv.unique().tolist())
+    assert used == {0} | set(range(2, 29))
+
+
+def test_qkv_interleave_and_contiguous_bias():
+    """qkv_super.py:72-83: rows 0,3,6.. -> q etc., bias is the plain prefix."""
+    from cream_amd.autoformer import qkv_super
+    lin = qkv_super(8, 12, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.arange(96.).view(12, 8))
+        lin.bias.copy_(torch.arange(12.))
+    lin.set_sample_config(sample_in_dim=5, sample_out_dim=6)
+    w, b = lin.samples["weight"], lin.samples["bias"]
+    assert torch.equal(w, torch.stack([lin.weight[r, :5] for r in (0, 3, 1, 4, 2, 5)]))
+    assert torch.equal(b, lin.bias[:6])
+    assert lin.calc_sampled_param_num() == 36
+
+
+@pytest.mark.parametrize("size,batch", [("T", 2), ("S", 1)])
+def test_product_step_on_host_matches_reference(size, batch):
+    """Whole supernet step through the product's modules on HOST tensors (bucketed
+    attention, C-ABI host entry points), fp32, against the reference's golden step."""
+    fix = load_npz(f"autoformer_{size}_step.npz")
+    cfg = config_of(fix)
+    from cream_amd.autoformer import Vision_TransformerSuper
+    m = Vision_TransformerSuper(**model_kwargs(size))
+    fill_params(m, seed=3)
+    m.set_sample_config(cfg)
+    m.train()
+    images, target = make_batch(batch, seed=5)
+    logits = m(images)
+    loss = AO.soft_target_cross_entropy(logits, target)
+    loss.backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+    worst = check_against_fixture(fix, logits, loss, grads, tol=1e-3)
+    assert worst < 1e-3
+    # structural: gradients are exactly zero outside the sampled slice
+    E = cfg["embed_dim"][0]
+    g = m.blocks[0].attn.qkv.weight.grad
+    assert torch.count_nonzero(g[:, E:]) == 0
+    assert torch.count_nonzero(g[3 * 64 * cfg["num_heads"][0]:, :]) == 0
+    assert m.blocks[cfg["layer_num"]].fc1.weight.grad is None if cfg["layer_num"] < len(m.blocks) else True
+
+
+def test_product_attention_on_host_matches_reference():
+    fix = load_npz("autoformer_attention.npz")
+    from cream_amd.autoformer import AttentionSuper
+    att = AttentionSuper(256, num_heads=4, qkv_bias=True, relative_position=True, change_qkv=True)
+    fill_params(att, seed=11)
+    att.set_sample_config(sample_q_embed_dim=192, sample_num_heads=3, sample_in_embed_dim=216)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 197, 216, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 216, generator=g)
+    y = att(x)
+    y.backward(gy)
+    assert max_rel(y.detach(), fix["y"]) < 1e-5
+    assert max_rel(x.grad, fix["dx"]) < 1e-5
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(dict(att.named_parameters())[k[5:]].grad, v) < 2e-5, k
+
+
+def test_dense_forward_of_relative_position_module_still_available():
+    from cream_amd.autoformer import RelativePosition2D_super
+    rp = RelativePosition2D_super(64, 14)
+    rp.set_sample_config(64)
+    emb = rp(197, 197)
+    want, _, _ = AO.rel_pos_embeddings(rp.embeddings_table_v.detach(), rp.embeddings_table_h.detach(), 197, 14)
+    assert torch.equal(emb.detach(), want)

@@ -1,0 +1,117 @@
+"""GPU parity of the AutoFormer supernet step against golden vectors produced by the
+reference itself (tests/golden, fp32 CPU): logits and gradients within 1e-3 relative in
+fp32 mode (BASELINE.json's bar); the bf16 throughput mode is held to a looser, documented
+tolerance (PyTorch's own CPU bf16 autocast of this model is 4e-3..9e-3 off)."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import check_against_fixture, config_of, load_npz, max_rel
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from fixture_utils import fill_params, make_batch, model_kwargs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+IMPLS = ["bucketed", "fused"]
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _set_impl(model, impl):
+    from cream_amd.autoformer import fused_attention
+    if impl == "fused" and not fused_attention.available():
+        pytest.skip("fused attention kernels not built")
+    for m in model.modules():
+        if hasattr(m, "attention_impl"):
+            m.attention_impl = impl
+
+
+def _step(size, batch, impl, amp):
+    from cream_amd.autoformer import Vision_TransformerSuper
+    from cream_amd.autoformer.engine import soft_target_cross_entropy
+    fix = load_npz(f"autoformer_{size}_step.npz")
+    cfg = config_of(fix)
+    m = Vision_TransformerSuper(**model_kwargs(size))
+    fill_params(m, seed=3)
+    m = m.to(_dev())
+    _set_impl(m, impl)
+    m.set_sample_config(cfg)
+    m.train()
+    images, target = make_batch(batch, seed=5)
+    images, target = images.to(_dev()), target.to(_dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        logits = m(images)
+        loss = soft_target_cross_entropy(logits, target)
+    loss.backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+    return fix, cfg, m, logits, loss, grads
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("size,batch", [("T", 2), ("S", 1)])
+def test_step_fp32_within_1e3_of_reference(size, batch, impl):
+    fix, cfg, m, logits, loss, grads = _step(size, batch, impl, amp=False)
+    worst = check_against_fixture(fix, logits, loss, grads, tol=1e-3)
+    assert worst < 1e-3
+    E = cfg["embed_dim"][0]
+    g = m.blocks[0].attn.qkv.weight.grad
+    assert torch.count_nonzero(g[:, E:]) == 0                              # nothing outside the slice
+    assert torch.count_nonzero(g[3 * 64 * cfg["num_heads"][0]:, :]) == 0
+    for t in ("k", "v"):                                                    # table rows 1 and 29 unused
+        tg = getattr(m.blocks[0].attn, f"rel_pos_embed_{t}").embeddings_table_v.grad
+        assert torch.count_nonzero(tg[1]) == 0 and torch.count_nonzero(tg[29]) == 0
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_step_bf16_autocast_documented_tolerance(impl):
+    fix, cfg, m, logits, loss, grads = _step("T", 2, impl, amp=True)
+    assert max_rel(logits.float().cpu(), fix["logits"]) < 3e-2
+    assert abs(float(loss) - float(fix["loss"][0])) / float(fix["loss"][0]) < 1e-2
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(grads[k[5:]].float().cpu(), v) < 8e-2, k
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_attention_module_fp32(impl):
+    from cream_amd.autoformer import AttentionSuper
+    fix = load_npz("autoformer_attention.npz")
+    att = AttentionSuper(256, num_heads=4, qkv_bias=True, relative_position=True, change_qkv=True)
+    fill_params(att, seed=11)
+    att = att.to(_dev())
+    _set_impl(att, impl)
+    att.set_sample_config(sample_q_embed_dim=192, sample_num_heads=3, sample_in_embed_dim=216)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 197, 216, generator=g).to(_dev()).requires_grad_()
+    gy = torch.randn(2, 197, 216, generator=g).to(_dev())
+    y = att(x)
+    y.backward(gy)
+    assert max_rel(y.detach().cpu(), fix["y"]) < 1e-3
+    assert max_rel(x.grad.cpu(), fix["dx"]) < 1e-3
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(dict(att.named_parameters())[k[5:]].grad.cpu(), v) < 1e-3, k
+
+
+def test_trainer_step_runs_and_updates_only_with_finite_values():
+    from cream_amd import comm
+    from cream_amd.autoformer import engine
+    torch.manual_seed(0)
+    model = engine.build_supernet("T", drop_path_rate=0.1).to(_dev())
+    opt = engine.build_optimizer(model, batch_size=8)
+    tr = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES["T"]["choices"], comm.GradReducer(model))
+    images = torch.randn(8, 3, 224, 224, device=_dev())
+    target = torch.softmax(torch.randn(8, 1000, device=_dev()), -1)
+    tr.start_epoch(0)
+    before = model.head.weight.detach().clone()
+    losses = [float(tr.step(images, target)) for _ in range(3)]
+    assert all(map(lambda v: v == v and abs(v) < 1e4, losses))
+    assert not torch.equal(before, model.head.weight.detach())
+    # golden draw sequence of epoch 0: third config drawn last
+    assert tr.config["layer_num"] in (12, 13, 14)

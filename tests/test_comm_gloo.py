@@ -1,0 +1,78 @@
+"""Multi-rank path on CPU: world_size-2 gloo run of the gradient reducer + trainer.
+Checks that (a) both ranks end with identical, correctly averaged gradients, (b) buckets of
+blocks beyond the sampled depth are not sent, (c) a trainer step keeps the replicas in sync."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    from cream_amd import comm
+    from cream_amd.autoformer import engine
+    r, _, w = comm.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)                                       # same weights on both ranks
+    model = engine.build_supernet("T", drop_path_rate=0.0, img_size=64, depth=3, embed_dim=128, num_heads=2)
+    choices = dict(mlp_ratio=[3.5, 4], num_heads=[1, 2], depth=[2, 3], embed_dim=[64, 128])
+    opt = engine.build_optimizer(model, lr=1e-3, batch_size=4, world_size=world)
+    reducer = comm.GradReducer(model)
+    tr = engine.SupernetTrainer(model, opt, choices, reducer, amp_dtype=torch.float32)
+    g = torch.Generator().manual_seed(100 + rank)              # different data per rank
+    images = torch.randn(4, 3, 64, 64, generator=g)
+    target = torch.softmax(torch.randn(4, 1000, generator=g), -1)
+    tr.start_epoch(3)
+    cfg = tr.sample()
+    # reference gradients: local grads of both ranks' data averaged by hand
+    loss = tr.forward_backward(images, target)
+    mine = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    sent = reducer.bytes_sent
+    # un-averaged local gradient for the cross-check
+    model.zero_grad(set_to_none=False)
+    from cream_amd.autoformer.engine import soft_target_cross_entropy
+    soft_target_cross_entropy(model(images), target).backward()
+    local = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered) / world
+    ok_avg = torch.allclose(mine, want, rtol=1e-5, atol=1e-7)
+    # a real step keeps replicas identical
+    tr.step(images, target)
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    in_sync = torch.equal(both[0], both[1])
+    inactive = [b for b in reducer.bucket_names if b.startswith("block") and int(b[5:]) >= cfg["layer_num"]]
+    full_bytes = sum(buf.numel() * 4 for buf in reducer.flat.values())
+    q.put((rank, ok_avg, in_sync, cfg["layer_num"], len(inactive), sent, full_bytes, float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_avg, in_sync, depth, n_inactive, sent, full, loss in res:
+        assert ok_avg, f"rank {rank}: averaged gradients wrong"
+        assert in_sync, f"rank {rank}: replicas diverged after a step"
+        if depth < 3:
+            assert n_inactive == 3 - depth and sent < full      # dead blocks are not sent
+        else:
+            assert sent == full
+    assert res[0][3] == res[1][3]                               # same sub-network on both ranks
