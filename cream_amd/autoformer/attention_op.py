@@ -11,9 +11,9 @@ against multihead_super.py:133-160 to fp32 round-off):
 Two executions, both on the HIP kernels of libcream_amd.so:
   * 'bucketed' — dense contractions through the GEMM library, gather/scatter through the
     rpe_index kernels (cream_amd.rpe_index).  Shape-generic (any N, head_dim, dropout).
-  * 'fused'    — one HIP kernel per direction (cream_attn_rpe2d_fwd/bwd): QK^T, the LDS
-    bucket lookups, softmax, PV and the bucket sums in one pass, nothing of size N^2
-    touches HBM.  head_dim 64, N <= 256, no attention dropout.
+  * 'fused'    — cream_attn_rpe2d_fwd/bwd: QK^T, the bucket lookups (as a one-hot
+    extension of the MFMA contraction), softmax, PV and the bucket sums in one pass,
+    nothing of size N^2 touches HBM.  head_dim 64, N = g*g + 1 <= 256, no attention dropout.
 'auto' picks 'fused' whenever its constraints hold.
 """
 import torch
@@ -94,20 +94,27 @@ def _bucketed(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p):
     return out.transpose(1, 2)                                     # (B, N, H, D)
 
 
-def fused_supported(qkv, dropout_p):
-    from . import fused_attention
-    return fused_attention.supported(qkv, dropout_p)
+def _fused_operands(qkv, tables):
+    """The fused kernels read fp32 tables and a bf16/fp32 qkv buffer; under autocast the
+    tables are fp32 parameters already."""
+    return qkv, tuple(t.float() if t.dtype != torch.float32 else t for t in tables)
 
 
-def attention_rpe2d(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p=0.0, impl='auto'):
+def attention_rpe2d(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p=0.0, impl='auto',
+                    max_relative_position=14):
     """qkv: (B, N, 3, H, D) — q/k/v of head h at [:, :, 0/1/2, h, :]; tables (nb, D);
-    iv/ih int32 (N, N).  Returns (B, N, H, D)."""
+    iv/ih int32 (N, N) (used by the bucketed execution; the fused kernels regenerate them
+    from the grid geometry).  Returns (B, N, H, D)."""
     assert qkv.dim() == 5 and qkv.shape[2] == 3
     if impl not in ('auto', 'fused', 'bucketed'):
         raise ValueError(f"unknown attention impl {impl!r}")
-    if impl == 'fused' or (impl == 'auto' and fused_supported(qkv, dropout_p)):
+    if impl != 'bucketed' and qkv.is_cuda:
         from . import fused_attention
-        return fused_attention.attention_rpe2d_fused(qkv, tkv, tkh, tvv, tvh, iv, ih, scale)
+        qkv_f, tabs = _fused_operands(qkv, (tkv, tkh, tvv, tvh))
+        if impl == 'fused' or fused_attention.supported(qkv_f, dropout_p, max_relative_position, tabs):
+            return fused_attention.attention_rpe2d_fused(qkv_f, *tabs, scale, max_relative_position)
+    elif impl == 'fused':
+        raise RuntimeError("cream_amd: the fused attention kernels need device tensors")
     return _bucketed(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p)
 
 

@@ -1,13 +1,121 @@
-"""Fused attention + 2-D relative position bias (HIP, cream_attn_rpe2d_fwd/bwd)."""
+"""Fused attention + 2-D relative position bias on the HIP kernels cream_attn_rpe2d_fwd /
+cream_attn_rpe2d_bwd (cream_amd/csrc/attn_rpe2d.hip) — the core of AttentionSuper.forward
+between the qkv and proj GEMMs (AutoFormer/model/module/multihead_super.py:135-154).
+
+One launch per direction for all (batch, head) pairs; nothing of size N^2 reaches HBM; the
+relative position index matrices are generated in-kernel from the grid geometry.  There
+is no fallback here: if the geometry is outside the kernel family, `supported()` says so
+and the caller picks the bucketed HIP path (attention_op) explicitly.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib, timing
+
+_DT = {torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+
+
+def padded_len(n):
+    return (n + 31) // 32 * 32
+
+
+def grid_of(n, max_relative_position):
+    """(gh, gw) of a length-n sequence as the reference derives it (multihead_super.py:47:
+    side = int((n-1)**0.5)), or None when the fused kernel family does not cover it."""
+    side = int((n - 1) ** 0.5)
+    if side < 1 or side * side != n - 1:
+        return None
+    if n > 256 or 2 * side + 1 > 32 or 2 * max_relative_position + 2 > 32:
+        return None
+    return side, side
 
 
 def available():
-    return False
+    return True
 
 
-def supported(qkv, dropout_p):
-    return False
+def supported(qkv, dropout_p, max_relative_position=14, tables=()):
+    if dropout_p != 0.0 or not qkv.is_cuda or qkv.dtype not in _DT:
+        return False
+    B, N, three, H, D = qkv.shape
+    if D != 64 or grid_of(N, max_relative_position) is None:
+        return False
+    if qkv.stride(4) != 1 or any((s * qkv.element_size()) % 16 for s in qkv.stride()[:4]):
+        return False
+    for t in tables:
+        if t.dtype != torch.float32 or t.stride(1) != 1 or t.shape[1] != 64 or t.stride(0) % 4:
+            return False
+    return True
 
 
-def attention_rpe2d_fused(qkv, tkv, tkh, tvv, tvh, iv, ih, scale):
-    raise NotImplementedError("fused attention kernels are not built yet")
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _flops(B, H, N):
+    NP = padded_len(N)
+    return 2 * B * H * NP * NP * (96 + 96) + 2 * B * H * NP * 64 * 64 * 2
+
+
+class _FusedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, tkv, tkh, tvv, tvh, scale, mr):
+        B, N, _, H, D = qkv.shape
+        gh, gw = grid_of(N, mr)
+        NP = padded_len(N)
+        out = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        sp = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
+        lib = _lib.load()
+        with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_fwd", flops=_flops(B, H, N)):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.cream_attn_rpe2d_fwd(
+                _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
+                _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
+                B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_fwd")
+        ctx.save_for_backward(qkv, tkv, tkh, tvv, tvh, out, lse, sp)
+        ctx.scale, ctx.mr = float(scale), mr
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tkv, tkh, tvv, tvh, out, lse, sp = ctx.saved_tensors
+        B, N, _, H, D = qkv.shape
+        gh, gw = grid_of(N, ctx.mr)
+        NP = padded_len(N)
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
+        # side buffers of the two backward launches (see include/cream_amd.h)
+        dlt = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
+        qe = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
+        de = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
+        delta = torch.empty((B, H, NP), dtype=torch.float32, device=qkv.device)
+        dtab = torch.empty((B * H, 4, 32, 64), dtype=torch.float32, device=qkv.device)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
+        dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+        dsb, dsn, dsh = dqkv.stride(0), dqkv.stride(1), dqkv.stride(3)
+        lib = _lib.load()
+        with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=3 * _flops(B, H, N)):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.cream_attn_rpe2d_bwd(
+                _ptr(dq), _ptr(dk), _ptr(dv), dsb, dsn, dsh, _ptr(dtab),
+                _ptr(dlt), _ptr(qe), _ptr(de), _ptr(delta),
+                _ptr(dout), _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
+                _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
+                B, H, N, gh, gw, ctx.mr, ctx.scale, _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
+        nb = tkv.shape[0]
+        dt = dtab.sum(dim=0)                                  # fixed-order reduction over (b, h)
+        return (dqkv, dt[0, :nb].to(tkv.dtype), dt[1, :nb].to(tkh.dtype), dt[2, :nb].to(tvv.dtype),
+                dt[3, :nb].to(tvh.dtype), None, None)
+
+
+def attention_rpe2d_fused(qkv, tkv, tkh, tvv, tvh, scale, max_relative_position=14):
+    """qkv (B, N, 3, H, 64) bf16/fp32; tables (2*mr+2, 64) fp32 -> (B, N, H, 64)."""
+    if not supported(qkv, 0.0, max_relative_position, (tkv, tkh, tvv, tvh)):
+        raise RuntimeError("cream_amd: fused attention does not cover this shape/dtype/layout "
+                           f"(qkv {tuple(qkv.shape)} {qkv.dtype}, strides {qkv.stride()})")
+    return _FusedAttention.apply(qkv, tkv, tkh, tvv, tvh, scale, max_relative_position)

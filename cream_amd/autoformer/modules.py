@@ -356,7 +356,8 @@ class AttentionSuper(nn.Module):
             tvv, tvh = self.rel_pos_embed_v.tables()
             iv, ih = self.rel_pos_embed_k.index_tables(N, x.device)
             out = attention_op.attention_rpe2d(qkv, tkv, tkh, tvv, tvh, iv, ih, self.sample_scale,
-                                               dropout_p=drop_p, impl=self.attention_impl)
+                                               dropout_p=drop_p, impl=self.attention_impl,
+                                               max_relative_position=self.max_relative_position)
         else:
             out = attention_op.attention_plain(qkv, self.sample_scale, dropout_p=drop_p)
         out = out.reshape(B, N, -1)

@@ -1,0 +1,388 @@
+// attn_rpe2d.hip — fused multi-head attention with AutoFormer's 2-D relative position bias
+// on keys and values, forward and backward, for gfx950 (MI355X).
+//
+// Reference semantics (AutoFormer/model/module/multihead_super.py:135-154),
+// per (batch b, head h), head_dim 64, N tokens (token 0 = class token, then a gh x gw grid):
+//     Lv = q Tkv^T ; Lh = q Tkh^T                                  (N x nb bucket lookups)
+//     A[i,j] = scale * ( q_i.k_j + Lv[i, iv[i,j]] + Lh[i, ih[i,j]] )
+//     P = softmax_j(A)
+//     Sv[i,u] = sum_{j: iv[i,j]=u} P[i,j] ; Sh likewise
+//     O_i = sum_j P[i,j] v_j + Sv[i,:] Tvv + Sh[i,:] Tvh
+// Nothing of size N^2 touches HBM.  One workgroup = one (b,h); wave w owns the 32-query
+// tile w and keeps the whole row block of scores in registers (N <= 256), so the softmax is
+// exact (no online rescaling).  The bias gather / slot sums ride on the MFMAs through the
+// one-hot extension described in attn_common.hpp.  Row-major operands (Q, K, dO, ...) are
+// read straight from global memory (they are L2-resident: 25 KB per head); LDS holds only
+// the transposed tiles the matrix cores need with the contraction index contiguous (V^T,
+// K^T, Q^T, dO^T), the transposed value tables and the per-wave shift scratch.
+//
+// dtype = bf16 (throughput mode: bf16 operands, fp32 accumulation/softmax) or fp32 (parity
+// mode: v_mfma_f32_32x32x2_f32, exact fp32 products) — one code path, Tr<T> traits.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bfloat16.h>
+#include <stdint.h>
+
+#include "attn_common.hpp"
+#include "cream_amd.h"
+
+namespace {
+using namespace cream;
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct FwdArgs {
+    const void* q; const void* k; const void* v;    // element (b, n, h, :) at b*sb + n*sn + h*sh
+    int64_t sb, sn, sh;
+    void* out;                                       // (B, N, H, 64) contiguous
+    float* lse;                                      // (B, H, N)   log-sum-exp of scaled logits
+    void* sp;                                        // (B, H, 64, NP) bucket sums S'^T, dtype T
+    const float *tkv, *tkh, *tvv, *tvh;              // (nb, 64) tables, row stride ldt
+    int ldt, nb;
+    int H, NP;
+    RelGeom G;
+    float scale;
+};
+
+// ---- pieces shared by forward and backward ---------------------------------------------
+
+// B operand fragments of a 32-row tile of a row-major (n, 64) matrix: lane = row, steps over d
+template <typename T>
+__device__ __forceinline__ void load_rows_as_b(typename Tr<T>::frag (&f)[64 / Tr<T>::KI],
+                                               const typename Tr<T>::elem* rowp, bool valid, int g) {
+    using TT = Tr<T>;
+#pragma unroll
+    for (int ks = 0; ks < 64 / TT::KI; ++ks)
+        f[ks] = valid ? TT::load(rowp + ks * TT::KI + g * TT::EPL) : TT::zero();
+}
+
+// lookups^T (32 buckets x 32 queries) = table(32 x 64) . X^T for the vertical and horizontal
+// table, written to the wave's scratch as row[q][u] / row[q][32 + u]
+template <typename T>
+__device__ __forceinline__ void table_lookups(float* scr, const typename Tr<T>::frag (&xb)[64 / Tr<T>::KI],
+                                              const float* tv, const float* th, int ldt, int nb, int lane) {
+    using TT = Tr<T>;
+    const int u = lane & 31, g = lane >> 5;
+    f32x16 av = {}, ah = {};
+#pragma unroll
+    for (int ks = 0; ks < 64 / TT::KI; ++ks) {
+        const int k0 = ks * TT::KI + g * TT::EPL;
+        av = TT::mma(TT::load_f32(tv + (int64_t)u * ldt + k0, u < nb), xb[ks], av);
+        ah = TT::mma(TT::load_f32(th + (int64_t)u * ldt + k0, u < nb), xb[ks], ah);
+    }
+    float* row = scr + (lane & 31) * LP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        row[acc_row(r, g)] = av[r];
+        row[32 + acc_row(r, g)] = ah[r];
+    }
+}
+
+// extension fragments x_i[slot] (B operand, 32 slots) from the wave's scratch
+template <typename T>
+__device__ __forceinline__ void build_ext(typename Tr<T>::frag (&xe)[32 / Tr<T>::KI], const float* scr,
+                                          int lane, int qi, int qr, int qc, const RelGeom& G) {
+    using TT = Tr<T>;
+    const int g = lane >> 5;
+    const float* row = scr + (lane & 31) * LP;
+#pragma unroll
+    for (int ks = 0; ks < 32 / TT::KI; ++ks) {
+        if constexpr (TT::EPL == 1) {
+            xe[ks] = ext_gather(row, ks * 2 + g, qi, qr, qc, G);
+        } else {
+#pragma unroll
+            for (int e = 0; e < TT::EPL; ++e)
+                xe[ks][e] = TT::from_f(ext_gather(row, ks * TT::KI + g * TT::EPL + e, qi, qr, qc, G));
+        }
+    }
+}
+
+// slot tile (accumulator, lane = query, rows = slots) -> bucket rows row[q][0..63] in scratch
+__device__ __forceinline__ void scatter_slots(float* scr, const f32x16& x, int lane, int qi, int qr, int qc,
+                                              const RelGeom& G) {
+    const int g = lane >> 5;
+    float* row = scr + (lane & 31) * LP;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) row[g * 32 + r] = 0.f;
+    wave_lds_fence();
+    // the two lanes of a query take turns (their slots can meet in one bucket: class token
+    // row / clamped distances)
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ext_scatter(row, acc_row(r, 0), x[r], qi, qr, qc, G);
+    }
+    wave_lds_fence();
+    if (g == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ext_scatter(row, acc_row(r, 1), x[r], qi, qr, qc, G);
+    }
+    wave_lds_fence();
+}
+
+// acc^T(64 x 32 queries) += Tab^T(64 x 64 buckets) . rows^T  with Tab^T in LDS ([64][tp]) and the
+// bucket rows in the wave's fp32 scratch
+template <typename T>
+__device__ __forceinline__ void add_bucket_product(f32x16 (&o)[2], const typename Tr<T>::elem* tabT, int tp,
+                                                   const float* scr, int lane) {
+    using TT = Tr<T>;
+    const int g = lane >> 5;
+    const float* row = scr + (lane & 31) * LP;
+#pragma unroll
+    for (int ks = 0; ks < 64 / TT::KI; ++ks) {
+        const int k0 = ks * TT::KI + g * TT::EPL;
+        const typename TT::frag b = TT::load_f32(row + k0, true);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            o[dt] = TT::mma(TT::load(tabT + ((lane & 31) + 32 * dt) * tp + k0), b, o[dt]);
+    }
+}
+
+// workgroup-cooperative: transposed tile  dst[d][n] = src(n, d)  for n < NP (zero beyond N)
+template <typename T>
+__device__ __forceinline__ void fill_transposed(typename Tr<T>::elem* dst, int pitch,
+                                                const typename Tr<T>::elem* src, int64_t sn, int N, int NP) {
+    using E = typename Tr<T>::elem;
+    constexpr int V = 16 / sizeof(E);
+    for (int n = threadIdx.x; n < NP; n += blockDim.x) {
+        const E* rowp = src + (int64_t)n * sn;
+#pragma unroll
+        for (int c = 0; c < 64 / V; ++c) {
+            union { u32x4v v; E e[V]; } u;
+            if (n < N) u.v = *reinterpret_cast<const u32x4v*>(rowp + c * V);
+            else u.v = u32x4v{0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < V; ++e) dst[(c * V + e) * pitch + n] = u.e[e];
+        }
+    }
+}
+
+// workgroup-cooperative: tabT[d][u] = (u < 32 ? tv[u][d] : th[u-32][d]), zero for u >= nb
+template <typename T>
+__device__ __forceinline__ void fill_tables_T(typename Tr<T>::elem* tabT, int tp, const float* tv,
+                                              const float* th, int ldt, int nb) {
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const int d = i & 63, u = i >> 6, uu = u & 31;
+        const float* t = u < 32 ? tv : th;
+        tabT[d * tp + u] = Tr<T>::from_f(uu < nb ? t[(int64_t)uu * ldt + d] : 0.f);
+    }
+}
+
+template <typename T> __host__ __device__ constexpr int table_pitch() { return sizeof(typename Tr<T>::elem) == 2 ? 72 : 65; }
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_rpe2d_fwd_kernel(const FwdArgs a) {
+    using TT = Tr<T>;
+    using E = typename TT::elem;
+    using F = typename TT::frag;
+    constexpr int KI = TT::KI, EPL = TT::EPL, S64 = 64 / KI, S32 = 32 / KI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const RelGeom G = a.G;
+    const int N = G.n, NP = a.NP;
+    const int nt = NP >> 5;
+    const int vp = NP + TT::PADT;
+    constexpr int tp = table_pitch<T>();
+    E* vt = reinterpret_cast<E*>(smem);                                   // [64][vp]
+    E* tvt = vt + 64 * vp;                                                // [64][tp]
+    uint16_t* slots = reinterpret_cast<uint16_t*>(tvt + 64 * tp);         // [NP]
+    float* scratch = reinterpret_cast<float*>(slots + NP);                // [nt][32][LP]
+
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const E* qp = reinterpret_cast<const E*>(a.q) + base;
+    const E* kp = reinterpret_cast<const E*>(a.k) + base;
+    const E* vpg = reinterpret_cast<const E*>(a.v) + base;
+
+    // ---- workgroup prologue: V^T, value tables^T, key slots -----------------------------
+    fill_transposed<T>(vt, vp, vpg, a.sn, N, NP);
+    fill_tables_T<T>(tvt, tp, a.tvv, a.tvh, a.ldt, a.nb);
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) slots[j] = key_slots(j, G);
+
+    // ---- this wave's query tile ------------------------------------------------------------
+    float* scr = scratch + wave * 32 * LP;
+    const int qi = wave * 32 + c32;
+    const bool qok = qi < N;
+    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
+    F qb[S64];
+    load_rows_as_b<T>(qb, qp + (int64_t)qi * a.sn, qok, g);
+    table_lookups<T>(scr, qb, a.tkv, a.tkh, a.ldt, a.nb, lane);
+    wave_lds_fence();
+    F qe[S32];
+    build_ext<T>(qe, scr, lane, qi, qr, qc, G);
+
+    __syncthreads();                                  // slots (and V^T, tables^T) are in place
+
+    // ---- S^T tiles: scores of all keys against this wave's 32 queries -------------------
+    f32x16 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = f32x16{};
+        if (t < nt) {
+            const int kj = t * 32 + c32;
+            const E* krow = kp + (int64_t)kj * a.sn;
+#pragma unroll
+            for (int ks = 0; ks < S64; ++ks) {
+                const F ka = kj < N ? TT::load(krow + ks * KI + g * EPL) : TT::zero();
+                s[t] = TT::mma(ka, qb[ks], s[t]);
+            }
+            const uint32_t pk = slots[kj];
+#pragma unroll
+            for (int ks = 0; ks < S32; ++ks) s[t] = TT::mma(TT::onehot_row(pk, ks, g), qe[ks], s[t]);
+        }
+    }
+
+    // ---- softmax over keys (in-lane + one exchange with the partner lane) ---------------
+    const float sc = a.scale * LOG2E;
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t * 32 + acc_row(r, g) < N;
+                s[t][r] = ok ? s[t][r] * sc : -INFINITY;
+                m = fmaxf(m, s[t][r]);
+            }
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[t][r] - m);
+                s[t][r] = p;
+                l += p;
+            }
+        }
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.f / l;
+    if (qok && g == 0)
+        a.lse[((int64_t)b * a.H + h) * N + qi] = (m + log2f(l)) * (1.f / LOG2E);
+
+    // ---- [O | slot sums]^T = [V | one-hot]^T . P^T ----------------------------------------
+    f32x16 o[2] = {f32x16{}, f32x16{}};
+    f32x16 ox = {};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int st = 0; st < S32; ++st) {
+                const F pb = TT::from_acc(s[t], st);
+                o[0] = TT::mma(TT::load_perm(vt + c32 * vp + t * 32, st, g), pb, o[0]);
+                o[1] = TT::mma(TT::load_perm(vt + (c32 + 32) * vp + t * 32, st, g), pb, o[1]);
+                ox = TT::mma(TT::onehot_perm(slots + t * 32, st, g, c32), pb, ox);
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; ox[r] *= inv_l; }
+
+    // ---- value-side relative position term: slot sums -> bucket sums -> . tables ---------
+    scatter_slots(scr, ox, lane, qi, qr, qc, G);
+    {   // S'^T (64 buckets x NP queries) for backward (dTvv / dTvh)
+        E* spp = reinterpret_cast<E*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi;
+        const float* row = scr + c32 * LP + g * 32;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) spp[(int64_t)(g * 32 + r) * NP] = TT::from_f(row[r]);
+    }
+    add_bucket_product<T>(o, tvt, tp, scr, lane);
+
+    // ---- store O (b, n, h, :) ----------------------------------------------------------------
+    if (qok) {
+        E* op = reinterpret_cast<E*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = dt * 32 + 8 * r4 + 4 * g;
+                if constexpr (sizeof(E) == 2) {
+                    union { u32x2v v; E e[4]; } u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u.e[e] = TT::from_f(o[dt][4 * r4 + e]);
+                    *reinterpret_cast<u32x2v*>(op + d) = u.v;
+                } else {
+                    *reinterpret_cast<f32x4v*>(op + d) =
+                        f32x4v{o[dt][4 * r4], o[dt][4 * r4 + 1], o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]};
+                }
+            }
+    }
+}
+
+template <typename T> size_t fwd_lds_bytes(int NP) {
+    using E = typename Tr<T>::elem;
+    const int nt = NP / 32;
+    return (size_t)64 * (NP + Tr<T>::PADT) * sizeof(E) + (size_t)64 * table_pitch<T>() * sizeof(E) +
+           (size_t)NP * 2 + (size_t)nt * 32 * LP * 4;
+}
+
+template <typename T, int NT>
+int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
+    const size_t lds = fwd_lds_bytes<T>(a.NP);
+    auto kern = attn_rpe2d_fwd_kernel<T, NT>;
+    static bool attr_done = false;           // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * a.H), dim3((a.NP / 32) * 64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
+    const int nt = a.NP / 32;
+    if (nt <= 2) return launch_fwd_nt<T, 2>(a, B, st);
+    if (nt <= 4) return launch_fwd_nt<T, 4>(a, B, st);
+    if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
+    return launch_fwd_nt<T, 8>(a, B, st);
+}
+
+bool geom_ok(int N, int gh, int gw, int mr, int nb) {
+    return N >= 1 && N <= 256 && gh >= 0 && gw >= 1 && gh * gw + 1 == N && gh + gw + 1 <= 32 && mr >= 0 &&
+           nb == 2 * mr + 2 && nb <= 32;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cream_attn_rpe2d_padded_len(int N) { return N <= 0 ? 0 : ((N + 31) / 32) * 32; }
+
+int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const void* k, const void* v,
+                         int64_t sb, int64_t sn, int64_t sh, const float* tkv, const float* tkh,
+                         const float* tvv, const float* tvh, int ldt, int B, int H, int N, int gh, int gw,
+                         int mr, float scale, int dtype, void* stream)
+{
+    if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
+    if (B == 0 || H == 0) return CREAM_OK;
+    if (!out || !lse || !sp || !q || !k || !v || !tkv || !tkh || !tvv || !tvh) return CREAM_ERR_BAD_ARG;
+    if (!geom_ok(N, gh, gw, mr, 2 * mr + 2)) return CREAM_ERR_TOO_LARGE;
+    if (ldt < 64) return CREAM_ERR_BAD_ARG;
+    const int esz = dtype == CREAM_F32 ? 4 : 2;
+    // 16-byte vector loads of operand rows
+    if ((sb * esz) % 16 || (sn * esz) % 16 || (sh * esz) % 16) return CREAM_ERR_BAD_ARG;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16) return CREAM_ERR_BAD_ARG;
+    if (ldt % 4 || ((uintptr_t)tkv | (uintptr_t)tkh) % 16) return CREAM_ERR_BAD_ARG;
+    FwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.sb = sb; a.sn = sn; a.sh = sh;
+    a.out = out; a.lse = lse; a.sp = sp;
+    a.tkv = tkv; a.tkh = tkh; a.tvv = tvv; a.tvh = tvh; a.ldt = ldt; a.nb = 2 * mr + 2;
+    a.H = H; a.NP = cream_attn_rpe2d_padded_len(N);
+    a.G = RelGeom{N, gh, gw, mr};
+    a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case CREAM_BF16: return launch_fwd<hip_bfloat16>(a, B, st);
+        case CREAM_F32: return launch_fwd<float>(a, B, st);
+        default: return CREAM_ERR_BAD_DTYPE;
+    }
+}
+
+}  // extern "C"

@@ -79,6 +79,38 @@ int cream_rpe_index_fwd_host(void* y, const void* in, const int32_t* idx,
 int cream_rpe_index_bwd_host(void* gin, const void* gout, const int32_t* idx,
                              int B, int H, int Lq, int Lk, int nb, int dtype);
 
+/* ---- fused attention with AutoFormer's 2-D relative position bias -------------------- */
+
+/* Padded token count used by the side buffers below: N rounded up to a multiple of 32. */
+int cream_attn_rpe2d_padded_len(int N);
+
+/* The attention core of AttentionSuper.forward between the qkv and proj GEMMs
+ * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
+ * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
+ *     A[i,j] = scale * ( q_i.k_j + q_i.(Tkv[iv[i,j]] + Tkh[ih[i,j]]) )
+ *     P = softmax_j(A)          (attention dropout must be 0 — the supernet recipe's value)
+ *     O_i = sum_j P[i,j] * ( v_j + Tvv[iv[i,j]] + Tvh[ih[i,j]] )
+ * for every (b, h); head_dim is 64 (supernet_transformer.py:243).  iv/ih are the
+ * reference's index matrices for a gh x gw token grid behind one class token
+ * (N = gh*gw + 1, bucket 0 for the class row/column, clamp(+-mr) + mr + 1 otherwise); they
+ * are generated in-kernel from (gh, gw, mr), never read from memory.
+ *   q, k, v : element (b, n, h, d) at  ptr[b*sb + n*sn + h*sh + d]  (strides in elements;
+ *             the three may alias one (B, N, 3, H, 64) qkv buffer), dtype bf16 or f32
+ *   tkv,tkh,tvv,tvh : (2*mr+2, 64) fp32 tables, row stride ldt elements
+ *   out     : (B, N, H, 64) contiguous, same dtype as q
+ *   lse     : (B, H, N) fp32       log-sum-exp of the scaled logits   (saved for backward)
+ *   sp      : (B, H, 64, NP) same dtype as q: bucket sums S'^T, rows 0..31 vertical table,
+ *             32..63 horizontal table, NP = cream_attn_rpe2d_padded_len(N)  (for backward)
+ * Limits: N <= 256, gh + gw + 1 <= 32, 2*mr + 2 <= 32, 16-byte aligned rows
+ * (CREAM_ERR_TOO_LARGE / CREAM_ERR_BAD_ARG otherwise).  dtype: CREAM_BF16 (bf16 MFMA, fp32
+ * accumulate and softmax) or CREAM_F32 (fp32 MFMA, exact fp32 products). */
+int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp,
+                         const void* q, const void* k, const void* v,
+                         int64_t sb, int64_t sn, int64_t sh,
+                         const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                         int ldt, int B, int H, int N, int gh, int gw, int mr,
+                         float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif
