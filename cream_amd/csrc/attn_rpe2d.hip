@@ -166,6 +166,39 @@ __device__ __forceinline__ void fill_tables_T(typename Tr<T>::elem* tabT, int tp
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void store_ext_rows(typename Tr<T>::elem* dst /* row of 32 */,
+                                               const typename Tr<T>::frag (&xe)[32 / Tr<T>::KI], int g) {
+    using TT = Tr<T>;
+#pragma unroll
+    for (int ks = 0; ks < 32 / TT::KI; ++ks) {
+        if constexpr (TT::EPL == 1) dst[ks * 2 + g] = xe[ks];
+        else *reinterpret_cast<bf16x8*>(dst + ks * TT::KI + g * TT::EPL) = xe[ks];
+    }
+}
+
+// accumulator tile (lane = row n of the output, 16 x 2 d-values) -> (.., n, h, :) row pointer
+template <typename T>
+__device__ __forceinline__ void store_rows_64(typename Tr<T>::elem* op, const f32x16 (&o)[2], int g) {
+    using TT = Tr<T>;
+    using E = typename TT::elem;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = dt * 32 + 8 * r4 + 4 * g;
+            if constexpr (sizeof(E) == 2) {
+                union { u32x2v v; E e[4]; } u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u.e[e] = TT::from_f(o[dt][4 * r4 + e]);
+                *reinterpret_cast<u32x2v*>(op + d) = u.v;
+            } else {
+                *reinterpret_cast<f32x4v*>(op + d) =
+                    f32x4v{o[dt][4 * r4], o[dt][4 * r4 + 1], o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]};
+            }
+        }
+}
+
 template <typename T> __host__ __device__ constexpr int table_pitch() { return sizeof(typename Tr<T>::elem) == 2 ? 72 : 65; }
 
 // ---------------------------------------------------------------------------------------
@@ -293,24 +326,7 @@ __global__ __launch_bounds__(NT * 64) void attn_rpe2d_fwd_kernel(const FwdArgs a
     add_bucket_product<T>(o, tvt, tp, scr, lane);
 
     // ---- store O (b, n, h, :) ----------------------------------------------------------------
-    if (qok) {
-        E* op = reinterpret_cast<E*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = dt * 32 + 8 * r4 + 4 * g;
-                if constexpr (sizeof(E) == 2) {
-                    union { u32x2v v; E e[4]; } u;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) u.e[e] = TT::from_f(o[dt][4 * r4 + e]);
-                    *reinterpret_cast<u32x2v*>(op + d) = u.v;
-                } else {
-                    *reinterpret_cast<f32x4v*>(op + d) =
-                        f32x4v{o[dt][4 * r4], o[dt][4 * r4 + 1], o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]};
-                }
-            }
-    }
+    if (qok) store_rows_64<T>(reinterpret_cast<E*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64, o, g);
 }
 
 template <typename T> size_t fwd_lds_bytes(int NP) {
@@ -342,6 +358,309 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     if (nt <= 4) return launch_fwd_nt<T, 4>(a, B, st);
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+// With Qx = [Q | X] (X = per-query slot extension of the key-side bucket lookups), Kx = [K | E],
+// Vx = [V | E] (E = one-hot slots of the keys), S = scale Qx Kx^T, P = softmax(S),
+// [O_pv | SA] = P Vx, O = O_pv + shift(SA) [Tvv; Tvh]:
+//     dOx = [dO | gather(dO [Tvv;Tvh]^T)]       dP = dOx Vx^T        delta_i = dO_i . O_i
+//     dS = scale P o (dP - delta)               dQx = dS Kx          dK = dS^T Q     dV = P^T dO
+//     dQ = dQx[:, :64] + shift(dQx[:, 64:]) [Tkv; Tkh]
+//     d[Tkv;Tkh] = shift(dQx[:, 64:])^T Q       d[Tvv;Tvh] = shift(SA)^T dO
+// Two launches, both one workgroup per (b,h), no atomics, fixed summation order:
+//   A  wave = query tile (lanes own queries): dQ, and the side buffers the second launch needs
+//      (slot extensions of Q and dO, delta, the shifted bucket gradients dL'^T)
+//   B  wave = key tile (lanes own keys): dK, dV (contraction over queries, so Q^T and dO^T
+//      live in LDS), then the four table gradients of this (b,h) as eight 32x32 MFMA jobs.
+struct BwdArgs {
+    const void* q; const void* k; const void* v;
+    int64_t sb, sn, sh;
+    void* dq; void* dk; void* dv;                    // same indexing with (dsb, dsn, dsh)
+    int64_t dsb, dsn, dsh;
+    const void* dout; const void* out;               // (B, N, H, 64) contiguous
+    const float* lse;                                // (B, H, N)
+    const void* sp;                                  // (B, H, 64, NP) from forward
+    void* dlt;                                       // (B, H, 64, NP)  dL'^T            (A -> B)
+    void* qe; void* de;                              // (B, H, NP, 32)  slot extensions  (A -> B)
+    float* delta;                                    // (B, H, NP)                       (A -> B)
+    float* dtab;                                     // (B*H, 4, 32, 64) per-(b,h) table gradients
+    const float *tkv, *tkh, *tvv, *tvh;
+    int ldt, nb;
+    int H, NP;
+    RelGeom G;
+    float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) {
+    using TT = Tr<T>;
+    using E = typename TT::elem;
+    using F = typename TT::frag;
+    constexpr int KI = TT::KI, EPL = TT::EPL, S64 = 64 / KI, S32 = 32 / KI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const RelGeom G = a.G;
+    const int N = G.n, NP = a.NP;
+    const int nt = NP >> 5;
+    const int kpch = NP + TT::PADT;
+    constexpr int tp = table_pitch<T>();
+    E* kt = reinterpret_cast<E*>(smem);                                   // K^T [64][kpch]
+    E* tkt = kt + 64 * kpch;                                              // key tables^T [64][tp]
+    uint16_t* slots = reinterpret_cast<uint16_t*>(tkt + 64 * tp);
+    float* scratch = reinterpret_cast<float*>(slots + NP);
+
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int64_t bh = (int64_t)b * a.H + h;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const E* qp = reinterpret_cast<const E*>(a.q) + base;
+    const E* kp = reinterpret_cast<const E*>(a.k) + base;
+    const E* vpg = reinterpret_cast<const E*>(a.v) + base;
+    const int64_t orow = (int64_t)a.H * 64;                               // token stride of out / dout
+    const E* dop = reinterpret_cast<const E*>(a.dout) + ((int64_t)b * N * a.H + h) * 64;
+    const E* outp = reinterpret_cast<const E*>(a.out) + ((int64_t)b * N * a.H + h) * 64;
+
+    fill_transposed<T>(kt, kpch, kp, a.sn, N, NP);
+    fill_tables_T<T>(tkt, tp, a.tkv, a.tkh, a.ldt, a.nb);
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) slots[j] = key_slots(j, G);
+
+    float* scr = scratch + wave * 32 * LP;
+    const int qi = wave * 32 + c32;
+    const bool qok = qi < N;
+    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
+
+    F qb[S64], dob[S64], qe[S32], de[S32];
+    load_rows_as_b<T>(qb, qp + (int64_t)qi * a.sn, qok, g);
+    load_rows_as_b<T>(dob, dop + (int64_t)qi * orow, qok, g);
+    // delta_i = dO_i . O_i  (this lane holds half of the 64 d-values; the partner the rest)
+    float delta = 0.f;
+    {
+        F ob[S64];
+        load_rows_as_b<T>(ob, outp + (int64_t)qi * orow, qok, g);
+#pragma unroll
+        for (int ks = 0; ks < S64; ++ks) {
+            if constexpr (EPL == 1) delta += dob[ks] * ob[ks];
+            else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) delta += TT::to_f(dob[ks][e]) * TT::to_f(ob[ks][e]);
+            }
+        }
+        delta += __shfl_xor(delta, 32);
+    }
+    if (g == 0) a.delta[bh * NP + qi] = delta;
+
+    table_lookups<T>(scr, qb, a.tkv, a.tkh, a.ldt, a.nb, lane);
+    wave_lds_fence();
+    build_ext<T>(qe, scr, lane, qi, qr, qc, G);
+    wave_lds_fence();
+    table_lookups<T>(scr, dob, a.tvv, a.tvh, a.ldt, a.nb, lane);
+    wave_lds_fence();
+    build_ext<T>(de, scr, lane, qi, qr, qc, G);
+    wave_lds_fence();
+    store_ext_rows<T>(reinterpret_cast<E*>(a.qe) + (bh * NP + qi) * 32, qe, g);
+    store_ext_rows<T>(reinterpret_cast<E*>(a.de) + (bh * NP + qi) * 32, de, g);
+
+    const float m2 = qok ? a.lse[bh * N + qi] * LOG2E : 0.f;
+    const float sc = a.scale * LOG2E;
+
+    __syncthreads();                                  // K^T, tables^T, slots in place
+
+    f32x16 dq[2] = {f32x16{}, f32x16{}};
+    f32x16 dx = {};
+    for (int t = 0; t < nt; ++t) {
+        const int kj = t * 32 + c32;
+        const bool kok = kj < N;
+        const E* krow = kp + (int64_t)kj * a.sn;
+        const E* vrow = vpg + (int64_t)kj * a.sn;
+        f32x16 sacc = {}, pacc = {};
+#pragma unroll
+        for (int ks = 0; ks < S64; ++ks) {
+            const F ka = kok ? TT::load(krow + ks * KI + g * EPL) : TT::zero();
+            const F va = kok ? TT::load(vrow + ks * KI + g * EPL) : TT::zero();
+            sacc = TT::mma(ka, qb[ks], sacc);
+            pacc = TT::mma(va, dob[ks], pacc);
+        }
+        const uint32_t pk = slots[kj];
+#pragma unroll
+        for (int ks = 0; ks < S32; ++ks) {
+            const F oh = TT::onehot_row(pk, ks, g);
+            sacc = TT::mma(oh, qe[ks], sacc);
+            pacc = TT::mma(oh, de[ks], pacc);
+        }
+        // dS^T = scale * P o (dP - delta), keys beyond N contribute nothing
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = t * 32 + acc_row(r, g) < N;
+            const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * sc - m2) : 0.f;
+            sacc[r] = p * (pacc[r] - delta) * a.scale;
+        }
+#pragma unroll
+        for (int st = 0; st < S32; ++st) {
+            const F db = TT::from_acc(sacc, st);
+            dq[0] = TT::mma(TT::load_perm(kt + c32 * kpch + t * 32, st, g), db, dq[0]);
+            dq[1] = TT::mma(TT::load_perm(kt + (c32 + 32) * kpch + t * 32, st, g), db, dq[1]);
+            dx = TT::mma(TT::onehot_perm(slots + t * 32, st, g, c32), db, dx);
+        }
+    }
+
+    scatter_slots(scr, dx, lane, qi, qr, qc, G);
+    {   // dL'^T (64 buckets x NP queries) for the table gradients of launch B
+        E* dl = reinterpret_cast<E*>(a.dlt) + bh * 64 * NP + qi;
+        const float* row = scr + c32 * LP + g * 32;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) dl[(int64_t)(g * 32 + r) * NP] = TT::from_f(row[r]);
+    }
+    add_bucket_product<T>(dq, tkt, tp, scr, lane);
+    if (qok)
+        store_rows_64<T>(reinterpret_cast<E*>(a.dq) + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh,
+                         dq, g);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a) {
+    using TT = Tr<T>;
+    using E = typename TT::elem;
+    using F = typename TT::frag;
+    constexpr int KI = TT::KI, EPL = TT::EPL, S64 = 64 / KI, S32 = 32 / KI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const RelGeom G = a.G;
+    const int N = G.n, NP = a.NP;
+    const int nt = NP >> 5;
+    const int pch = NP + TT::PADT;
+    E* qt = reinterpret_cast<E*>(smem);                                   // Q^T  [64][pch]
+    E* dot = qt + 64 * pch;                                               // dO^T [64][pch]
+    float* lse2 = reinterpret_cast<float*>(dot + 64 * pch);               // [NP]
+    float* dlt_s = lse2 + NP;                                             // delta [NP]
+
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int64_t bh = (int64_t)b * a.H + h;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const E* qp = reinterpret_cast<const E*>(a.q) + base;
+    const E* kp = reinterpret_cast<const E*>(a.k) + base;
+    const E* vpg = reinterpret_cast<const E*>(a.v) + base;
+    const int64_t orow = (int64_t)a.H * 64;
+    const E* dop = reinterpret_cast<const E*>(a.dout) + ((int64_t)b * N * a.H + h) * 64;
+    const E* qep = reinterpret_cast<const E*>(a.qe) + bh * NP * 32;
+    const E* dep = reinterpret_cast<const E*>(a.de) + bh * NP * 32;
+
+    fill_transposed<T>(qt, pch, qp, a.sn, N, NP);
+    fill_transposed<T>(dot, pch, dop, orow, N, NP);
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        lse2[i] = i < N ? a.lse[bh * N + i] * LOG2E : INFINITY;           // P = 0 for padding queries
+        dlt_s[i] = i < N ? a.delta[bh * NP + i] : 0.f;
+    }
+
+    const int kj = wave * 32 + c32;
+    const bool kok = kj < N;
+    F kb[S64], vb[S64], oh[S32];
+    load_rows_as_b<T>(kb, kp + (int64_t)kj * a.sn, kok, g);
+    load_rows_as_b<T>(vb, vpg + (int64_t)kj * a.sn, kok, g);
+    {
+        const uint32_t pk = key_slots(kj, G);
+#pragma unroll
+        for (int ks = 0; ks < S32; ++ks) oh[ks] = TT::onehot_row(pk, ks, g);
+    }
+    const float sc = a.scale * LOG2E;
+
+    __syncthreads();
+
+    f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
+    for (int t = 0; t < nt; ++t) {
+        const int qi = t * 32 + c32;                     // A-operand row of this lane
+        const bool qok = qi < N;
+        const E* qrow = qp + (int64_t)qi * a.sn;
+        const E* drow = dop + (int64_t)qi * orow;
+        f32x16 sacc = {}, pacc = {};
+#pragma unroll
+        for (int ks = 0; ks < S64; ++ks) {
+            const F qa = qok ? TT::load(qrow + ks * KI + g * EPL) : TT::zero();
+            const F da = qok ? TT::load(drow + ks * KI + g * EPL) : TT::zero();
+            sacc = TT::mma(qa, kb[ks], sacc);
+            pacc = TT::mma(da, vb[ks], pacc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < S32; ++ks) {
+            sacc = TT::mma(TT::load(qep + (int64_t)qi * 32 + ks * KI + g * EPL), oh[ks], sacc);
+            pacc = TT::mma(TT::load(dep + (int64_t)qi * 32 + ks * KI + g * EPL), oh[ks], pacc);
+        }
+        // lane = key, registers = queries t*32 + acc_row(r, g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = t * 32 + acc_row(r, g);
+            const float p = kok ? __builtin_amdgcn_exp2f(sacc[r] * sc - lse2[qq]) : 0.f;
+            sacc[r] = p;
+            pacc[r] = p * (pacc[r] - dlt_s[qq]) * a.scale;
+        }
+#pragma unroll
+        for (int st = 0; st < S32; ++st) {
+            const F pb = TT::from_acc(sacc, st);
+            const F db = TT::from_acc(pacc, st);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = TT::mma(TT::load_perm(dot + (c32 + 32 * dt) * pch + t * 32, st, g), pb, dv[dt]);
+                dk[dt] = TT::mma(TT::load_perm(qt + (c32 + 32 * dt) * pch + t * 32, st, g), db, dk[dt]);
+            }
+        }
+    }
+    if (kok) {
+        const int64_t off = (int64_t)b * a.dsb + (int64_t)kj * a.dsn + (int64_t)h * a.dsh;
+        store_rows_64<T>(reinterpret_cast<E*>(a.dk) + off, dk, g);
+        store_rows_64<T>(reinterpret_cast<E*>(a.dv) + off, dv, g);
+    }
+
+    // ---- table gradients of this (b,h): dT^T(64 d x 32 u) = X^T(d x q) . R(q x u) ------------
+    //   job = tab*2 + dt;  tab 0/1 = key tables v/h (X = Q, R = dL'), 2/3 = value tables (X = dO, R = S')
+    const E* dltp = reinterpret_cast<const E*>(a.dlt) + bh * 64 * NP;
+    const E* spp = reinterpret_cast<const E*>(a.sp) + bh * 64 * NP;
+    for (int job = wave; job < 8; job += nt) {
+        const int tab = job >> 1, dt = job & 1;
+        const E* xT = (tab < 2 ? qt : dot) + (c32 + 32 * dt) * pch;
+        const E* rT = (tab < 2 ? dltp : spp) + (int64_t)((tab & 1) * 32 + c32) * NP;
+        f32x16 acc = {};
+        for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int st = 0; st < S32; ++st)
+                acc = TT::mma(TT::load_perm(xT + t * 32, st, g), TT::load_perm(rT + t * 32, st, g), acc);
+        }
+        // lane = bucket u (column), registers = d rows
+        float* dst = a.dtab + ((bh * 4 + tab) * 32 + c32) * 64 + dt * 32;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            *reinterpret_cast<f32x4v*>(dst + 8 * r4 + 4 * g) =
+                f32x4v{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+    }
+}
+
+template <typename T> size_t bwd_q_lds_bytes(int NP) { return fwd_lds_bytes<T>(NP); }
+template <typename T> size_t bwd_kv_lds_bytes(int NP) {
+    return (size_t)2 * 64 * (NP + Tr<T>::PADT) * sizeof(typename Tr<T>::elem) + (size_t)NP * 8;
+}
+
+template <typename T>
+int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
+    auto kq = attn_rpe2d_bwd_q_kernel<T>;
+    auto kkv = attn_rpe2d_bwd_kv_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const dim3 grid(B * a.H), block((a.NP / 32) * 64);
+    hipLaunchKernelGGL(kq, grid, block, bwd_q_lds_bytes<T>(a.NP), st, a);
+    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    hipLaunchKernelGGL(kkv, grid, block, bwd_kv_lds_bytes<T>(a.NP), st, a);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
 bool geom_ok(int N, int gh, int gw, int mr, int nb) {
@@ -381,6 +700,45 @@ int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const v
     switch (dtype) {
         case CREAM_BF16: return launch_fwd<hip_bfloat16>(a, B, st);
         case CREAM_F32: return launch_fwd<float>(a, B, st);
+        default: return CREAM_ERR_BAD_DTYPE;
+    }
+}
+
+int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh, float* dtab,
+                         void* dlt, void* qe, void* de, float* delta,
+                         const void* dout, const void* out, const float* lse, const void* sp,
+                         const void* q, const void* k, const void* v, int64_t sb, int64_t sn, int64_t sh,
+                         const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt,
+                         int B, int H, int N, int gh, int gw, int mr, float scale, int dtype, void* stream)
+{
+    if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
+    if (B == 0 || H == 0) return CREAM_OK;
+    if (!dq || !dk || !dv || !dtab || !dlt || !qe || !de || !delta || !dout || !out || !lse || !sp || !q || !k ||
+        !v || !tkv || !tkh || !tvv || !tvh)
+        return CREAM_ERR_BAD_ARG;
+    if (!geom_ok(N, gh, gw, mr, 2 * mr + 2)) return CREAM_ERR_TOO_LARGE;
+    if (ldt < 64 || ldt % 4) return CREAM_ERR_BAD_ARG;
+    const int esz = dtype == CREAM_F32 ? 4 : 2;
+    if ((sb * esz) % 16 || (sn * esz) % 16 || (sh * esz) % 16 || (dsb * esz) % 16 || (dsn * esz) % 16 ||
+        (dsh * esz) % 16)
+        return CREAM_ERR_BAD_ARG;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv |
+         (uintptr_t)dout | (uintptr_t)out | (uintptr_t)sp | (uintptr_t)dlt | (uintptr_t)qe | (uintptr_t)de |
+         (uintptr_t)dtab | (uintptr_t)tkv | (uintptr_t)tkh | (uintptr_t)tvv | (uintptr_t)tvh) % 16)
+        return CREAM_ERR_BAD_ARG;
+    BwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.sb = sb; a.sn = sn; a.sh = sh;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dsb = dsb; a.dsn = dsn; a.dsh = dsh;
+    a.dout = dout; a.out = out; a.lse = lse; a.sp = sp;
+    a.dlt = dlt; a.qe = qe; a.de = de; a.delta = delta; a.dtab = dtab;
+    a.tkv = tkv; a.tkh = tkh; a.tvv = tvv; a.tvh = tvh; a.ldt = ldt; a.nb = 2 * mr + 2;
+    a.H = H; a.NP = cream_attn_rpe2d_padded_len(N);
+    a.G = RelGeom{N, gh, gw, mr};
+    a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case CREAM_BF16: return launch_bwd<hip_bfloat16>(a, B, st);
+        case CREAM_F32: return launch_bwd<float>(a, B, st);
         default: return CREAM_ERR_BAD_DTYPE;
     }
 }

@@ -111,6 +111,27 @@ int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp,
                          int ldt, int B, int H, int N, int gh, int gw, int mr,
                          float scale, int dtype, void* stream);
 
+/* Backward of cream_attn_rpe2d_fwd (what autograd derives for multihead_super.py:135-154 and
+ * the index_put of RelativePosition2D_super's table lookup, multihead_super.py:64):
+ *   dq, dk, dv : gradients, element (b, n, h, d) at ptr[b*dsb + n*dsn + h*dsh + d] (may alias
+ *                one (B, N, 3, H, 64) buffer), same dtype as q
+ *   dtab       : (B*H, 4, 32, 64) fp32, per-(b,h) gradients of [tkv, tkh, tvv, tvh] (rows
+ *                >= 2*mr+2 are zero); the caller sums over the first axis — a fixed-order
+ *                reduction instead of atomics
+ *   dlt, qe, de, delta : scratch handed from the first to the second launch:
+ *                dlt (B,H,64,NP) and qe, de (B,H,NP,32) in q's dtype, delta (B,H,NP) fp32
+ *   dout, out  : (B, N, H, 64) contiguous, q's dtype;  lse, sp: as written by the forward
+ * Two kernels are enqueued on `stream` (dQ; then dK, dV and the table gradients).  No
+ * atomics: results are bit-reproducible run to run. */
+int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh,
+                         float* dtab, void* dlt, void* qe, void* de, float* delta,
+                         const void* dout, const void* out, const float* lse, const void* sp,
+                         const void* q, const void* k, const void* v,
+                         int64_t sb, int64_t sn, int64_t sh,
+                         const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                         int ldt, int B, int H, int N, int gh, int gw, int mr,
+                         float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif
