@@ -35,19 +35,22 @@ typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int acc_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-__device__ __forceinline__ short f2bf(float f) {            // round-to-nearest-even
-    uint32_t x = __float_as_uint(f);
-    x += 0x7fffu + ((x >> 16) & 1u);
-    return (short)(x >> 16);
+typedef __bf16 hwbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short f2bf(float f) {            // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(short, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f2bf_pair(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v{lo, hi}), hwbf16x2));
 }
 __device__ __forceinline__ float bf2f(short h) { return __uint_as_float(((uint32_t)(uint16_t)h) << 16); }
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// slot pair of a key, packed (slotA | slotB << 8); 0xFF = none
-__device__ __forceinline__ bool slot_hit(uint32_t packed, int c) {
-    return (int)(packed & 0xFFu) == c || (int)((packed >> 8) & 0xFFu) == c;
-}
+// The slots of a key are kept as a 32-bit mask (bit c set <=> the key sits in slot c).
 
 // ---- per-dtype traits ---------------------------------------------------------------
 template <typename T> struct Tr;
@@ -74,17 +77,17 @@ template <> struct Tr<hip_bfloat16> {
     }
     // EPL elements from fp32 memory (tables / fp32 scratch), converted
     static __device__ __forceinline__ frag load_f32(const float* p, bool ok) {
-        frag f;
+        f32x8v x;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = ok ? f2bf(p[e]) : (short)0;
-        return f;
+        for (int e = 0; e < 8; ++e) x[e] = ok ? p[e] : 0.f;
+        return __builtin_bit_cast(frag, __builtin_convertvector(x, hwbf16x8));
     }
     // operand built from accumulator registers [s*EPL, s*EPL+EPL) (the permuted-k trick)
     static __device__ __forceinline__ frag from_acc(const f32x16& a, int s) {
-        frag f;
+        f32x8v x;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = f2bf(a[s * 8 + e]);
-        return f;
+        for (int e = 0; e < 8; ++e) x[e] = a[s * 8 + e];
+        return __builtin_bit_cast(frag, __builtin_convertvector(x, hwbf16x8));
     }
     // matching A operand: row pointer `rowp` of a TRANSPOSED tile ([d][n]), contraction
     // indices acc_row(s*8 + e, g): two runs of 4 consecutive columns (8-byte aligned)
@@ -94,26 +97,26 @@ template <> struct Tr<hip_bfloat16> {
         u.v[1] = *reinterpret_cast<const u32x2v*>(rowp + 16 * s + 8 + 4 * g);
         return u.f;
     }
-    // one-hot A operand, rows = keys: contraction slots c = ks*16 + 8g + e
-    static __device__ __forceinline__ frag onehot_row(uint32_t packed, int ks, int g) {
-        frag f;
+    // one-hot operand of a key with slot mask `mask`: contraction slots c = ks*16 + 8g + e
+    static __device__ __forceinline__ frag onehot_row(uint32_t mask, int ks, int g) {
+        const uint32_t m = mask >> (ks * 16 + 8 * g);
+        union { uint32_t w[4]; frag f; } u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = slot_hit(packed, ks * 16 + 8 * g + e) ? ONE : (short)0;
-        return f;
+        for (int p = 0; p < 4; ++p)
+            u.w[p] = ((m >> (2 * p)) & 1u) * 0x3F80u + ((m >> (2 * p + 1)) & 1u) * 0x3F800000u;
+        return u.f;
     }
     // one-hot A operand, rows = slots (this lane: slot c), contraction = keys in the permuted
-    // order of from_acc; `sl` points at the packed slots of the 32-key tile
-    static __device__ __forceinline__ frag onehot_perm(const uint16_t* sl, int s, int g, int c) {
-        union { u32x2v v; uint16_t h[4]; } lo, hi;
-        lo.v = *reinterpret_cast<const u32x2v*>(sl + 16 * s + 4 * g);
-        hi.v = *reinterpret_cast<const u32x2v*>(sl + 16 * s + 8 + 4 * g);
-        frag f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f[e] = slot_hit(lo.h[e], c) ? ONE : (short)0;
-            f[4 + e] = slot_hit(hi.h[e], c) ? ONE : (short)0;
-        }
-        return f;
+    // order of from_acc; `km` points at the slot masks of the 32-key tile (16-byte aligned)
+    static __device__ __forceinline__ frag onehot_perm(const uint32_t* km, int s, int g, int c) {
+        const u32x4v lo = *reinterpret_cast<const u32x4v*>(km + 16 * s + 4 * g);
+        const u32x4v hi = *reinterpret_cast<const u32x4v*>(km + 16 * s + 8 + 4 * g);
+        union { uint32_t w[4]; frag f; } u;
+        u.w[0] = ((lo[0] >> c) & 1u) * 0x3F80u + ((lo[1] >> c) & 1u) * 0x3F800000u;
+        u.w[1] = ((lo[2] >> c) & 1u) * 0x3F80u + ((lo[3] >> c) & 1u) * 0x3F800000u;
+        u.w[2] = ((hi[0] >> c) & 1u) * 0x3F80u + ((hi[1] >> c) & 1u) * 0x3F800000u;
+        u.w[3] = ((hi[2] >> c) & 1u) * 0x3F80u + ((hi[3] >> c) & 1u) * 0x3F800000u;
+        return u.f;
     }
 };
 
@@ -136,11 +139,11 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ frag load_perm(const elem* rowp, int s, int g) {
         return rowp[acc_row(s, g)];
     }
-    static __device__ __forceinline__ frag onehot_row(uint32_t packed, int ks, int g) {
-        return slot_hit(packed, ks * 2 + g) ? 1.f : 0.f;
+    static __device__ __forceinline__ frag onehot_row(uint32_t mask, int ks, int g) {
+        return (float)((mask >> (ks * 2 + g)) & 1u);
     }
-    static __device__ __forceinline__ frag onehot_perm(const uint16_t* sl, int s, int g, int c) {
-        return slot_hit(sl[acc_row(s, g)], c) ? 1.f : 0.f;
+    static __device__ __forceinline__ frag onehot_perm(const uint32_t* km, int s, int g, int c) {
+        return (float)((km[acc_row(s, g)] >> c) & 1u);
     }
 };
 
@@ -156,39 +159,51 @@ struct RelGeom {
     int mr;         // max_relative_position
 };
 
-// packed slots of key j (0xFFFF for padding keys j >= n)
-__device__ __forceinline__ uint16_t key_slots(int j, const RelGeom& G) {
-    if (j >= G.n) return 0xFFFFu;
-    if (j == 0) return (uint16_t)(G.gh | 0xFF00u);
+// slot mask of key j (0 for padding keys j >= n)
+__device__ __forceinline__ uint32_t key_mask(int j, const RelGeom& G) {
+    if (j >= G.n) return 0u;
+    if (j == 0) return 1u << G.gh;
     const int r = (j - 1) / G.gw, c = (j - 1) - r * G.gw;
-    return (uint16_t)(r | ((G.gh + 1 + c) << 8));
+    return (1u << r) | (1u << (G.gh + 1 + c));
 }
 
 constexpr int LP = 65;      // pitch (floats) of the per-wave [32][64] shift scratch rows
 
 // x_i[c]: extension of query i for slot c, from its bucket lookups row[0..31] (vertical
 // table) and row[32..63] (horizontal table).  Used for the key-side bias (row = q.T_k^T)
-// and, in backward, for d(slot sums) (row = dO.T_v^T).
-__device__ __forceinline__ float ext_gather(const float* row, int c, int qi, int qr, int qc,
+// and, in backward, for d(slot sums) (row = dO.T_v^T).  Branch-free: one LDS read per slot.
+__device__ __forceinline__ float ext_gather(const float* row, float cls, int c, int qi, int qr, int qc,
                                             const RelGeom& G) {
-    const float cls = row[0] + row[32];
-    if (qi == 0) return c <= G.gh ? cls : 0.f;
-    if (c < G.gh) return row[clampi(c - qr, -G.mr, G.mr) + G.mr + 1];
-    if (c == G.gh) return cls;
-    if (c <= G.gh + G.gw) return row[32 + clampi(c - G.gh - 1 - qc, -G.mr, G.mr) + G.mr + 1];
-    return 0.f;
+    const int iv = clampi(c - qr, -G.mr, G.mr) + G.mr + 1;
+    const int ih = 32 + clampi(c - G.gh - 1 - qc, -G.mr, G.mr) + G.mr + 1;
+    float x = row[c < G.gh ? iv : ih];
+    x = c == G.gh ? cls : x;
+    x = c > G.gh + G.gw ? 0.f : x;
+    const float x0 = c <= G.gh ? cls : 0.f;          // class-token query: every key has bucket 0
+    return qi == 0 ? x0 : x;
 }
 
-// adjoint of ext_gather: add the slot value x (slot c of query i) into the bucket rows
-__device__ __forceinline__ void ext_scatter(float* row, int c, float x, int qi, int qr, int qc,
-                                            const RelGeom& G) {
-    if (qi == 0) {
-        if (c <= G.gh) { row[0] += x; row[32] += x; }
-        return;
+// Adjoint of ext_gather, as a gather: bucket u (0..31) of table `tab` (0 vertical, 1 horizontal)
+// of query i from its 32 slot values slot[0..31] (LDS row).
+//   u = 0            : class-token key slot (or, for the class-token query, all slots <= gh)
+//   u = d + mr + 1   : the slot at relative distance d, plus everything clamped onto it
+__device__ __forceinline__ float bucket_from_slots(const float* slot, int u, int tab, int qi, int qr, int qc,
+                                                   const RelGeom& G) {
+    const int lim = tab == 0 ? G.gh : G.gw, base = tab == 0 ? 0 : G.gh + 1, pos0 = tab == 0 ? qr : qc;
+    const int d = u - G.mr - 1;
+    const int pos = pos0 + d;
+    const bool inside = u >= 1 && u <= 2 * G.mr + 1 && pos >= 0 && pos < lim;
+    float x = slot[inside ? base + pos : G.gh];       // u == 0 reads the class-token key slot
+    x = (inside || u == 0) ? x : 0.f;
+    if (lim - 1 > G.mr) {                             // clamped distances exist (wave-uniform)
+        if (d == -G.mr) for (int p = 0; p < pos && p < lim; ++p) x += slot[base + p];
+        if (d == G.mr) for (int p = (pos < 0 ? 0 : pos + 1); p < lim; ++p) x += slot[base + p];
     }
-    if (c < G.gh) row[clampi(c - qr, -G.mr, G.mr) + G.mr + 1] += x;
-    else if (c == G.gh) { row[0] += x; row[32] += x; }
-    else if (c <= G.gh + G.gw) row[32 + clampi(c - G.gh - 1 - qc, -G.mr, G.mr) + G.mr + 1] += x;
+    if (qi == 0) {                                    // class-token query: sum of all key slots
+        x = 0.f;
+        if (u == 0) for (int c = 0; c <= G.gh; ++c) x += slot[c];
+    }
+    return x;
 }
 
 // make LDS traffic of this wave visible to its own later reads (in-order LDS, compiler fence)

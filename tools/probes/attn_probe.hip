@@ -1,0 +1,49 @@
+// Phase-level cycle profile of the fused attention forward (development probe, not part of
+// the library): includes the kernel source with ATTN_PROFILE so that every wave records
+// s_memtime stamps at its phase boundaries.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Icream_amd/csrc \
+//         tools/probes/attn_probe.hip -o tools/probes/attn_probe && tools/probes/attn_probe
+#define ATTN_PROFILE 1
+#include "../../cream_amd/csrc/attn_rpe2d.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char** argv) {
+    const int B = 128, H = 6, N = 197, gh = 14, gw = 14, mr = 14, NP = 224;
+    const int64_t sn = 3 * H * 64, sb = (int64_t)N * sn, sh = 64;
+    std::vector<uint16_t> hq((size_t)B * N * sn);
+    srand(1);
+    for (auto& x : hq) { float f = (rand() / (float)RAND_MAX - 0.5f) * 2.f; uint32_t u; memcpy(&u, &f, 4); x = u >> 16; }
+    std::vector<float> ht(4 * 30 * 64);
+    for (auto& x : ht) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+    uint16_t *dqkv, *dout, *dsp; float *dt, *dlse; long long* dprof;
+    hipMalloc(&dqkv, hq.size() * 2); hipMalloc(&dout, (size_t)B * N * H * 64 * 2);
+    hipMalloc(&dsp, (size_t)B * H * 64 * NP * 2); hipMalloc(&dt, ht.size() * 4); hipMalloc(&dlse, (size_t)B * H * N * 4);
+    hipMalloc(&dprof, (size_t)B * H * 8 * 12 * 8);
+    hipMemcpy(dqkv, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &dprof, sizeof(dprof));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0);
+        int rc = cream_attn_rpe2d_fwd(dout, dlse, dsp, dqkv, dqkv + H * 64, dqkv + 2 * H * 64, sb, sn, sh, dt, dt + 1920,
+                                      dt + 3840, dt + 5760, 64, B, H, N, gh, gw, mr, 0.125f, CREAM_BF16, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("rc=%d fwd %.1f us\n", rc, ms * 1e3);
+    }
+    std::vector<long long> hp((size_t)B * H * 8 * 12);
+    hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost);
+    const char* names[] = {"fill+sync", "lookups", "build_ext", "S tiles", "softmax", "PV", "slots->bkt", "sp store", "bucket mma", "store O"};
+    double sum[10] = {0}; double tot = 0; int cnt = 0;
+    for (int blk = 0; blk < B * H; ++blk) for (int w = 0; w < 7; ++w) {
+        long long* d = &hp[((size_t)blk * 8 + w) * 12];
+        for (int i = 0; i < 10; ++i) sum[i] += (double)(d[i + 1] - d[i]);
+        tot += (double)(d[10] - d[0]); ++cnt;
+    }
+    for (int i = 0; i < 10; ++i) printf("%-12s %10.0f cycles\n", names[i], sum[i] / cnt);
+    printf("%-12s %10.0f cycles (s_memtime ticks, 100 MHz?)\n", "total", tot / cnt);
+    return 0;
+}
