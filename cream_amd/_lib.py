@@ -44,6 +44,15 @@ SIGNATURES = {
     "cream_attn_rpe2d_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                   _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cream_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cream_ln_partials": (_i, []),
+    "cream_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cream_gelu_fwd": (_i, [_vp, _vp, _i64, _vp]),
+    "cream_gelu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "cream_residual_add": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "cream_scale_cast": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "cream_colsum_slabs": (_i, [_i]),
+    "cream_colsum": (_i, [_vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

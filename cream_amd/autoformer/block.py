@@ -1,0 +1,265 @@
+"""One supernet transformer block as a single autograd node on the HIP kernels — the bf16
+throughput execution of TransformerEncoderLayer.forward
+(AutoFormer/model/supernet_transformer.py:251-287):
+
+    x1 = x  + drop_path(proj(attn(LN1(x))))
+    x2 = x1 + drop_path(fc2(gelu(fc1(LN2(x1)))))
+
+What runs where:
+  * LayerNorm (fwd/bwd), GELU (fwd/bwd), residual add + drop-path scale, bias-gradient column
+    sums: the fused HBM passes of csrc/block_ops.hip (fp32 residual stream, bf16 GEMM operands,
+    every activation crosses HBM once per direction);
+  * attention core: csrc/attn_rpe2d.hip (nothing of size N^2 in HBM);
+  * the dense projections: the GEMM library on bf16 MIRRORS of the fp32 master weights, read in
+    place through strided `W[:out, :in]` views (leading dimension = super width); weight
+    gradients are split-K batched GEMMs (K = 25k tokens is split 8 ways, partial products
+    summed in fp32) accumulated straight into the active slice of the fp32 `.grad`.
+The backward is written by hand; parameter gradients are accumulated into `p.grad` directly
+and announced through `notify_grads_ready` (the gradient reducer starts a block's all-reduce
+the moment its last gradient exists).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib, timing
+from . import fused_attention
+
+_WGRAD_SPLIT = 8
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- thin wrappers over the C ABI ------------------------------------------------------------
+def ln_fwd(x2d, gamma, beta, eps):
+    M, E = x2d.shape
+    y = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    with timing.region("ln_fwd", nbytes=M * E * 6):
+        _lib.check(_lib.load().cream_ln_fwd(_p(y), _p(mean), _p(rstd), _p(x2d), _p(gamma), _p(beta), M, E,
+                                           float(eps), _stream()), "cream_ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
+    M, E = x2d.shape
+    lib = _lib.load()
+    dx = torch.empty((M, E), dtype=torch.float32, device=x2d.device)
+    dxs = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device) if want_scaled else None
+    partial = torch.empty((lib.cream_ln_partials(), 2, E), dtype=torch.float32, device=x2d.device)
+    with timing.region("ln_bwd", nbytes=M * E * (2 + 4 + 4 + 4 + (2 if want_scaled else 0))):
+        _lib.check(lib.cream_ln_bwd(_p(dx), _p(dxs), _p(partial), _p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma),
+                                    _p(dres), _p(sample_scale), rows_per_sample, M, E, _stream()), "cream_ln_bwd")
+    return dx, dxs, partial.sum(dim=0)
+
+
+def gelu_fwd(h):
+    g = torch.empty_like(h)
+    with timing.region("gelu_fwd", nbytes=h.numel() * 4):
+        _lib.check(_lib.load().cream_gelu_fwd(_p(g), _p(h), h.numel(), _stream()), "cream_gelu_fwd")
+    return g
+
+
+def gelu_bwd(dg, h):
+    dh = torch.empty_like(h)
+    with timing.region("gelu_bwd", nbytes=h.numel() * 6):
+        _lib.check(_lib.load().cream_gelu_bwd(_p(dh), _p(dg), _p(h), h.numel(), _stream()), "cream_gelu_bwd")
+    return dh
+
+
+def residual_add(x2d, y, sample_scale, per_sample):
+    out = torch.empty_like(x2d)
+    with timing.region("residual_add", nbytes=x2d.numel() * 10):
+        _lib.check(_lib.load().cream_residual_add(_p(out), _p(x2d), _p(y), _p(sample_scale), x2d.numel(), per_sample,
+                                                  _stream()), "cream_residual_add")
+    return out
+
+
+def scale_cast(x2d, sample_scale, per_sample):
+    out = torch.empty(x2d.shape, dtype=torch.bfloat16, device=x2d.device)
+    with timing.region("scale_cast", nbytes=x2d.numel() * 6):
+        _lib.check(_lib.load().cream_scale_cast(_p(out), _p(x2d), _p(sample_scale), x2d.numel(), per_sample,
+                                                _stream()), "cream_scale_cast")
+    return out
+
+
+def colsum(a):
+    M, C = a.shape
+    lib = _lib.load()
+    partial = torch.empty((lib.cream_colsum_slabs(M), C), dtype=torch.float32, device=a.device)
+    with timing.region("colsum", nbytes=a.numel() * 2):
+        _lib.check(lib.cream_colsum(_p(partial), _p(a), M, C, _stream()), "cream_colsum")
+    return partial.sum(dim=0)
+
+
+def wgrad(dy, x):
+    """dW (out, in) fp32 = dy^T x with the token dimension split _WGRAD_SPLIT ways (the
+    library's single-pass TN GEMM leaves most CUs idle on a 25k-deep contraction)."""
+    M = dy.shape[0]
+    s = _WGRAD_SPLIT
+    while M % s:
+        s //= 2
+    part = torch.bmm(dy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1))
+    return part.sum(dim=0, dtype=torch.float32)
+
+
+# ---- bf16 mirrors of the fp32 master weights --------------------------------------------------
+class Mirror:
+    """bf16 copies of parameters, refreshed when the parameter's version counter moves (the
+    optimizer step bumps it).  `refresh_all` converts everything in a few fused launches."""
+
+    def __init__(self):
+        self._m = {}
+
+    def get(self, p):
+        e = self._m.get(id(p))
+        if e is None or e[1] != p._version or e[0].device != p.device:
+            m = p.detach().to(torch.bfloat16) if e is None or e[0].device != p.device else e[0].copy_(p.detach())
+            self._m[id(p)] = e = (m, p._version, p)
+        return e[0]
+
+    def refresh_all(self):
+        stale = [e for e in self._m.values() if e[1] != e[2]._version]
+        if stale:
+            torch._foreach_copy_([e[0] for e in stale], [e[2].detach() for e in stale])
+            for e in stale:
+                self._m[id(e[2])] = (e[0], e[2]._version, e[2])
+
+
+MIRROR = Mirror()
+_grad_ready_hooks = []
+
+
+def on_grads_ready(fn):
+    """Register fn(params) to be called when a block has finished writing these `.grad`s."""
+    _grad_ready_hooks.append(fn)
+    return fn
+
+
+def remove_grads_ready(fn):
+    if fn in _grad_ready_hooks:
+        _grad_ready_hooks.remove(fn)
+
+
+def _acc(p, sl, g):
+    """p.grad[sl] += g (fp32), creating a zero gradient if the parameter has none yet."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    p.grad[sl].add_(g)
+
+
+def supported(blk, x):
+    a = blk.attn
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and blk.normalize_before and not blk.scale
+            and a.relative_position and a.change_qkv and not a.fc_scale
+            and (not blk.training or (a.attn_drop.p == 0.0 and (blk.sample_dropout or 0.0) == 0.0
+                                      and (blk.sample_attn_dropout or 0.0) == 0.0 and a.proj_drop.p == 0.0))
+            and fused_attention.grid_of(x.shape[1], a.max_relative_position) is not None
+            and a.rel_pos_embed_k.embeddings_table_v.shape[1] == 64
+            and blk.sample_embed_dim % 8 == 0 and blk.sample_ffn_embed_dim_this_layer % 8 == 0
+            and blk.sample_out_dim == blk.sample_embed_dim)
+
+
+class BlockFunction(torch.autograd.Function):
+    """x (B, N, E) fp32 -> x2 (B, N, E) fp32.  dp1 / dp2: per-sample drop-path scales (B,) or None."""
+
+    @staticmethod
+    def forward(ctx, x, dp1, dp2, blk):
+        B, N, E = x.shape
+        M = B * N
+        at = blk.attn
+        H = at.sample_num_heads
+        Q = at.sample_qk_embed_dim
+        F_ = blk.sample_ffn_embed_dim_this_layer
+        mr = at.max_relative_position
+        mir = MIRROR.get
+        x2d = x.contiguous().view(M, E)
+        ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
+
+        a, mean1, rstd1 = ln_fwd(x2d, ln1.weight[:E], ln1.bias[:E], ln1.eps)
+        # qkv rows regrouped [q | k | v] from the interleaved super weight (qkv_super.py:72-77);
+        # bias is the plain prefix (qkv_super.py:80-83)
+        wqkv = mir(at.qkv.weight)[:3 * Q, :E].view(Q, 3, E).transpose(0, 1).reshape(3 * Q, E)
+        qkv = torch.addmm(mir(at.qkv.bias)[:3 * Q], a, wqkv.t())
+        tabs = (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
+                at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
+        tabs = tuple(t.detach() for t in tabs)
+        o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
+        o2d = o.view(M, Q)
+        wproj = mir(at.proj.weight)[:E, :Q]
+        p = torch.addmm(mir(at.proj.bias)[:E], o2d, wproj.t())
+        x1 = residual_add(x2d, p, dp1, N * E)
+        c, mean2, rstd2 = ln_fwd(x1, ln2.weight[:E], ln2.bias[:E], ln2.eps)
+        w1 = mir(blk.fc1.weight)[:F_, :E]
+        h = torch.addmm(mir(blk.fc1.bias)[:F_], c, w1.t())
+        g = gelu_fwd(h)
+        w2 = mir(blk.fc2.weight)[:E, :F_]
+        f = torch.addmm(mir(blk.fc2.bias)[:E], g, w2.t())
+        x2 = residual_add(x1, f, dp2, N * E)
+
+        ctx.blk = blk
+        ctx.dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
+        ctx.dp = (dp1, dp2)
+        ctx.save_for_backward(x2d, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
+        return x2.view(B, N, E)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        blk = ctx.blk
+        at = blk.attn
+        B, N, E, H, Q, F_, mr, scale = ctx.dims
+        dp1, dp2 = ctx.dp
+        M = B * N
+        x2d, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g = ctx.saved_tensors
+        mir = MIRROR.get
+        ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
+        dx2 = dx2.contiguous().view(M, E)
+
+        # ---- MLP branch -----------------------------------------------------------------------
+        df = scale_cast(dx2, dp2, N * E)                                   # d(fc2 out) = s_b * dx2
+        _acc(blk.fc2.weight, (slice(0, E), slice(0, F_)), wgrad(df, g))
+        _acc(blk.fc2.bias, slice(0, E), colsum(df))
+        dg = df @ mir(blk.fc2.weight)[:E, :F_]
+        dh = gelu_bwd(dg, h)
+        _acc(blk.fc1.weight, (slice(0, F_), slice(0, E)), wgrad(dh, c))
+        _acc(blk.fc1.bias, slice(0, F_), colsum(dh))
+        dc = dh @ mir(blk.fc1.weight)[:F_, :E]
+        dx1, dp, part2 = ln_bwd(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
+        _acc(ln2.weight, slice(0, E), part2[0])
+        _acc(ln2.bias, slice(0, E), part2[1])
+
+        # ---- attention branch (dp = s_b * dx1 is the gradient of the proj output) ---------------
+        _acc(at.proj.weight, (slice(0, E), slice(0, Q)), wgrad(dp, o.view(M, Q)))
+        _acc(at.proj.bias, slice(0, E), colsum(dp))
+        do = dp @ mir(at.proj.weight)[:E, :Q]
+        tabs_p = (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
+                  at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
+        dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
+                                                  *(t.detach() for t in tabs_p), o, lse, sp, scale, mr)
+        nb = tabs_p[0].shape[0]
+        for i, t in enumerate(tabs_p):
+            _acc(t, slice(None), dtab[i, :nb])
+        dqkv2d = dqkv.view(M, 3 * Q)
+        dwq = wgrad(dqkv2d, a)                                             # rows [q | k | v]
+        if at.qkv.weight.grad is None:
+            at.qkv.weight.grad = torch.zeros_like(at.qkv.weight)
+        gq = at.qkv.weight.grad
+        gq[:3 * Q].view(Q, 3, gq.shape[1])[:, :, :E].add_(dwq.view(3, Q, E).transpose(0, 1))
+        _acc(at.qkv.bias, slice(0, 3 * Q), colsum(dqkv2d))
+        da = dqkv2d @ wqkv
+        dx, _, part1 = ln_bwd(da, x2d, mean1, rstd1, ln1.weight[:E], dx1, None, N, False)
+        _acc(ln1.weight, slice(0, E), part1[0])
+        _acc(ln1.bias, slice(0, E), part1[1])
+
+        if _grad_ready_hooks:
+            params = [p for p in blk.parameters() if p.requires_grad]
+            for fn in _grad_ready_hooks:
+                fn(params)
+        return dx.view(B, N, E), None, None, None

@@ -17,6 +17,7 @@ import random
 import torch
 import torch.nn.functional as F
 
+from . import block as _block
 from .supernet import Vision_TransformerSuper
 
 # AutoFormer/experiments/supernet/supernet-{T,S,B}.yaml
@@ -129,4 +130,5 @@ class SupernetTrainer:
         if self.max_norm and self.max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
         self.optimizer.step()
+        _block.MIRROR.refresh_all()          # bf16 operand copies of the updated master weights
         return loss

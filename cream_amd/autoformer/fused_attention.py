@@ -58,24 +58,59 @@ def _flops(B, H, N):
     return 2 * B * H * NP * NP * (96 + 96) + 2 * B * H * NP * 64 * 64 * 2
 
 
+def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
+    """qkv (B, N, 3, H, 64) -> (out (B, N, H, 64), lse (B, H, N), sp (B, H, 64, NP)).  One launch."""
+    B, N, _, H, D = qkv.shape
+    gh, gw = grid_of(N, mr)
+    NP = padded_len(N)
+    out = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    sp = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
+    lib = _lib.load()
+    with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_fwd", flops=_flops(B, H, N)):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.cream_attn_rpe2d_fwd(
+            _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
+            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
+            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_fwd")
+    return out, lse, sp
+
+
+def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr):
+    """-> (dqkv (B, N, 3, H, 64), dtab (4, 32, 64) fp32 = gradients of [tkv, tkh, tvv, tvh] rows)."""
+    B, N, _, H, D = qkv.shape
+    gh, gw = grid_of(N, mr)
+    NP = padded_len(N)
+    dout = dout.contiguous()
+    dqkv = torch.empty((B, N, 3, H, D), dtype=qkv.dtype, device=qkv.device)
+    # side buffers of the two backward launches (see include/cream_amd.h)
+    dlt = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
+    qe = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
+    de = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
+    delta = torch.empty((B, H, NP), dtype=torch.float32, device=qkv.device)
+    dtab = torch.empty((B * H, 4, 32, 64), dtype=torch.float32, device=qkv.device)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
+    dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+    dsb, dsn, dsh = dqkv.stride(0), dqkv.stride(1), dqkv.stride(3)
+    lib = _lib.load()
+    with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=3 * _flops(B, H, N)):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.cream_attn_rpe2d_bwd(
+            _ptr(dq), _ptr(dk), _ptr(dv), dsb, dsn, dsh, _ptr(dtab),
+            _ptr(dlt), _ptr(qe), _ptr(de), _ptr(delta),
+            _ptr(dout), _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
+            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
+            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
+    return dqkv, dtab.sum(dim=0)                              # fixed-order reduction over (b, h)
+
+
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, tkv, tkh, tvv, tvh, scale, mr):
-        B, N, _, H, D = qkv.shape
-        gh, gw = grid_of(N, mr)
-        NP = padded_len(N)
-        out = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-        sp = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
-        lib = _lib.load()
-        with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_fwd", flops=_flops(B, H, N)):
-            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.check(lib.cream_attn_rpe2d_fwd(
-                _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
-                _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
-                B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_fwd")
+        out, lse, sp = attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr)
         ctx.save_for_backward(qkv, tkv, tkh, tvv, tvh, out, lse, sp)
         ctx.scale, ctx.mr = float(scale), mr
         return out
@@ -83,32 +118,8 @@ class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         qkv, tkv, tkh, tvv, tvh, out, lse, sp = ctx.saved_tensors
-        B, N, _, H, D = qkv.shape
-        gh, gw = grid_of(N, ctx.mr)
-        NP = padded_len(N)
-        dout = dout.contiguous()
-        dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
-        # side buffers of the two backward launches (see include/cream_amd.h)
-        dlt = torch.empty((B, H, 64, NP), dtype=qkv.dtype, device=qkv.device)
-        qe = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
-        de = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
-        delta = torch.empty((B, H, NP), dtype=torch.float32, device=qkv.device)
-        dtab = torch.empty((B * H, 4, 32, 64), dtype=torch.float32, device=qkv.device)
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
-        dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
-        dsb, dsn, dsh = dqkv.stride(0), dqkv.stride(1), dqkv.stride(3)
-        lib = _lib.load()
-        with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=3 * _flops(B, H, N)):
-            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.check(lib.cream_attn_rpe2d_bwd(
-                _ptr(dq), _ptr(dk), _ptr(dv), dsb, dsn, dsh, _ptr(dtab),
-                _ptr(dlt), _ptr(qe), _ptr(de), _ptr(delta),
-                _ptr(dout), _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
-                _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
-                B, H, N, gh, gw, ctx.mr, ctx.scale, _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
+        dqkv, dt = attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, ctx.scale, ctx.mr)
         nb = tkv.shape[0]
-        dt = dtab.sum(dim=0)                                  # fixed-order reduction over (b, h)
         return (dqkv, dt[0, :nb].to(tkv.dtype), dt[1, :nb].to(tkh.dtype), dt[2, :nb].to(tvv.dtype),
                 dt[3, :nb].to(tvh.dtype), None, None)
 

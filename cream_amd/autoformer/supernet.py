@@ -15,7 +15,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import block as _block
 from .modules import AttentionSuper, LayerNormSuper, LinearSuper, PatchembedSuper, _trunc_normal_
+
+
+def _bf16_autocast(x):
+    return (x.is_cuda and torch.is_autocast_enabled('cuda')
+            and torch.get_autocast_dtype('cuda') == torch.bfloat16)
 
 
 def gelu(x):
@@ -64,6 +70,8 @@ class TransformerEncoderLayer(nn.Module):
         self.sample_dropout = None
         self.sample_attn_dropout = None
         self.is_identity_layer = None
+        self.fused = True           # allow the fused-block execution under bf16 autocast
+        self._dp = None             # drop-path scales handed down by the model for this forward
 
         self.attn = AttentionSuper(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
                                    attn_drop=attn_drop, proj_drop=dropout, scale=self.scale,
@@ -101,9 +109,23 @@ class TransformerEncoderLayer(nn.Module):
         assert before ^ after
         return layer_norm(x) if (after ^ self.normalize_before) else x
 
+    def drop_path_scales(self, batch, device):
+        """Per-sample scales mask/keep of the two DropPath applications of this block (or None)."""
+        p = getattr(self.drop_path, 'drop_prob', None)
+        if not p or not self.training:
+            return None, None
+        keep = 1.0 - p
+        s = torch.floor(keep + torch.rand(2, batch, device=device)) / keep
+        return s[0], s[1]
+
     def forward(self, x):
         if self.is_identity_layer:
             return x
+        # bf16 throughput mode: the whole block is one autograd node on the HIP kernels
+        if self.fused and _bf16_autocast(x) and _block.supported(self, x):
+            dp = self._dp if self._dp is not None else self.drop_path_scales(x.shape[0], x.device)
+            self._dp = None
+            return _block.BlockFunction.apply(x, dp[0], dp[1], self)
         residual = x
         x = self.maybe_layer_norm(self.attn_layer_norm, x, before=True)
         x = self.attn(x)
@@ -250,6 +272,14 @@ class Vision_TransformerSuper(nn.Module):
         if self.abs_pos:
             x = x + self.pos_embed[..., :E]
         x = F.dropout(x, p=self.sample_dropout, training=self.training)
+        if self.training and _bf16_autocast(x):
+            # all drop-path draws of this forward in three launches instead of 3 per block
+            keep = 1.0 - torch.tensor([getattr(b.drop_path, 'drop_prob', 0.0) or 0.0 for b in self.blocks],
+                                      device=x.device).view(-1, 1, 1)
+            scales = torch.floor(keep + torch.rand(len(self.blocks), 2, B, device=x.device)) / keep
+            for i, blk in enumerate(self.blocks):
+                if getattr(blk.drop_path, 'drop_prob', None):
+                    blk._dp = (scales[i, 0], scales[i, 1])
         for blk in self.blocks:
             x = blk(x)
         if self.pre_norm:

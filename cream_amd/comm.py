@@ -60,6 +60,16 @@ class GradReducer:
         if self.world > 1:
             for _, p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+            # fused blocks write their parameter gradients themselves and announce them
+            from .autoformer import block as _block
+            self._ready_cb = _block.on_grads_ready(lambda params: [self._hook(p) for p in params])
+
+    def close(self):
+        cb = getattr(self, "_ready_cb", None)
+        if cb is not None:
+            from .autoformer import block as _block
+            _block.remove_grads_ready(cb)
+            self._ready_cb = None
 
     @staticmethod
     def _default_bucket_of(name):
@@ -91,8 +101,8 @@ class GradReducer:
             self.pending[b] = len(mem)
 
     def _hook(self, p):
-        b = self.bucket_index[id(p)]
-        if b not in self.pending:
+        b = self.bucket_index.get(id(p))
+        if b is None or b not in self.pending:
             return
         self.pending[b] -= 1
         if self.pending[b] == 0:

@@ -1,0 +1,357 @@
+// block_ops.hip — the HBM-bound passes of one supernet transformer block (gfx950), fused so
+// that every activation crosses HBM once per direction.
+//
+// Reference semantics: AutoFormer/model/supernet_transformer.py:251-287 (pre-norm block):
+//     x1 = x  + drop_path(proj(attn(LN1(x))))          LayerNormSuper: layernorm_super.py:26-37
+//     x2 = x1 + drop_path(fc2(gelu(fc1(LN2(x1)))))     gelu in fp32: supernet_transformer.py:14-16
+// The residual stream stays fp32 (as under the reference's autocast, where LayerNorm and the
+// residual adds run in fp32), GEMM operands are bf16.  Kernels here:
+//     ln_fwd         x(f32) -> LN(x)(bf16) + (mean, rstd)
+//     ln_bwd         dy(bf16), x, stats, gamma, dres(f32) -> dx = dres + LN'(dy)  (f32),
+//                    optionally also s_b * dx as bf16 (the gradient entering the previous
+//                    branch: drop-path scale fused), per-workgroup partials of dgamma/dbeta
+//     gelu_fwd/bwd   exact (erf) GELU evaluated in fp32 on bf16 storage
+//     residual_add   x + s_b * y   (y bf16 branch output, s_b per-sample drop-path scale)
+//     scale_cast     s_b * dx -> bf16
+//     colsum         column sums of a bf16 (M, C) matrix in fp32 (bias gradients), two-stage,
+//                    fixed order
+// All are one-pass, 16-byte vectorised, no atomics (deterministic).  Rows are contiguous
+// (leading dimension = the sampled width E: activations live in our own buffers).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "attn_common.hpp"
+#include "cream_amd.h"
+
+namespace {
+using namespace cream;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ void unpack_bf16x4(u32x2v v, float (&f)[4]) {
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xFFFF0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xFFFF0000u);
+}
+__device__ __forceinline__ u32x2v pack_bf16x4(const float (&f)[4]) {
+    return u32x2v{f2bf_pair(f[0], f[1]), f2bf_pair(f[2], f[3])};
+}
+
+constexpr int LN_MAXC = 5;          // float4 chunks per lane: E <= 64 * 4 * 5 = 1280
+
+// ---- LayerNorm forward: one wave per row ------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int M, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = E >> 2;
+    const float* xr = x + (int64_t)row * E;
+    f32x4v v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nch ? *reinterpret_cast<const f32x4v*>(xr + 4 * c) : f32x4v{0, 0, 0, 0};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mu = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)E + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    uint16_t* yr = y + (int64_t)row * E;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const f32x4v g = *reinterpret_cast<const f32x4v*>(gamma + 4 * c);
+            const f32x4v b = *reinterpret_cast<const f32x4v*>(beta + 4 * c);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+            *reinterpret_cast<u32x2v*>(yr + 4 * c) = pack_bf16x4(o);
+        }
+    }
+}
+
+// ---- LayerNorm backward (+ residual gradient, + optional scaled bf16 copy) ------------
+// grid = P workgroups of 4 waves; wave w of workgroup p walks rows (p*4 + w), += 4P, ...
+// partial[p][0][c] = sum dy*xhat (dgamma), partial[p][1][c] = sum dy (dbeta) over its rows
+__global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uint16_t* __restrict__ dxs,
+                                                     float* __restrict__ partial, const uint16_t* __restrict__ dy,
+                                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dres, const float* __restrict__ sscale,
+                                                     int rows_per_sample, int M, int E) {
+    __shared__ float red[4][2][LN_MAXC * 256 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = E >> 2;
+    f32x4v g[LN_MAXC], ag[LN_MAXC], ab[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        g[i] = c < nch ? *reinterpret_cast<const f32x4v*>(gamma + 4 * c) : f32x4v{0, 0, 0, 0};
+        ag[i] = f32x4v{0, 0, 0, 0};
+        ab[i] = f32x4v{0, 0, 0, 0};
+    }
+    const float invE = 1.f / (float)E;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + (int64_t)row * E;
+        const uint16_t* dyr = dy + (int64_t)row * E;
+        float xh[LN_MAXC][4], d[LN_MAXC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + 4 * c);
+                unpack_bf16x4(*reinterpret_cast<const u32x2v*>(dyr + 4 * c), d[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    ag[i][e] += d[i][e] * xh[i][e];
+                    ab[i][e] += d[i][e];
+                    const float dg = d[i][e] * g[i][e];
+                    d[i][e] = dg;
+                    s1 += dg;
+                    s2 += dg * xh[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) * invE;
+        s2 = wave_sum(s2) * invE;
+        const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                f32x4v r = dres ? *reinterpret_cast<const f32x4v*>(dres + (int64_t)row * E + 4 * c) : f32x4v{0, 0, 0, 0};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[e] += rs * (d[i][e] - s1 - xh[i][e] * s2);
+                    o[e] = r[e] * sc;
+                }
+                *reinterpret_cast<f32x4v*>(dx + (int64_t)row * E + 4 * c) = r;
+                if (dxs) *reinterpret_cast<u32x2v*>(dxs + (int64_t)row * E + 4 * c) = pack_bf16x4(o);
+            }
+        }
+    }
+    // workgroup partials: waves 1..3 hand their sums to wave 0 through LDS
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][(i * 64 + lane) * 4 + e] = ag[i][e];
+            red[wave][1][(i * 64 + lane) * 4 + e] = ab[i][e];
+        }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * E; k += 256) {
+        const int which = k >= E, c = k - which * E;
+        const float s = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        partial[((int64_t)blockIdx.x * 2 + which) * E + c] = s;
+    }
+}
+
+// ---- GELU -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(uint16_t* __restrict__ g, const uint16_t* __restrict__ h,
+                                                       int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(h + 8 * i);
+        float a[4], b[4];
+        unpack_bf16x4(u32x2v{v[0], v[1]}, a);
+        unpack_bf16x4(u32x2v{v[2], v[3]}, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = gelu_f(a[e]); b[e] = gelu_f(b[e]); }
+        const u32x2v pa = pack_bf16x4(a), pb = pack_bf16x4(b);
+        *reinterpret_cast<u32x4v*>(g + 8 * i) = u32x4v{pa[0], pa[1], pb[0], pb[1]};
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(uint16_t* __restrict__ dh, const uint16_t* __restrict__ dg,
+                                                       const uint16_t* __restrict__ h, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4v hv = *reinterpret_cast<const u32x4v*>(h + 8 * i);
+        const u32x4v gv = *reinterpret_cast<const u32x4v*>(dg + 8 * i);
+        float a[4], b[4], ga[4], gb[4];
+        unpack_bf16x4(u32x2v{hv[0], hv[1]}, a);
+        unpack_bf16x4(u32x2v{hv[2], hv[3]}, b);
+        unpack_bf16x4(u32x2v{gv[0], gv[1]}, ga);
+        unpack_bf16x4(u32x2v{gv[2], gv[3]}, gb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = ga[e] * gelu_grad_f(a[e]); b[e] = gb[e] * gelu_grad_f(b[e]); }
+        const u32x2v pa = pack_bf16x4(a), pb = pack_bf16x4(b);
+        *reinterpret_cast<u32x4v*>(dh + 8 * i) = u32x4v{pa[0], pa[1], pb[0], pb[1]};
+    }
+}
+
+// ---- residual add: out = x + s_b * y ------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_add_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                           const uint16_t* __restrict__ y, const float* __restrict__ ss,
+                                                           int64_t n4, int64_t per_sample4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4v xv = *reinterpret_cast<const f32x4v*>(x + 4 * i);
+        float yv[4];
+        unpack_bf16x4(*reinterpret_cast<const u32x2v*>(y + 4 * i), yv);
+        const float s = ss ? ss[i / per_sample4] : 1.f;
+        *reinterpret_cast<f32x4v*>(out + 4 * i) =
+            f32x4v{xv[0] + s * yv[0], xv[1] + s * yv[1], xv[2] + s * yv[2], xv[3] + s * yv[3]};
+    }
+}
+
+// ---- scale + cast: out(bf16) = s_b * x(f32) ----------------------------------------------------
+__global__ __launch_bounds__(256) void scale_cast_kernel(uint16_t* __restrict__ out, const float* __restrict__ x,
+                                                         const float* __restrict__ ss, int64_t n4, int64_t per_sample4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4v xv = *reinterpret_cast<const f32x4v*>(x + 4 * i);
+        const float s = ss ? ss[i / per_sample4] : 1.f;
+        const float o[4] = {xv[0] * s, xv[1] * s, xv[2] * s, xv[3] * s};
+        *reinterpret_cast<u32x2v*>(out + 4 * i) = pack_bf16x4(o);
+    }
+}
+
+// ---- column sums of a bf16 (M, C) matrix: partial[p][c] over the rows of slab p ---------
+// block = 256 threads = 32 column groups of 8 columns x 8 row lanes; grid = (ceil(C/256), P)
+__global__ __launch_bounds__(256) void colsum_kernel(float* __restrict__ partial, const uint16_t* __restrict__ a,
+                                                     int M, int C, int rows_per_slab) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const u32x4v v = *reinterpret_cast<const u32x4v*>(a + (int64_t)r * C + c0);
+            float f0[4], f1[4];
+            unpack_bf16x4(u32x2v{v[0], v[1]}, f0);
+            unpack_bf16x4(u32x2v{v[2], v[3]}, f1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += f0[e]; acc[4 + e] += f1[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+        partial[(int64_t)blockIdx.y * C + c] = s;
+    }
+}
+
+int grid_for(int64_t n_items, int per_block) {
+    const int64_t b = (n_items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cream_ln_partials(void) { return 512; }
+
+int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
+                 int M, int E, float eps, void* stream)
+{
+    if (M < 0 || E <= 0) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!y || !mean || !rstd || !x || !gamma || !beta) return CREAM_ERR_BAD_ARG;
+    if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
+    if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+                       x, gamma, beta, M, E, eps);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, const float* dres, const float* sample_scale,
+                 int rows_per_sample, int M, int E, void* stream)
+{
+    if (M <= 0 || E <= 0 || rows_per_sample <= 0) return CREAM_ERR_BAD_ARG;
+    if (!dx || !partial || !dy || !x || !mean || !rstd || !gamma) return CREAM_ERR_BAD_ARG;
+    if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
+    if (((uintptr_t)dx | (uintptr_t)dx_scaled | (uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dres) % 16)
+        return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
+                       (uint16_t*)dx_scaled, partial, (const uint16_t*)dy, x, mean, rstd, gamma, dres, sample_scale,
+                       rows_per_sample, M, E);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_gelu_fwd(void* g, const void* h, int64_t n, void* stream)
+{
+    if (n < 0 || n % 8) return CREAM_ERR_BAD_ARG;
+    if (n == 0) return CREAM_OK;
+    if (!g || !h || ((uintptr_t)g | (uintptr_t)h) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)g,
+                       (const uint16_t*)h, n / 8);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_gelu_bwd(void* dh, const void* dg, const void* h, int64_t n, void* stream)
+{
+    if (n < 0 || n % 8) return CREAM_ERR_BAD_ARG;
+    if (n == 0) return CREAM_OK;
+    if (!dh || !dg || !h || ((uintptr_t)dh | (uintptr_t)dg | (uintptr_t)h) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dh,
+                       (const uint16_t*)dg, (const uint16_t*)h, n / 8);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_residual_add(float* out, const float* x, const void* y, const float* sample_scale,
+                       int64_t n, int64_t per_sample, void* stream)
+{
+    if (n < 0 || n % 4 || per_sample <= 0 || per_sample % 4) return CREAM_ERR_BAD_ARG;
+    if (n == 0) return CREAM_OK;
+    if (!out || !x || !y || ((uintptr_t)out | (uintptr_t)x) % 16 || (uintptr_t)y % 8) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(residual_add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, x,
+                       (const uint16_t*)y, sample_scale, n / 4, per_sample / 4);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_scale_cast(void* out, const float* x, const float* sample_scale, int64_t n, int64_t per_sample,
+                     void* stream)
+{
+    if (n < 0 || n % 4 || per_sample <= 0 || per_sample % 4) return CREAM_ERR_BAD_ARG;
+    if (n == 0) return CREAM_OK;
+    if (!out || !x || (uintptr_t)x % 16 || (uintptr_t)out % 8) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)out,
+                       x, sample_scale, n / 4, per_sample / 4);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_colsum_slabs(int M) { return M <= 0 ? 0 : (M + 511) / 512; }
+
+int cream_colsum(float* partial, const void* a, int M, int C, void* stream)
+{
+    if (M < 0 || C <= 0 || C % 8) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!partial || !a || (uintptr_t)a % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, cream_colsum_slabs(M)), dim3(256), 0, (hipStream_t)stream,
+                       partial, (const uint16_t*)a, M, C, 512);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+}  // extern "C"

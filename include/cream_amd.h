@@ -132,6 +132,46 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
                          int ldt, int B, int H, int N, int gh, int gw, int mr,
                          float scale, int dtype, void* stream);
 
+/* ---- HBM-bound passes of one supernet transformer block ------------------------------------
+ * Reference: TransformerEncoderLayer.forward, AutoFormer/model/supernet_transformer.py:251-287
+ * (pre-norm block), LayerNormSuper.forward (model/module/layernorm_super.py:26-37), gelu in
+ * fp32 (supernet_transformer.py:14-16), DropPath (model/utils.py:68-98).  The residual stream
+ * is fp32 (as under the reference's autocast), GEMM operands are bf16.  All matrices are
+ * row-major and contiguous with leading dimension = their width.  No atomics anywhere. */
+
+/* y(bf16, M x E) = LayerNorm(x(f32))*gamma + beta over the last dim; mean/rstd (M) saved. */
+int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma,
+                 const float* beta, int M, int E, float eps, void* stream);
+
+/* Number of row slabs ln_bwd reduces over: partial must hold cream_ln_partials()*2*E floats. */
+int cream_ln_partials(void);
+
+/* dx(f32) = dres + dLayerNorm(dy(bf16)); if dx_scaled != NULL also writes
+ * bf16(dx * sample_scale[row / rows_per_sample]) (sample_scale may be NULL = 1): the gradient
+ * entering the previous residual branch with its drop-path scale.  dres may be NULL.
+ * partial[p][0][:] / partial[p][1][:] = per-slab sums for dgamma / dbeta (caller adds the
+ * slabs: fixed order). */
+int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, const float* x,
+                 const float* mean, const float* rstd, const float* gamma, const float* dres,
+                 const float* sample_scale, int rows_per_sample, int M, int E, void* stream);
+
+/* g = gelu(h) / dh = dg * gelu'(h): exact erf GELU evaluated in fp32, bf16 storage; n % 8 == 0 */
+int cream_gelu_fwd(void* g, const void* h, int64_t n, void* stream);
+int cream_gelu_bwd(void* dh, const void* dg, const void* h, int64_t n, void* stream);
+
+/* out(f32) = x(f32) + sample_scale[i / per_sample] * y(bf16)   (flat index i; scale may be NULL) */
+int cream_residual_add(float* out, const float* x, const void* y, const float* sample_scale,
+                       int64_t n, int64_t per_sample, void* stream);
+
+/* out(bf16) = sample_scale[i / per_sample] * x(f32) */
+int cream_scale_cast(void* out, const float* x, const float* sample_scale, int64_t n,
+                     int64_t per_sample, void* stream);
+
+/* Bias gradients: partial[s][c] = sum of a(bf16, M x C)[r][c] over the rows of slab s
+ * (cream_colsum_slabs(M) slabs of 512 rows); the caller adds the slabs. */
+int cream_colsum_slabs(int M);
+int cream_colsum(float* partial, const void* a, int M, int C, void* stream);
+
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif
