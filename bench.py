@@ -100,6 +100,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.supernet, a.cpu_seconds)
 
+    gemm_sel = engine.enable_gemm_selection(a.supernet, a.batch) if a.dtype == "bf16" else False
     torch.manual_seed(0 + rank)                               # supernet_train.py:196-198
     model = engine.build_supernet(a.supernet, drop_path_rate=0.1).to(dev)
     for m in model.modules():
@@ -174,7 +175,8 @@ def main():
             "config": {"workload": f"AutoFormer-{a.supernet} supernet train step, random-path sampling "
                                    f"(random.seed(epoch)), per-GPU batch {a.batch}, 224x224, AdamW, "
                                    f"grad all-reduce RCCL", "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "attention_impl": a.impl},
+                       "parallelism": f"dp{world}", "attention_impl": a.impl,
+                       "gemm_selection": "offline table" if gemm_sel else "library default"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -33,6 +33,27 @@ SEARCH_SPACES = {
 }
 
 
+def enable_gemm_selection(size='S', batch=128):
+    """Use the offline-selected GEMM-library kernels for the step's GEMM shapes
+    (cream_amd/tuning/gemm_<size>_b<batch>.csv, produced by tools/tune_gemms.py through
+    PyTorch's TunableOp over hipBLASLt / rocBLAS solutions).  Selection only — nothing is
+    tuned at run time.  Returns True when the table was loaded (its validators — library
+    versions, GPU arch — must match this machine)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning',
+                        f'gemm_{size}_b{batch}.csv')
+    if not (torch.cuda.is_available() and os.path.exists(path)):
+        return False
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.tuning_enable(False)
+    tun.set_filename(path, insert_device_ordinal=False)
+    try:
+        return bool(tun.read_file(path))
+    except Exception:
+        return False
+
+
 def sample_configs(choices):
     """supernet_engine.py:13-24.  Draw order: depth, mlp_ratio x depth, num_heads x depth,
     then ONE embed_dim shared by all layers."""
