@@ -7,12 +7,15 @@ import contextlib
 import torch
 
 _enabled = False
+_only = None           # optional set of region names to time (None = all)
 _records = {}          # name -> list of (start_event, end_event, algorithmic_bytes, flops)
 
 
-def enable(flag=True):
-    global _enabled
+def enable(flag=True, only=None):
+    """`only`: iterable of region names to time; the other regions cost one dict test."""
+    global _enabled, _only
     _enabled = bool(flag)
+    _only = set(only) if only else None
 
 
 def reset():
@@ -21,7 +24,7 @@ def reset():
 
 @contextlib.contextmanager
 def region(name, nbytes=0, flops=0):
-    if not _enabled:
+    if not _enabled or (_only is not None and name not in _only):
         yield
         return
     a = torch.cuda.Event(enable_timing=True)
