@@ -125,8 +125,11 @@ class Mirror:
             self._m[id(p)] = e = (m, p._version, p)
         return e[0]
 
-    def refresh_all(self):
-        stale = [e for e in self._m.values() if e[1] != e[2]._version]
+    def refresh_all(self, force=False):
+        """Re-convert the mirrored parameters.  force=True ignores the version counters: fused
+        optimizer kernels (torch._fused_adamw_) update parameters without bumping them, so the
+        optimizer-step hook installed by engine.build_optimizer always forces."""
+        stale = [e for e in self._m.values() if force or e[1] != e[2]._version]
         if stale:
             torch._foreach_copy_([e[0] for e in stale], [e[2].detach() for e in stale])
             for e in stale:

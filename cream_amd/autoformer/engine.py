@@ -99,8 +99,11 @@ def build_optimizer(model, lr=5e-4, batch_size=128, world_size=1, weight_decay=0
     """AdamW with the linear lr scaling of supernet_train.py:294: lr * batch * world / 512."""
     scaled = lr * batch_size * world_size / 512.0
     fused = next(model.parameters()).is_cuda
-    return torch.optim.AdamW(param_groups(model, weight_decay), lr=scaled, betas=(0.9, 0.999), eps=1e-8,
-                             fused=fused)
+    opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=scaled, betas=(0.9, 0.999), eps=1e-8,
+                            fused=fused)
+    # the fused blocks read bf16 operand copies of the master weights: re-convert after every step
+    opt.register_step_post_hook(lambda *_: _block.MIRROR.refresh_all(force=True))
+    return opt
 
 
 class SupernetTrainer:
@@ -150,6 +153,5 @@ class SupernetTrainer:
         loss = self.forward_backward(images, target)
         if self.max_norm and self.max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
-        self.optimizer.step()
-        _block.MIRROR.refresh_all()          # bf16 operand copies of the updated master weights
+        self.optimizer.step()                # (its post-hook refreshes the bf16 operand copies)
         return loss

@@ -54,8 +54,11 @@ def _ptr(t):
 
 
 def _flops(B, H, N):
-    NP = padded_len(N)
-    return 2 * B * H * NP * NP * (96 + 96) + 2 * B * H * NP * 64 * 64 * 2
+    """ALGORITHMIC forward flops of the attention core: QK^T and PV at 2*N*N*64
+    each per head, plus the bucketed relative-position terms (two 30-row tables on the key and
+    on the value side: 4*N*64*60).  Padding, the one-hot extension columns and recomputation
+    are NOT counted.  Backward is taken as 2.5x forward (dV, dP, dQ, dK + one score recompute)."""
+    return B * H * (4 * N * N * 64 + 4 * N * 64 * 60)
 
 
 def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
@@ -96,7 +99,7 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr):
     dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
     dsb, dsn, dsh = dqkv.stride(0), dqkv.stride(1), dqkv.stride(3)
     lib = _lib.load()
-    with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=3 * _flops(B, H, N)):
+    with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=int(2.5 * _flops(B, H, N))):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(lib.cream_attn_rpe2d_bwd(
             _ptr(dq), _ptr(dk), _ptr(dv), dsb, dsn, dsh, _ptr(dtab),

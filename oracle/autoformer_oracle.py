@@ -80,6 +80,24 @@ def attention(sd, prefix, x, E, H, max_rel=14, change_qkv=True, relative_positio
     return F.linear(out, sd[prefix + 'proj.weight'][:E, :Q], sd[prefix + 'proj.bias'][:E])
 
 
+def attention_core(qkv, tkv, tkh, tvv, tvh, scale, max_rel=14):
+    """The part of model/module/multihead_super.py:135-154 between the qkv and proj GEMMs, in the
+    reference's DENSE formulation: qkv (B, N, 3, H, d) -> (B, N, H, d).  (What the fused HIP
+    kernels cream_attn_rpe2d_fwd/bwd replace; autograd of this function is their backward oracle.)"""
+    B, N, _, H, d = qkv.shape
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (q @ k.transpose(-2, -1)) * scale                                              # :138
+    r_p_k, _, _ = rel_pos_embeddings(tkv, tkh, N, max_rel)                                # :140
+    attn = attn + (q.permute(2, 0, 1, 3).reshape(N, H * B, -1) @ r_p_k.transpose(2, 1)) \
+        .transpose(1, 0).reshape(B, H, N, N) * scale                                      # :141-142
+    attn = attn.softmax(dim=-1)                                                           # :144
+    out = (attn @ v).transpose(1, 2).reshape(B, N, -1)                                    # :147
+    r_p_v, _, _ = rel_pos_embeddings(tvv, tvh, N, max_rel)                                # :149
+    attn_1 = attn.permute(2, 0, 1, 3).reshape(N, B * H, -1)
+    out = out + (attn_1 @ r_p_v).transpose(1, 0).reshape(B, H, N, -1).transpose(2, 1).reshape(B, N, -1)   # :150-154
+    return out.reshape(B, N, H, d)
+
+
 def block(sd, i, x, E, H, ratio, **kw):
     """model/supernet_transformer.py:251-287 (pre-norm, dropout 0, no drop-path)."""
     p = f'blocks.{i}.'

@@ -1,0 +1,125 @@
+"""GPU tests of the fused transformer block (cream_amd/autoformer/block.py on csrc/block_ops.hip):
+each HBM-pass kernel against a plain PyTorch fp32 reference of the same op, and the whole block
+(bf16 throughput mode) against the module path and the fp32 CPU oracle."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from fixture_utils import fill_params  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,E", [(197 * 3, 384), (1000, 216), (64, 448), (5, 1280)])
+def test_layernorm_kernels_match_torch_fp32(M, E):
+    from cream_amd.autoformer import block as K
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(M, E, device=DEV, generator=g) * 2 + 0.5
+    w = torch.randn(E, device=DEV, generator=g)
+    b = torch.randn(E, device=DEV, generator=g)
+    dy = torch.randn(M, E, device=DEV, generator=g).bfloat16()
+    dres = torch.randn(M, E, device=DEV, generator=g)
+    xr = x.clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.layer_norm(xr, (E,), wr, br, 1e-5)
+    ref.backward(dy.float())
+    y, mean, rstd = K.ln_fwd(x, w, b, 1e-5)
+    assert _rel(y.float(), ref) < 1e-2                                   # bf16 output rounding
+    assert _rel(mean, x.mean(1)) < 1e-5 and _rel(rstd, (x.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    rows = 7 if M % 7 == 0 else M
+    scale = torch.rand(M // rows, device=DEV, generator=g) + 0.5
+    dx, dxs, part = K.ln_bwd(dy, x, mean, rstd, w, dres, scale, rows, True)
+    assert _rel(dx, xr.grad + dres) < 1e-5
+    assert _rel(dxs.float(), (xr.grad + dres) * scale.repeat_interleave(rows)[:, None]) < 1e-2
+    assert _rel(part[0], wr.grad) < 1e-4 and _rel(part[1], br.grad) < 1e-4
+    dx2, none, _ = K.ln_bwd(dy, x, mean, rstd, w, None, None, 1, False)
+    assert none is None and _rel(dx2, xr.grad) < 1e-5
+
+
+def test_gelu_residual_scale_colsum_match_torch_fp32():
+    from cream_amd.autoformer import block as K
+    g = torch.Generator(device=DEV).manual_seed(1)
+    M, C, rows = 197 * 4, 1344, 197
+    h = (torch.randn(M, C, device=DEV, generator=g) * 2).bfloat16()
+    dg = torch.randn(M, C, device=DEV, generator=g).bfloat16()
+    hr = h.float().requires_grad_()
+    ref = F.gelu(hr)
+    ref.backward(dg.float())
+    assert _rel(K.gelu_fwd(h).float(), ref) < 1e-2
+    assert _rel(K.gelu_bwd(dg, h).float(), hr.grad) < 1e-2
+    x = torch.randn(M, C, device=DEV, generator=g)
+    s = torch.rand(M // rows, device=DEV, generator=g)
+    srow = s.repeat_interleave(rows)[:, None]
+    assert torch.equal(K.residual_add(x, h, s, rows * C), x + srow * h.float())
+    assert torch.equal(K.residual_add(x, h, None, rows * C), x + h.float())
+    assert _rel(K.scale_cast(x, s, rows * C).float(), x * srow) < 1e-2
+    assert _rel(K.colsum(h), h.float().sum(0)) < 1e-5
+    assert _rel(K.wgrad(dg, h), dg.float().t() @ h.float()) < 2e-2
+
+
+def _supernet(depth=2):
+    from cream_amd.autoformer import engine
+    m = engine.build_supernet("S", drop_path_rate=0.0, depth=depth)
+    fill_params(m, seed=7)
+    return m
+
+
+def test_fused_block_matches_module_path_and_oracle():
+    """bf16 throughput mode: the fused block must be as close to the fp32 CPU oracle as PyTorch's
+    own bf16 autocast of the module path is (documented tolerance 3e-2 on gradients)."""
+    from cream_amd.autoformer import engine
+    from oracle import autoformer_oracle as AO
+    m = _supernet()
+    cfg = dict(layer_num=2, embed_dim=[384, 384], num_heads=[6, 5], mlp_ratio=[3.5, 3.0])
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(2, 3, 224, 224, generator=g)
+    target = torch.softmax(torch.randn(2, 1000, generator=g), -1)
+    loss_ref, grads_ref = AO.train_step({k: v.detach().clone() for k, v in m.named_parameters()}, cfg, images, target)
+    m = m.to(DEV)
+    m.set_sample_config(cfg)
+    m.train()
+    res = {}
+    for fused in (False, True):
+        for blk in m.blocks:
+            blk.fused = fused
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = engine.soft_target_cross_entropy(m(images.to(DEV)), target.to(DEV))
+        loss.backward()
+        res[fused] = (float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert set(res[True][1]) == set(res[False][1])
+    assert abs(res[True][0] - float(loss_ref)) / float(loss_ref) < 5e-3
+    worst_fused = max(_rel(v, grads_ref[k]) for k, v in res[True][1].items())
+    worst_module = max(_rel(v, grads_ref[k]) for k, v in res[False][1].items())
+    assert worst_fused < 3e-2, (worst_fused, worst_module)
+    # structure: nothing outside the sampled slices
+    gq = res[True][1]["blocks.1.attn.qkv.weight"]
+    assert torch.count_nonzero(gq[:, 384:]) == 0 and torch.count_nonzero(gq[3 * 320:, :]) == 0
+    assert torch.count_nonzero(res[True][1]["blocks.0.fc1.weight"][int(384 * 3.5):]) == 0
+
+
+def test_mirror_follows_optimizer_and_droppath_runs():
+    from cream_amd.autoformer import block as K, engine
+    m2 = engine.build_supernet("S", drop_path_rate=0.5, depth=2).to(DEV)
+    opt = engine.build_optimizer(m2, batch_size=4)
+    tr = engine.SupernetTrainer(m2, opt, engine.SEARCH_SPACES["S"]["choices"])
+    x = torch.randn(4, 3, 224, 224, device=DEV)
+    t = torch.softmax(torch.randn(4, 1000, device=DEV), -1)
+    tr.start_epoch(0)
+    l0 = float(tr.step(x, t))
+    w = m2.blocks[0].fc1.weight
+    assert torch.equal(K.MIRROR.get(w), w.detach().bfloat16())          # refreshed after the step
+    l1 = float(tr.step(x, t))
+    assert l0 == l0 and l1 == l1
