@@ -47,6 +47,7 @@ def enable_gemm_selection(size='S', batch=128):
     tun = torch.cuda.tunable
     tun.enable(True)
     tun.tuning_enable(False)
+    tun.write_file_on_exit(False)        # read-only use of the committed table (8 ranks share it)
     tun.set_filename(path, insert_device_ordinal=False)
     try:
         return bool(tun.read_file(path))

@@ -123,3 +123,50 @@ def test_mirror_follows_optimizer_and_droppath_runs():
     assert torch.equal(K.MIRROR.get(w), w.detach().bfloat16())          # refreshed after the step
     l1 = float(tr.step(x, t))
     assert l0 == l0 and l1 == l1
+
+
+def test_reducer_bucket_protocol_with_fused_blocks(monkeypatch):
+    """One process cannot run RCCL with itself, so the collective is stubbed: every active bucket
+    must be all-reduced exactly once per step, after its last gradient was written (fused blocks
+    announce theirs explicitly), blocks beyond the sampled depth are never sent, and the result
+    is the SUM scaled by 1/world."""
+    import torch.distributed as dist
+    from cream_amd import comm
+    from cream_amd.autoformer import engine
+    calls = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), float(t.abs().sum())))
+        t.mul_(2.0)                                   # "sum over 2 identical ranks"
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    torch.manual_seed(0)
+    m = engine.build_supernet("S", drop_path_rate=0.0, depth=3).to(DEV)
+    red = comm.GradReducer(m, world=2)
+    try:
+        opt = engine.build_optimizer(m, batch_size=2)
+        tr = engine.SupernetTrainer(m, opt, engine.SEARCH_SPACES["S"]["choices"], red)
+        tr.config = dict(layer_num=2, embed_dim=[320] * 2, num_heads=[5, 6], mlp_ratio=[3.0, 4.0])
+        m.set_sample_config(tr.config)
+        m.train()
+        x = torch.randn(2, 3, 224, 224, device=DEV)
+        t = torch.softmax(torch.randn(2, 1000, device=DEV), -1)
+        # reference gradients without the reducer's scaling: single-process autograd on a copy
+        tr.forward_backward(x, t)
+        torch.cuda.synchronize()
+        ptrs = {red.flat[b].data_ptr(): b for b in red.flat}
+        sent = [ptrs[c[0]] for c in calls]
+        assert sorted(sent) == ["block00", "block01", "stem", "tail"]          # block02 is beyond the depth
+        assert all(c[2] > 0 for c in calls), "a bucket was sent before its gradients were written"
+        # reverse layer order, stem last: communication overlaps the rest of backward
+        assert sent[-1] == "stem" and sent.index("block01") < sent.index("block00")
+        assert float(red.flat["block02"].abs().sum()) == 0.0
+        g1 = m.blocks[0].fc1.weight.grad.clone()
+        calls.clear()
+        for blk in m.blocks:
+            blk.fused = False                                                 # module path: autograd hooks
+        tr.forward_backward(x, t)
+        torch.cuda.synchronize()
+        assert sorted(ptrs[c[0]] for c in calls) == ["block00", "block01", "stem", "tail"]
+        assert _rel(m.blocks[0].fc1.weight.grad, g1) < 3e-2                   # (2x sum) / 2 either way
+    finally:
+        red.close()

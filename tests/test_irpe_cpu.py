@@ -1,0 +1,130 @@
+"""iRPE host logic on CPU against golden vectors produced by the reference itself
+(tests/golden/irpe_*.npz|json, deit_tiny_irpe_k.npz; generator: tests/golden/make_golden.py):
+bucket ids and the piecewise index are integer work -> bit-exact; module outputs/gradients and
+the DeiT-tiny forward (BASELINE config 1) within fp32 round-off."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import load_json, load_npz, max_rel
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from fixture_utils import fill_params  # noqa: E402
+
+from cream_amd import irpe as I  # noqa: E402
+
+METH = dict(product=I.METHOD.PRODUCT, euc=I.METHOD.EUCLIDEAN, quant=I.METHOD.QUANT,
+            cross_rows=I.METHOD.CROSS_ROWS, cross_cols=I.METHOD.CROSS_COLS)
+
+
+def test_bucket_tables_bit_exact():
+    fix, meta = load_npz("irpe_buckets.npz"), load_json("irpe_buckets.json")
+    assert len(meta) == 12
+    for m in meta:
+        r = m["ratio"]
+        ids, nb = I.get_bucket_ids_2d(METH[m["method"]], m["h"], m["w"], m["skip"], r, 2 * r, 8 * r, dtype=torch.long)
+        assert nb == m["num_buckets"] and list(ids.shape) == m["shape"] and int(ids.sum()) == m["sum"], m["key"]
+        if m["key"] in fix:
+            np.testing.assert_array_equal(ids.numpy(), fix[m["key"]].astype(np.int64))
+        else:
+            np.testing.assert_array_equal(ids.numpy()[::16], fix[m["key"] + "|rows16"].astype(np.int64))
+    # SURVEY §4 known answers: product, ratio 1.9, skip 1
+    ids, nb = I.get_bucket_ids_2d(I.METHOD.PRODUCT, 14, 14, 1, 1.9, 3.8, 15.2)
+    assert nb == 50 and int(ids.sum()) == 941241 and ids[1, 1:8].tolist() == [24, 23, 22, 22, 21, 21, 21]
+    assert int(I.get_bucket_ids_2d(I.METHOD.PRODUCT, 24, 24, 1, 1.9, 3.8, 15.2)[0].sum()) == 8019121
+
+
+def test_piecewise_index_bit_exact():
+    fix = load_npz("irpe_buckets.npz")
+    xs = torch.arange(-64, 65)
+    xf = torch.arange(0, 400).float().sqrt().round()
+    for ratio in (1.9, 3.0, 7.5, 20, 51):
+        key = f"{ratio}"
+        np.testing.assert_array_equal(I.piecewise_index(xs, ratio, 2 * ratio, 8 * ratio, torch.long).numpy(),
+                                      fix[f"piecewise_int_{key}"].astype(np.int64))
+        np.testing.assert_array_equal(I.piecewise_index(xf, ratio, 2 * ratio, 8 * ratio, torch.long).numpy(),
+                                      fix[f"piecewise_flt_{key}"].astype(np.int64))
+
+
+def test_config_builders():
+    c = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="qkv")
+    assert c.rpe_k.alpha == 1.9 and c.rpe_k.beta == 3.8 and c.rpe_k.gamma == 15.2 and c.rpe_k.num_buckets == 50
+    q, k, v = I.build_rpe(c, head_dim=64, num_heads=3)
+    assert q.transposed and k.transposed and not v.transposed
+    assert tuple(k.lookup_table_weight.shape) == (1, 64, 50) and tuple(v.lookup_table_weight.shape) == (1, 50, 64)
+    c2 = I.get_rpe_config(ratio=1.9, method="cross", mode="bias", shared_head=False, skip=0, rpe_on="k")
+    _, k2, _ = I.build_rpe(c2, head_dim=32, num_heads=4)
+    assert isinstance(k2, I.iRPE_Cross) and tuple(k2.rp_rows.lookup_table_bias.shape) == (4, 7)
+    assert I.build_rpe(None, 64, 3) == (None, None, None)
+    with pytest.raises(NotImplementedError):
+        I.iRPE(64, 3, mode="bias", method=I.METHOD.PRODUCT, transposed=False, num_buckets=50)
+
+
+@pytest.mark.parametrize("tag,kw", [("ctx_shared", dict(mode="ctx", shared_head=True)),
+                                    ("ctx_perhead", dict(mode="ctx", shared_head=False)),
+                                    ("bias_perhead", dict(mode="bias", shared_head=False))])
+def test_modules_match_reference_outputs_and_grads(tag, kw):
+    fix = load_npz("irpe_modules.npz")
+    cfg = I.get_rpe_config(ratio=1.9, method="product", skip=1, rpe_on="qkv" if kw["mode"] == "ctx" else "qk", **kw)
+    mods = I.build_rpe(cfg, head_dim=64, num_heads=3)
+    g = torch.Generator().manual_seed(31)
+    for which, mod in zip("qkv", mods):
+        if mod is None:
+            continue
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        if which == "v":
+            x = torch.randn(2, 3, 197, 197, generator=g).softmax(-1).requires_grad_()
+        else:
+            x = torch.randn(2, 3, 197, 64, generator=g, requires_grad=True)
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [x] + list(mod.parameters()), gy, allow_unused=True)
+        ysub = y[:, :, ::7, ::5] if y.shape[-1] == 197 else y[:, :, ::7]
+        assert max_rel(ysub.detach(), fix[f"{tag}|{which}|y"]) < 1e-5
+        assert abs(float(y.double().sum()) - float(fix[f"{tag}|{which}|ysum"][0])) < 1e-3 * max(1.0, abs(float(fix[f"{tag}|{which}|ysum"][0])))
+        if grads[0] is not None:
+            dsub = grads[0][:, :, ::7, ::5] if grads[0].shape[-1] == 197 else grads[0][:, :, ::7]
+            assert max_rel(dsub, fix[f"{tag}|{which}|dx"]) < 1e-5
+        assert max_rel(grads[1], fix[f"{tag}|{which}|dw"]) < 1e-5
+
+
+def test_rpe_attention_matches_reference():
+    from cream_amd.rpe_attention import RPEAttention
+    fix = load_npz("irpe_attention.npz")
+    cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="qkv")
+    att = RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg)
+    fill_params(att, seed=19)
+    with torch.no_grad():
+        for n, p in att.named_parameters():
+            if "lookup_table" in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))))
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 197, 192, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 192, generator=g)
+    y = att(x)
+    y.backward(gy)
+    assert max_rel(y.detach(), fix["y"]) < 1e-5 and max_rel(x.grad, fix["dx"]) < 1e-5
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(dict(att.named_parameters())[k[5:]].grad, v) < 1e-5, k
+
+
+def test_deit_tiny_irpe_k_single_image_forward():
+    """BASELINE config 1: DeiT-tiny + iRPE (contextual product, 50 buckets, shared head, on keys)."""
+    from cream_amd.rpe_attention import deit_tiny_patch16_224_ctx_product_50_shared_k
+    fix = load_npz("deit_tiny_irpe_k.npz")
+    torch.manual_seed(0)
+    model = deit_tiny_patch16_224_ctx_product_50_shared_k()
+    assert sum(p.numel() for p in model.parameters()) == int(fix["n_params"][0]) == 5755816
+    fill_params(model, seed=17)
+    model.eval()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        logits = model(x)
+    assert max_rel(logits, fix["logits"]) < 1e-4
