@@ -78,4 +78,4 @@ def test_deit_base_384_attention_bf16_runs_and_is_close():
     ref = att(x)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = att(x)
-    assert y.dtype == torch.bfloat16 and max_rel(y.float().cpu(), ref.detach().cpu()) < 3e-2
+    assert y.dtype == torch.bfloat16 and max_rel(y.detach().float().cpu(), ref.detach().cpu()) < 3e-2
