@@ -40,6 +40,7 @@ def enable_gemm_selection(size='S', batch=128):
     tuned at run time.  Returns True when the table was loaded (its validators — library
     versions, GPU arch — must match this machine)."""
     import os
+    import tempfile
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning',
                         f'gemm_{size}_b{batch}.csv')
     if not (torch.cuda.is_available() and os.path.exists(path)):
@@ -47,12 +48,17 @@ def enable_gemm_selection(size='S', batch=128):
     tun = torch.cuda.tunable
     tun.enable(True)
     tun.tuning_enable(False)
-    tun.write_file_on_exit(False)        # read-only use of the committed table (8 ranks share it)
-    tun.set_filename(path, insert_device_ordinal=False)
+    # read-only use of the committed table (8 ranks share it): whatever the library writes at
+    # exit goes to a per-process scratch file, never back into the package
+    if hasattr(tun, 'write_file_on_exit'):
+        tun.write_file_on_exit(False)
     try:
-        return bool(tun.read_file(path))
+        ok = bool(tun.read_file(path))
     except Exception:
-        return False
+        ok = False
+    tun.set_filename(os.path.join(tempfile.gettempdir(), f'cream_tunableop_{os.getpid()}.csv'),
+                     insert_device_ordinal=False)
+    return ok
 
 
 def sample_configs(choices):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats, HBM traffic counters.
+# usage (from the repo root on the box): bash tools/gpu_round.sh <tag> [steps]
+TAG=${1:-r01}
+STEPS=${2:-40}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_pytest_gpu.log 2>&1
+echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
+timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "bench exit $?"; cat $OUT/${TAG}_bench.json
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_' -d $OUT/${TAG}_pmc_$C -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$C.err
+  echo "pmc $C exit $?"
+done
+cd $REPO
+find $OUT -name '*.csv' | head -20
+# keep the merge small: drop raw traces, keep stats + counter csv
+find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" -delete
+du -sh $OUT

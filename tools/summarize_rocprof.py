@@ -15,10 +15,32 @@ def short(name):
     return name[:110]
 
 
+def category(k):
+    if k.startswith("hipBLASLt GEMM") or "Cijk_" in k:
+        return "GEMM library (hipBLASLt)"
+    if "attn_rpe2d" in k:
+        return "attention (csrc/attn_rpe2d.hip)"
+    if re.search(r"(ln_fwd|ln_bwd|gelu_|residual_add|scale_cast|colsum|rpe_)", k):
+        return "HBM passes (csrc/block_ops.hip, rpe_index.hip)"
+    if "FusedAdam" in k or "multi_tensor_apply" in k:
+        return "optimizer + bf16 operand refresh (multi-tensor)"
+    return "framework elementwise / reductions / copies / fills"
+
+
+def read_rows(path):
+    """rocprofv3 --stats output: either <x>_kernel_stats.csv or the rocpd database <x>_results.db."""
+    if path.endswith(".db"):
+        import sqlite3
+        c = sqlite3.connect(path)
+        q = "select name, count(*), sum(duration) from kernels group by name"
+        return [{"Name": n, "Calls": k, "TotalDurationNs": d} for n, k, d in c.execute(q)]
+    return list(csv.DictReader(open(path)))
+
+
 def main():
     path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else None
-    rows = list(csv.DictReader(open(path)))
+    rows = read_rows(path)
     total = sum(int(r["TotalDurationNs"]) for r in rows)
     print(f"source: {path}")
     print(f"total kernel time: {total / 1e6:.2f} ms" + (f" over {steps} steps = {total / 1e6 / steps:.2f} ms/step" if steps else ""))
@@ -33,6 +55,16 @@ def main():
         a[1] += int(r["TotalDurationNs"])
     for k, (calls, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"| {100 * ns / total:.2f} | {calls} | {ns / calls / 1e3:.1f} | {ns / 1e6:.2f} | `{k}` |")
+    cats = {}
+    for k, (calls, ns) in agg.items():
+        c = cats.setdefault(category(k), [0, 0])
+        c[0] += calls
+        c[1] += ns
+    print()
+    print("| category | calls | total ms |" + (" ms/step |" if steps else ""))
+    print("|---|---:|---:|" + ("---:|" if steps else ""))
+    for k, (calls, ns) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+        print(f"| {k} | {calls} | {ns / 1e6:.2f} |" + (f" {ns / 1e6 / steps:.2f} |" if steps else ""))
 
 
 if __name__ == "__main__":
