@@ -53,7 +53,22 @@ SIGNATURES = {
     "cream_scale_cast": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "cream_colsum_slabs": (_i, [_i]),
     "cream_colsum": (_i, [_vp, _vp, _i, _i, _vp]),
+    "cream_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
+    "cream_colsum128_slabs": (_i, [_i]),
+    "cream_colsum128": (_i, [_vp, _vp, _i, _i, _vp]),
+    "cream_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "cream_scale_cast_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cream_grad_finalize": (_i, [_vp, _i, _vp]),
 }
+
+MAX_GRAD_JOBS = 24
+
+
+class GradJob(ctypes.Structure):
+    """struct cream_grad_job of include/cream_amd.h."""
+    _fields_ = [("dst", _vp), ("src", _vp), ("ld", _i64), ("pstride", _i64),
+                ("nparts", _c.c_int32), ("rows", _c.c_int32), ("cols", _c.c_int32),
+                ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("reserved", _c.c_int32)]
 
 _lib = None
 

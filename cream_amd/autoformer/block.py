@@ -48,15 +48,37 @@ def ln_fwd(x2d, gamma, beta, eps):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
+def add_ln_fwd(x2d, res, sample_scale, rows_per_sample, gamma, beta, eps):
+    """x1 = x + s_b * res (fp32), y = LN(x1) (bf16): the residual add and the next LayerNorm in
+    one pass.  -> (x1, y, mean, rstd)"""
+    M, E = x2d.shape
+    x1 = torch.empty_like(x2d)
+    y = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    with timing.region("add_ln_fwd", nbytes=M * E * (4 + 2 + 4 + 2)):
+        _lib.check(_lib.load().cream_add_ln_fwd(_p(x1), _p(y), _p(mean), _p(rstd), _p(x2d), _p(res), _p(sample_scale),
+                                               rows_per_sample, _p(gamma), _p(beta), M, E, float(eps), _stream()),
+                   "cream_add_ln_fwd")
+    return x1, y, mean, rstd
+
+
+def ln_bwd_raw(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
+    """-> (dx, dx_scaled or None, partial (P, 3, E): per-slab [dgamma, dbeta, colsum(dx_scaled)])"""
     M, E = x2d.shape
     lib = _lib.load()
     dx = torch.empty((M, E), dtype=torch.float32, device=x2d.device)
     dxs = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device) if want_scaled else None
-    partial = torch.empty((lib.cream_ln_partials(), 2, E), dtype=torch.float32, device=x2d.device)
+    partial = torch.empty((lib.cream_ln_partials(), 3, E), dtype=torch.float32, device=x2d.device)
     with timing.region("ln_bwd", nbytes=M * E * (2 + 4 + 4 + 4 + (2 if want_scaled else 0))):
         _lib.check(lib.cream_ln_bwd(_p(dx), _p(dxs), _p(partial), _p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma),
                                     _p(dres), _p(sample_scale), rows_per_sample, M, E, _stream()), "cream_ln_bwd")
+    return dx, dxs, partial
+
+
+def ln_bwd(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
+    """-> (dx, dx_scaled, (3, E) sums [dgamma, dbeta, colsum(dx_scaled)])"""
+    dx, dxs, partial = ln_bwd_raw(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled)
     return dx, dxs, partial.sum(dim=0)
 
 
@@ -97,6 +119,83 @@ def colsum(a):
     with timing.region("colsum", nbytes=a.numel() * 2):
         _lib.check(lib.cream_colsum(_p(partial), _p(a), M, C, _stream()), "cream_colsum")
     return partial.sum(dim=0)
+
+
+def gelu_bwd_colsum(dg, h):
+    """-> (dh, partial (slabs, F)): dh = dg * gelu'(h) and its per-slab column sums (fc1 bias)."""
+    M, C = h.shape
+    lib = _lib.load()
+    dh = torch.empty_like(h)
+    partial = torch.empty((lib.cream_colsum128_slabs(M), C), dtype=torch.float32, device=h.device)
+    with timing.region("gelu_bwd", nbytes=h.numel() * 6):
+        _lib.check(lib.cream_gelu_bwd_colsum(_p(dh), _p(partial), _p(dg), _p(h), M, C, _stream()),
+                   "cream_gelu_bwd_colsum")
+    return dh, partial
+
+
+def scale_cast_colsum(x2d, sample_scale, rows_per_sample):
+    """-> (bf16(s_b * x), partial (slabs, C)) — the branch-output gradient and its column sums."""
+    M, C = x2d.shape
+    lib = _lib.load()
+    out = torch.empty((M, C), dtype=torch.bfloat16, device=x2d.device)
+    partial = torch.empty((lib.cream_colsum128_slabs(M), C), dtype=torch.float32, device=x2d.device)
+    with timing.region("scale_cast", nbytes=x2d.numel() * 6):
+        _lib.check(lib.cream_scale_cast_colsum(_p(out), _p(partial), _p(x2d), _p(sample_scale), rows_per_sample,
+                                               M, C, _stream()), "cream_scale_cast_colsum")
+    return out, partial
+
+
+def colsum128(a):
+    """per-slab column sums (slabs, C) fp32 of a bf16 (M, C) matrix"""
+    M, C = a.shape
+    lib = _lib.load()
+    partial = torch.empty((lib.cream_colsum128_slabs(M), C), dtype=torch.float32, device=a.device)
+    with timing.region("colsum", nbytes=a.numel() * 2):
+        _lib.check(lib.cream_colsum128(_p(partial), _p(a), M, C, _stream()), "cream_colsum128")
+    return partial
+
+
+def wgrad_parts(dy, x):
+    """Split-K weight gradient: (s, out, in) partial products dy_s^T x_s over s slices of the
+    token dimension (the library's single-pass TN GEMM leaves most CUs idle on a 25k-deep
+    contraction); the slices are added by cream_grad_finalize."""
+    M = dy.shape[0]
+    s = _WGRAD_SPLIT
+    while M % s:
+        s //= 2
+    return torch.bmm(dy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1))
+
+
+class GradJobs:
+    """The gradient finalisation of one block: every `add` names an fp32 gradient (the active
+    slice of a super-weight's .grad) and the partial sums that go into it; `launch` adds them all
+    in ONE kernel (cream_grad_finalize), fixed summation order."""
+
+    def __init__(self):
+        self.jobs = (_lib.GradJob * _lib.MAX_GRAD_JOBS)()
+        self.n = 0
+        self.keep = []
+
+    def add(self, param, src, nparts, pstride, rows, cols, interleave=0, src_offset=0):
+        if param.grad is None:
+            param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        g = param.grad
+        j = self.jobs[self.n]
+        j.dst = g.data_ptr()
+        j.src = src.data_ptr() + src_offset * src.element_size()
+        j.ld = g.stride(0) if g.dim() == 2 else cols
+        j.pstride = pstride
+        j.nparts, j.rows, j.cols = nparts, rows, cols
+        j.interleave = interleave
+        j.src_bf16 = 1 if src.dtype == torch.bfloat16 else 0
+        self.n += 1
+        self.keep.append(src)
+
+    def launch(self):
+        with timing.region("grad_finalize"):
+            _lib.check(_lib.load().cream_grad_finalize(ctypes.cast(self.jobs, ctypes.c_void_p), self.n, _stream()),
+                       "cream_grad_finalize")
+        self.keep.clear()
 
 
 def wgrad(dy, x):
@@ -198,8 +297,7 @@ class BlockFunction(torch.autograd.Function):
         o2d = o.view(M, Q)
         wproj = mir(at.proj.weight)[:E, :Q]
         p = torch.addmm(mir(at.proj.bias)[:E], o2d, wproj.t())
-        x1 = residual_add(x2d, p, dp1, N * E)
-        c, mean2, rstd2 = ln_fwd(x1, ln2.weight[:E], ln2.bias[:E], ln2.eps)
+        x1, c, mean2, rstd2 = add_ln_fwd(x2d, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
         w1 = mir(blk.fc1.weight)[:F_, :E]
         h = torch.addmm(mir(blk.fc1.bias)[:F_], c, w1.t())
         g = gelu_fwd(h)
@@ -225,41 +323,48 @@ class BlockFunction(torch.autograd.Function):
         ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
         dx2 = dx2.contiguous().view(M, E)
 
+        jobs = GradJobs()
         # ---- MLP branch -----------------------------------------------------------------------
-        df = scale_cast(dx2, dp2, N * E)                                   # d(fc2 out) = s_b * dx2
-        _acc(blk.fc2.weight, (slice(0, E), slice(0, F_)), wgrad(df, g))
-        _acc(blk.fc2.bias, slice(0, E), colsum(df))
+        df, pb2 = scale_cast_colsum(dx2, dp2, N)                           # d(fc2 out) = s_b * dx2
+        pw2 = wgrad_parts(df, g)
+        jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
+        jobs.add(blk.fc2.bias, pb2, pb2.shape[0], E, 1, E)
         dg = df @ mir(blk.fc2.weight)[:E, :F_]
-        dh = gelu_bwd(dg, h)
-        _acc(blk.fc1.weight, (slice(0, F_), slice(0, E)), wgrad(dh, c))
-        _acc(blk.fc1.bias, slice(0, F_), colsum(dh))
+        dh, pb1 = gelu_bwd_colsum(dg, h)
+        pw1 = wgrad_parts(dh, c)
+        jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
+        jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
         dc = dh @ mir(blk.fc1.weight)[:F_, :E]
-        dx1, dp, part2 = ln_bwd(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
-        _acc(ln2.weight, slice(0, E), part2[0])
-        _acc(ln2.bias, slice(0, E), part2[1])
+        # dx1 = dx2 + dLN2(dc); dp = s_b * dx1 is the gradient of the proj output, and its
+        # column sums (proj bias) come out of the same pass
+        dx1, dp, pl2 = ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
+        P = pl2.shape[0]
+        jobs.add(ln2.weight, pl2, P, 3 * E, 1, E)
+        jobs.add(ln2.bias, pl2, P, 3 * E, 1, E, src_offset=E)
+        jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
 
-        # ---- attention branch (dp = s_b * dx1 is the gradient of the proj output) ---------------
-        _acc(at.proj.weight, (slice(0, E), slice(0, Q)), wgrad(dp, o.view(M, Q)))
-        _acc(at.proj.bias, slice(0, E), colsum(dp))
+        # ---- attention branch ---------------------------------------------------------------------
+        pwp = wgrad_parts(dp, o.view(M, Q))
+        jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
         do = dp @ mir(at.proj.weight)[:E, :Q]
         tabs_p = (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
                   at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
         dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
-                                                  *(t.detach() for t in tabs_p), o, lse, sp, scale, mr)
+                                                  *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
+                                                  reduce_tables=False)
         nb = tabs_p[0].shape[0]
-        for i, t in enumerate(tabs_p):
-            _acc(t, slice(None), dtab[i, :nb])
+        for i, t in enumerate(tabs_p):                                     # dtab (B*H, 4, 32, 64)
+            jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
         dqkv2d = dqkv.view(M, 3 * Q)
-        dwq = wgrad(dqkv2d, a)                                             # rows [q | k | v]
-        if at.qkv.weight.grad is None:
-            at.qkv.weight.grad = torch.zeros_like(at.qkv.weight)
-        gq = at.qkv.weight.grad
-        gq[:3 * Q].view(Q, 3, gq.shape[1])[:, :, :E].add_(dwq.view(3, Q, E).transpose(0, 1))
-        _acc(at.qkv.bias, slice(0, 3 * Q), colsum(dqkv2d))
+        pwq = wgrad_parts(dqkv2d, a)                                       # rows [q | k | v]
+        jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
+        pbq = colsum128(dqkv2d)
+        jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
         da = dqkv2d @ wqkv
-        dx, _, part1 = ln_bwd(da, x2d, mean1, rstd1, ln1.weight[:E], dx1, None, N, False)
-        _acc(ln1.weight, slice(0, E), part1[0])
-        _acc(ln1.bias, slice(0, E), part1[1])
+        dx, _, pl1 = ln_bwd_raw(da, x2d, mean1, rstd1, ln1.weight[:E], dx1, None, N, False)
+        jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
+        jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
+        jobs.launch()
 
         if _grad_ready_hooks:
             params = [p for p in blk.parameters() if p.requires_grad]

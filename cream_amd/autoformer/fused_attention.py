@@ -81,8 +81,9 @@ def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
     return out, lse, sp
 
 
-def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr):
-    """-> (dqkv (B, N, 3, H, 64), dtab (4, 32, 64) fp32 = gradients of [tkv, tkh, tvv, tvh] rows)."""
+def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_tables=True):
+    """-> (dqkv (B, N, 3, H, 64), dtab (4, 32, 64) fp32 = gradients of [tkv, tkh, tvv, tvh] rows;
+    with reduce_tables=False the per-(b,h) partials (B*H, 4, 32, 64) for cream_grad_finalize)."""
     B, N, _, H, D = qkv.shape
     gh, gw = grid_of(N, mr)
     NP = padded_len(N)
@@ -107,6 +108,8 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr):
             _ptr(dout), _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
             _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
             B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
+    if not reduce_tables:
+        return dqkv, dtab
     return dqkv, dtab.sum(dim=0)                              # fixed-order reduction over (b, h)
 
 

@@ -50,10 +50,15 @@ __device__ __forceinline__ u32x2v pack_bf16x4(const float (&f)[4]) {
 constexpr int LN_MAXC = 5;          // float4 chunks per lane: E <= 64 * 4 * 5 = 1280
 
 // ---- LayerNorm forward: one wave per row ------------------------------------------------
+// With a branch output `res` (bf16) the kernel first forms the new residual stream
+// x1 = x + s_b * res (written to `xsum`, fp32) and normalises that: the residual add and the
+// next LayerNorm of the block in one pass.
 __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int M, int E, float eps) {
+                                                     int M, int E, float eps, float* __restrict__ xsum,
+                                                     const uint16_t* __restrict__ res, const float* __restrict__ sscale,
+                                                     int rows_per_sample) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -61,10 +66,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
     const float* xr = x + (int64_t)row * E;
     f32x4v v[LN_MAXC];
     float s = 0.f;
+    const float sc = (res && sscale) ? sscale[row / rows_per_sample] : 1.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < nch ? *reinterpret_cast<const f32x4v*>(xr + 4 * c) : f32x4v{0, 0, 0, 0};
+        if (res && c < nch) {
+            float r[4];
+            unpack_bf16x4(*reinterpret_cast<const u32x2v*>(res + (int64_t)row * E + 4 * c), r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += sc * r[e];
+            *reinterpret_cast<f32x4v*>(xsum + (int64_t)row * E + 4 * c) = v[i];
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mu = wave_sum(s) / (float)E;
@@ -95,33 +108,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
 
 // ---- LayerNorm backward (+ residual gradient, + optional scaled bf16 copy) ------------
 // grid = P workgroups of 4 waves; wave w of workgroup p walks rows (p*4 + w), += 4P, ...
-// partial[p][0][c] = sum dy*xhat (dgamma), partial[p][1][c] = sum dy (dbeta) over its rows
+// partial[p][0][c] = sum dy*xhat (dgamma), partial[p][1][c] = sum dy (dbeta) over its rows,
+// partial[p][2][c] = column sums of the bf16 values written to dxs (the bias gradient of the
+// projection whose output gradient dxs is), zero without dxs
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uint16_t* __restrict__ dxs,
                                                      float* __restrict__ partial, const uint16_t* __restrict__ dy,
                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, const float* __restrict__ sscale,
                                                      int rows_per_sample, int M, int E) {
-    __shared__ float red[4][2][LN_MAXC * 256 + 4];
+    __shared__ float red[4][MAXC * 256 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = E >> 2;
-    f32x4v g[LN_MAXC], ag[LN_MAXC], ab[LN_MAXC];
+    f32x4v g[MAXC], ag[MAXC], ab[MAXC], as[MAXC];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         g[i] = c < nch ? *reinterpret_cast<const f32x4v*>(gamma + 4 * c) : f32x4v{0, 0, 0, 0};
         ag[i] = f32x4v{0, 0, 0, 0};
         ab[i] = f32x4v{0, 0, 0, 0};
+        as[i] = f32x4v{0, 0, 0, 0};
     }
     const float invE = 1.f / (float)E;
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         const float* xr = x + (int64_t)row * E;
         const uint16_t* dyr = dy + (int64_t)row * E;
-        float xh[LN_MAXC][4], d[LN_MAXC][4];
+        float xh[MAXC][4], d[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + 4 * c);
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uin
         s2 = wave_sum(s2) * invE;
         const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 f32x4v r = dres ? *reinterpret_cast<const f32x4v*>(dres + (int64_t)row * E + 4 * c) : f32x4v{0, 0, 0, 0};
@@ -153,23 +170,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uin
                     o[e] = r[e] * sc;
                 }
                 *reinterpret_cast<f32x4v*>(dx + (int64_t)row * E + 4 * c) = r;
-                if (dxs) *reinterpret_cast<u32x2v*>(dxs + (int64_t)row * E + 4 * c) = pack_bf16x4(o);
+                if (dxs) {
+                    const u32x2v pk = pack_bf16x4(o);
+                    *reinterpret_cast<u32x2v*>(dxs + (int64_t)row * E + 4 * c) = pk;
+                    unpack_bf16x4(pk, o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) as[i][e] += o[e];
+                }
             }
         }
     }
-    // workgroup partials: waves 1..3 hand their sums to wave 0 through LDS
+    // workgroup partials, one plane at a time: the four waves' sums meet in LDS (fixed order)
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i)
+    for (int which = 0; which < 3; ++which) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[wave][0][(i * 64 + lane) * 4 + e] = ag[i][e];
-            red[wave][1][(i * 64 + lane) * 4 + e] = ab[i][e];
-        }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 2 * E; k += 256) {
-        const int which = k >= E, c = k - which * E;
-        const float s = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
-        partial[((int64_t)blockIdx.x * 2 + which) * E + c] = s;
+        for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                red[wave][(i * 64 + lane) * 4 + e] = which == 0 ? ag[i][e] : (which == 1 ? ab[i][e] : as[i][e]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < E; c += 256)
+            partial[((int64_t)blockIdx.x * 3 + which) * E + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        __syncthreads();
     }
 }
 
@@ -261,6 +283,166 @@ __global__ __launch_bounds__(256) void colsum_kernel(float* __restrict__ partial
     }
 }
 
+// ---- elementwise pass + column sums of what it writes (bias gradients ride along) ---------
+// block = 32 column groups (8 columns, 16 bytes of bf16) x 8 row lanes; grid = (ceil(C/256),
+// ceil(M/CS_ROWS)); partial[slab][c] = sum over the slab's rows of the bf16-ROUNDED outputs.
+constexpr int CS_ROWS = 128;
+
+__device__ __forceinline__ void colsum_block_reduce(float* __restrict__ partial, const float (&acc)[8], int C) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+        partial[(int64_t)blockIdx.y * C + c] = s;
+    }
+}
+
+// dh = dg * gelu'(h) (bf16), partial = column sums of dh  (fc1 bias gradient)
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(uint16_t* __restrict__ dh, float* __restrict__ partial,
+                                                              const uint16_t* __restrict__ dg,
+                                                              const uint16_t* __restrict__ h, int M, int C) {
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const int64_t off = (int64_t)r * C + c0;
+            const u32x4v hv = *reinterpret_cast<const u32x4v*>(h + off);
+            const u32x4v gv = *reinterpret_cast<const u32x4v*>(dg + off);
+            float a[4], b[4], ga[4], gb[4];
+            unpack_bf16x4(u32x2v{hv[0], hv[1]}, a);
+            unpack_bf16x4(u32x2v{hv[2], hv[3]}, b);
+            unpack_bf16x4(u32x2v{gv[0], gv[1]}, ga);
+            unpack_bf16x4(u32x2v{gv[2], gv[3]}, gb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = ga[e] * gelu_grad_f(a[e]); b[e] = gb[e] * gelu_grad_f(b[e]); }
+            const u32x2v pa = pack_bf16x4(a), pb = pack_bf16x4(b);
+            *reinterpret_cast<u32x4v*>(dh + off) = u32x4v{pa[0], pa[1], pb[0], pb[1]};
+            unpack_bf16x4(pa, a);
+            unpack_bf16x4(pb, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+        }
+    }
+    colsum_block_reduce(partial, acc, C);
+}
+
+// out = bf16(s_b * x), partial = column sums of out  (fc2 bias gradient)
+__global__ __launch_bounds__(256) void scale_cast_colsum_kernel(uint16_t* __restrict__ out, float* __restrict__ partial,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ ss, int rows_per_sample,
+                                                                int M, int C) {
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const int64_t off = (int64_t)r * C + c0;
+            const f32x4v x0 = *reinterpret_cast<const f32x4v*>(x + off);
+            const f32x4v x1 = *reinterpret_cast<const f32x4v*>(x + off + 4);
+            const float s = ss ? ss[r / rows_per_sample] : 1.f;
+            float a[4] = {x0[0] * s, x0[1] * s, x0[2] * s, x0[3] * s};
+            float b[4] = {x1[0] * s, x1[1] * s, x1[2] * s, x1[3] * s};
+            const u32x2v pa = pack_bf16x4(a), pb = pack_bf16x4(b);
+            *reinterpret_cast<u32x4v*>(out + off) = u32x4v{pa[0], pa[1], pb[0], pb[1]};
+            unpack_bf16x4(pa, a);
+            unpack_bf16x4(pb, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+        }
+    }
+    colsum_block_reduce(partial, acc, C);
+}
+
+// plain column sums at the same slab size (qkv bias gradient: dqkv comes out of the attention kernels)
+__global__ __launch_bounds__(256) void colsum128_kernel(float* __restrict__ partial, const uint16_t* __restrict__ a,
+                                                        int M, int C) {
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const u32x4v v = *reinterpret_cast<const u32x4v*>(a + (int64_t)r * C + c0);
+            float f0[4], f1[4];
+            unpack_bf16x4(u32x2v{v[0], v[1]}, f0);
+            unpack_bf16x4(u32x2v{v[2], v[3]}, f1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += f0[e]; acc[4 + e] += f1[e]; }
+        }
+    }
+    colsum_block_reduce(partial, acc, C);
+}
+
+// ---- gradient finalisation: dst[map(r)][c] += sum_p part[p][r][c], many tensors per launch ---
+// One workgroup = CL consecutive 4-element chunks x PL part lanes (CL * PL = 256): part lane l
+// adds parts l, l + PL, ... in ascending order, the lanes are combined in ascending order through
+// LDS — a fixed summation tree (bit-reproducible), no atomics.
+struct GradJobs {
+    cream_grad_job job[CREAM_MAX_GRAD_JOBS];
+    int first_block[CREAM_MAX_GRAD_JOBS + 1];
+    int njobs;
+};
+
+__device__ __forceinline__ f32x4v load_part4(const void* src, int64_t idx, bool is_bf16) {
+    if (is_bf16) {
+        float f[4];
+        unpack_bf16x4(*reinterpret_cast<const u32x2v*>(reinterpret_cast<const uint16_t*>(src) + idx), f);
+        return f32x4v{f[0], f[1], f[2], f[3]};
+    }
+    return *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(src) + idx);
+}
+
+__device__ __forceinline__ int grad_part_lanes(int nparts) { return nparts <= 16 ? 4 : 16; }
+
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J) {
+    __shared__ f32x4v red[256];
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const cream_grad_job jb = J.job[j];
+    const int PL = grad_part_lanes(jb.nparts), CL = 256 / PL;
+    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    const int cpr = jb.cols >> 2;                              // chunks per row
+    const int64_t nchunks = (int64_t)jb.rows * cpr;
+    const int64_t chunk = (int64_t)((int)blockIdx.x - J.first_block[j]) * CL + cl;
+    f32x4v acc = {0, 0, 0, 0};
+    if (chunk < nchunks) {
+        const bool bf = jb.src_bf16 != 0;
+        int p = pl;
+        for (; p + 3 * PL < jb.nparts; p += 4 * PL) {          // four loads in flight
+            const f32x4v a0 = load_part4(jb.src, (int64_t)p * jb.pstride + chunk * 4, bf);
+            const f32x4v a1 = load_part4(jb.src, (int64_t)(p + PL) * jb.pstride + chunk * 4, bf);
+            const f32x4v a2 = load_part4(jb.src, (int64_t)(p + 2 * PL) * jb.pstride + chunk * 4, bf);
+            const f32x4v a3 = load_part4(jb.src, (int64_t)(p + 3 * PL) * jb.pstride + chunk * 4, bf);
+            acc += a0; acc += a1; acc += a2; acc += a3;
+        }
+        for (; p < jb.nparts; p += PL) acc += load_part4(jb.src, (int64_t)p * jb.pstride + chunk * 4, bf);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0 && chunk < nchunks) {
+        f32x4v s = red[cl];
+        for (int l = 1; l < PL; ++l) s += red[l * CL + cl];
+        const int r = (int)(chunk / cpr), c = (int)(chunk - (int64_t)r * cpr) * 4;
+        const int rr = jb.interleave > 0 ? 3 * (r % jb.interleave) + r / jb.interleave : r;
+        float* d = jb.dst + (int64_t)rr * jb.ld + c;
+        f32x4v o = *reinterpret_cast<f32x4v*>(d);
+        o += s;
+        *reinterpret_cast<f32x4v*>(d) = o;
+    }
+}
+
 int grid_for(int64_t n_items, int per_block) {
     const int64_t b = (n_items + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
@@ -270,7 +452,7 @@ int grid_for(int64_t n_items, int per_block) {
 
 extern "C" {
 
-int cream_ln_partials(void) { return 512; }
+int cream_ln_partials(void) { return 1024; }
 
 int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
                  int M, int E, float eps, void* stream)
@@ -281,7 +463,22 @@ int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float*
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16) return CREAM_ERR_BAD_ARG;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
-                       x, gamma, beta, M, E, eps);
+                       x, gamma, beta, M, E, eps, (float*)nullptr, (const uint16_t*)nullptr, (const float*)nullptr, 1);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float* x, const void* res,
+                     const float* sample_scale, int rows_per_sample, const float* gamma, const float* beta,
+                     int M, int E, float eps, void* stream)
+{
+    if (M < 0 || E <= 0 || rows_per_sample <= 0) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!xsum || !y || !mean || !rstd || !x || !res || !gamma || !beta) return CREAM_ERR_BAD_ARG;
+    if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
+    if (((uintptr_t)xsum | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16 || (uintptr_t)res % 8)
+        return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+                       x, gamma, beta, M, E, eps, xsum, (const uint16_t*)res, sample_scale, rows_per_sample);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -294,7 +491,9 @@ int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, con
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)dx | (uintptr_t)dx_scaled | (uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dres) % 16)
         return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
+    // register footprint follows the row width: 2 chunks per lane cover E <= 512, 3 cover E <= 768
+    auto kern = E <= 512 ? ln_bwd_kernel<2> : (E <= 768 ? ln_bwd_kernel<3> : ln_bwd_kernel<LN_MAXC>);
+    hipLaunchKernelGGL(kern, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
                        (uint16_t*)dx_scaled, partial, (const uint16_t*)dy, x, mean, rstd, gamma, dres, sample_scale,
                        rows_per_sample, M, E);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
@@ -351,6 +550,64 @@ int cream_colsum(float* partial, const void* a, int M, int C, void* stream)
     if (!partial || !a || (uintptr_t)a % 16) return CREAM_ERR_BAD_ARG;
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, cream_colsum_slabs(M)), dim3(256), 0, (hipStream_t)stream,
                        partial, (const uint16_t*)a, M, C, 512);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_colsum128_slabs(int M) { return M <= 0 ? 0 : (M + CS_ROWS - 1) / CS_ROWS; }
+
+int cream_colsum128(float* partial, const void* a, int M, int C, void* stream)
+{
+    if (M < 0 || C <= 0 || C % 8) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!partial || !a || (uintptr_t)a % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(colsum128_kernel, dim3((C + 255) / 256, cream_colsum128_slabs(M)), dim3(256), 0,
+                       (hipStream_t)stream, partial, (const uint16_t*)a, M, C);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_gelu_bwd_colsum(void* dh, float* partial, const void* dg, const void* h, int M, int C, void* stream)
+{
+    if (M < 0 || C <= 0 || C % 8) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!dh || !partial || !dg || !h || ((uintptr_t)dh | (uintptr_t)dg | (uintptr_t)h) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((C + 255) / 256, cream_colsum128_slabs(M)), dim3(256), 0,
+                       (hipStream_t)stream, (uint16_t*)dh, partial, (const uint16_t*)dg, (const uint16_t*)h, M, C);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_scale_cast_colsum(void* out, float* partial, const float* x, const float* sample_scale,
+                            int rows_per_sample, int M, int C, void* stream)
+{
+    if (M < 0 || C <= 0 || C % 8 || rows_per_sample <= 0) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!out || !partial || !x || ((uintptr_t)out | (uintptr_t)x) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scale_cast_colsum_kernel, dim3((C + 255) / 256, cream_colsum128_slabs(M)), dim3(256), 0,
+                       (hipStream_t)stream, (uint16_t*)out, partial, x, sample_scale, rows_per_sample, M, C);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream)
+{
+    if (njobs < 0 || njobs > CREAM_MAX_GRAD_JOBS) return CREAM_ERR_BAD_ARG;
+    if (njobs == 0) return CREAM_OK;
+    if (!jobs) return CREAM_ERR_BAD_ARG;
+    GradJobs J;
+    J.njobs = njobs;
+    int blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const cream_grad_job& b = jobs[j];
+        if (!b.dst || !b.src || b.nparts <= 0 || b.rows <= 0 || b.cols <= 0 || b.cols % 4 || b.ld % 4 ||
+            b.pstride % 4 || b.interleave < 0 || (b.interleave > 0 && b.rows != 3 * b.interleave))
+            return CREAM_ERR_BAD_ARG;
+        if ((uintptr_t)b.dst % 16 || (uintptr_t)b.src % (b.src_bf16 ? 8 : 16)) return CREAM_ERR_BAD_ARG;
+        J.job[j] = b;
+        J.first_block[j] = blocks;
+        const int CL = 256 / (b.nparts <= 16 ? 4 : 16);
+        const int64_t nchunks = (int64_t)b.rows * (b.cols / 4);
+        blocks += (int)((nchunks + CL - 1) / CL);
+    }
+    J.first_block[njobs] = blocks;
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

@@ -22,11 +22,27 @@ def reset():
     _records.clear()
 
 
-@contextlib.contextmanager
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+
+
 def region(name, nbytes=0, flops=0):
+    """Context manager around one or more launches.  Disabled / filtered regions return a
+    shared no-op object (this sits on the launch path of every kernel)."""
     if not _enabled or (_only is not None and name not in _only):
-        yield
-        return
+        return _NULL
+    return _timed(name, nbytes, flops)
+
+
+@contextlib.contextmanager
+def _timed(name, nbytes, flops):
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
     a.record()

@@ -143,14 +143,24 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
 int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma,
                  const float* beta, int M, int E, float eps, void* stream);
 
-/* Number of row slabs ln_bwd reduces over: partial must hold cream_ln_partials()*2*E floats. */
+/* Residual add fused with the following LayerNorm (supernet_transformer.py:266-275: the
+ * attention branch's  x = residual + drop_path(x)  and the  ffn_layer_norm  that reads it):
+ * xsum(f32) = x(f32) + sample_scale[row / rows_per_sample] * res(bf16)  (scale may be NULL = 1),
+ * y(bf16) = LayerNorm(xsum), mean/rstd of xsum saved. */
+int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float* x, const void* res,
+                     const float* sample_scale, int rows_per_sample, const float* gamma,
+                     const float* beta, int M, int E, float eps, void* stream);
+
+/* Number of row slabs ln_bwd reduces over: partial must hold cream_ln_partials()*3*E floats. */
 int cream_ln_partials(void);
 
 /* dx(f32) = dres + dLayerNorm(dy(bf16)); if dx_scaled != NULL also writes
  * bf16(dx * sample_scale[row / rows_per_sample]) (sample_scale may be NULL = 1): the gradient
  * entering the previous residual branch with its drop-path scale.  dres may be NULL.
- * partial[p][0][:] / partial[p][1][:] = per-slab sums for dgamma / dbeta (caller adds the
- * slabs: fixed order). */
+ * partial[p][0][:] / partial[p][1][:] = per-slab sums for dgamma / dbeta; partial[p][2][:] =
+ * column sums of the bf16 values written to dx_scaled (= bias gradient of the projection
+ * whose output gradient dx_scaled is; zeros when dx_scaled is NULL).  The caller adds the
+ * slabs (cream_grad_finalize): fixed order. */
 int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, const float* x,
                  const float* mean, const float* rstd, const float* gamma, const float* dres,
                  const float* sample_scale, int rows_per_sample, int M, int E, void* stream);
@@ -171,6 +181,43 @@ int cream_scale_cast(void* out, const float* x, const float* sample_scale, int64
  * (cream_colsum_slabs(M) slabs of 512 rows); the caller adds the slabs. */
 int cream_colsum_slabs(int M);
 int cream_colsum(float* partial, const void* a, int M, int C, void* stream);
+
+/* The same passes with the bias gradient riding along (what autograd's sum-to-size of
+ * F.linear's bias produces, Linear_super.py:52-54 / qkv_super.py:49-51), 128-row slabs:
+ * partial[s][c] = sum over the rows of slab s of the bf16-ROUNDED values written (so the result
+ * equals cream_colsum of the output), cream_colsum128_slabs(M) slabs, C % 8 == 0.
+ *   cream_gelu_bwd_colsum    dh(bf16, M x C) = dg * gelu'(h)                    (fc1 bias)
+ *   cream_scale_cast_colsum  out(bf16, M x C) = sample_scale[row / rows_per_sample] * x(f32)
+ *                                                                                  (fc2 bias)
+ *   cream_colsum128          column sums only (qkv bias: dqkv leaves the attention kernels) */
+int cream_colsum128_slabs(int M);
+int cream_colsum128(float* partial, const void* a, int M, int C, void* stream);
+int cream_gelu_bwd_colsum(void* dh, float* partial, const void* dg, const void* h, int M, int C,
+                          void* stream);
+int cream_scale_cast_colsum(void* out, float* partial, const float* x, const float* sample_scale,
+                            int rows_per_sample, int M, int C, void* stream);
+
+/* Gradient finalisation for the weight-entangled parameters: every tensor of a block gets
+ *     dst[map(r)*ld + c] += sum_p src[p*pstride + r*cols + c]          r < rows, c < cols
+ * in ONE launch — dst is the ACTIVE SLICE W[:out, :in] of the fp32 super-weight gradient
+ * (ld = super width; what autograd's backward of the slicing in Linear_super.py:71-81 and
+ * qkv_super.py:72-83 accumulates), src are partial sums produced upstream (split-K weight
+ * gradient GEMMs, per-slab column sums, per-(batch, head) table gradients).  interleave = Q > 0:
+ * the rows of src are grouped [q | k | v] (Q each) and row r goes to super row
+ * 3*(r % Q) + r / Q — the adjoint of qkv_super's row gather (qkv_super.py:75).  Parts are
+ * added in a fixed tree: bit-reproducible.  cols, ld, pstride % 4 == 0. */
+typedef struct cream_grad_job {
+    float* dst;
+    const void* src;
+    int64_t ld;
+    int64_t pstride;       /* elements between consecutive parts */
+    int32_t nparts, rows, cols;
+    int32_t interleave;
+    int32_t src_bf16;      /* partials are bf16 (1) or fp32 (0) */
+    int32_t reserved;
+} cream_grad_job;
+#define CREAM_MAX_GRAD_JOBS 24
+int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
 #ifdef __cplusplus
 }  /* extern "C" */

@@ -44,8 +44,18 @@ def test_layernorm_kernels_match_torch_fp32(M, E):
     assert _rel(dx, xr.grad + dres) < 1e-5
     assert _rel(dxs.float(), (xr.grad + dres) * scale.repeat_interleave(rows)[:, None]) < 1e-2
     assert _rel(part[0], wr.grad) < 1e-4 and _rel(part[1], br.grad) < 1e-4
-    dx2, none, _ = K.ln_bwd(dy, x, mean, rstd, w, None, None, 1, False)
-    assert none is None and _rel(dx2, xr.grad) < 1e-5
+    assert _rel(part[2], dxs.float().sum(0)) < 1e-5                      # bias gradient rides along
+    dx2, none, part2 = K.ln_bwd(dy, x, mean, rstd, w, None, None, 1, False)
+    assert none is None and _rel(dx2, xr.grad) < 1e-5 and float(part2[2].abs().max()) == 0.0
+    # residual add fused with the LayerNorm that follows it
+    res = torch.randn(M, E, device=DEV, generator=g).bfloat16()
+    x1, y1, mean1, rstd1 = K.add_ln_fwd(x, res, scale, rows, w, b, 1e-5)
+    x1_ref = x + scale.repeat_interleave(rows)[:, None] * res.float()
+    assert _rel(x1, x1_ref) < 1e-6
+    assert _rel(y1.float(), F.layer_norm(x1_ref, (E,), w, b, 1e-5)) < 1e-2
+    assert _rel(mean1, x1_ref.mean(1)) < 1e-5
+    x1n, _, _, _ = K.add_ln_fwd(x, res, None, 1, w, b, 1e-5)
+    assert _rel(x1n, x + res.float()) < 1e-6
 
 
 def test_gelu_residual_scale_colsum_match_torch_fp32():
@@ -67,6 +77,72 @@ def test_gelu_residual_scale_colsum_match_torch_fp32():
     assert _rel(K.scale_cast(x, s, rows * C).float(), x * srow) < 1e-2
     assert _rel(K.colsum(h), h.float().sum(0)) < 1e-5
     assert _rel(K.wgrad(dg, h), dg.float().t() @ h.float()) < 2e-2
+
+
+@pytest.mark.parametrize("M,C", [(197 * 4, 1344), (130, 320), (25216, 448)])
+def test_passes_with_bias_gradient_match_torch_fp32(M, C):
+    """gelu_bwd / scale_cast with the column sums riding along, against the two-kernel form."""
+    from cream_amd.autoformer import block as K
+    g = torch.Generator(device=DEV).manual_seed(2)
+    rows = 197 if M % 197 == 0 else M
+    h = (torch.randn(M, C, device=DEV, generator=g) * 2).bfloat16()
+    dg = torch.randn(M, C, device=DEV, generator=g).bfloat16()
+    dh, part = K.gelu_bwd_colsum(dg, h)
+    assert torch.equal(dh, K.gelu_bwd(dg, h))
+    assert _rel(part.sum(0), dh.float().sum(0)) < 1e-5
+    x = torch.randn(M, C, device=DEV, generator=g)
+    s = torch.rand(M // rows, device=DEV, generator=g)
+    out, part = K.scale_cast_colsum(x, s, rows)
+    assert torch.equal(out, K.scale_cast(x, s, rows * C))
+    assert _rel(part.sum(0), out.float().sum(0)) < 1e-5
+    assert _rel(K.colsum128(h).sum(0), h.float().sum(0)) < 1e-5
+
+
+def test_grad_finalize_adds_partials_into_super_weight_slices():
+    """cream_grad_finalize: many tensors in one launch, strided destination slices, the qkv row
+    interleave (qkv_super.py:75), bf16 and fp32 partials, accumulation (+=), reproducible bits."""
+    from cream_amd.autoformer import block as K
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Q, E, SE = 128, 216, 256
+    w = torch.nn.Parameter(torch.zeros(448, SE, device=DEV))            # plain slice W[:out, :in]
+    wq = torch.nn.Parameter(torch.zeros(3 * 192, SE, device=DEV))       # interleaved qkv rows
+    bias = torch.nn.Parameter(torch.zeros(448, device=DEV))
+    tab = torch.nn.Parameter(torch.zeros(30, 64, device=DEV))
+    w.grad = torch.randn(448, SE, device=DEV, generator=g)
+    wq.grad = torch.randn(3 * 192, SE, device=DEV, generator=g)
+    bias.grad = torch.randn(448, device=DEV, generator=g)
+    before = [p.grad.clone() for p in (w, wq, bias, tab) if p.grad is not None]
+    pw = torch.randn(8, 320, E, device=DEV, generator=g).bfloat16()
+    pq = torch.randn(8, 3 * Q, E, device=DEV, generator=g).bfloat16()
+    pb = torch.randn(197, 320, device=DEV, generator=g)
+    pt = torch.randn(768, 4, 32, 64, device=DEV, generator=g)
+
+    def run():
+        jobs = K.GradJobs()
+        jobs.add(w, pw, 8, 320 * E, 320, E)
+        jobs.add(wq, pq, 8, 3 * Q * E, 3 * Q, E, interleave=Q)
+        jobs.add(bias, pb, 197, 320, 1, 320)
+        jobs.add(tab, pt, 768, 4 * 32 * 64, 30, 64, src_offset=2 * 32 * 64)
+        jobs.launch()
+
+    run()
+    ref_w = before[0].clone()
+    ref_w[:320, :E] += pw.float().sum(0)
+    assert _rel(w.grad, ref_w) < 1e-6 and torch.equal(w.grad[320:], before[0][320:]) \
+        and torch.equal(w.grad[:, E:], before[0][:, E:])
+    ref_q = before[1].clone()
+    ref_q[:3 * Q].view(Q, 3, SE)[:, :, :E] += pq.float().sum(0).view(3, Q, E).transpose(0, 1)
+    assert _rel(wq.grad, ref_q) < 1e-6
+    ref_b = before[2].clone()
+    ref_b[:320] += pb.sum(0)
+    assert _rel(bias.grad, ref_b) < 1e-5
+    assert _rel(tab.grad, pt[:, 2, :30].sum(0)) < 1e-5                  # grad was None: created as zeros
+    first = [p.grad.clone() for p in (w, wq, bias, tab)]
+    for p, b0 in zip((w, wq, bias), before):
+        p.grad.copy_(b0)
+    tab.grad.zero_()
+    run()
+    assert all(torch.equal(a, p.grad) for a, p in zip(first, (w, wq, bias, tab)))   # fixed summation tree
 
 
 def _supernet(depth=2):
