@@ -151,23 +151,27 @@ template <> struct Tr<float> {
 // token 0 = class token, tokens 1.. = gh x gw grid (row-major); bucket of (query i, key j)
 //   vertical   : clamp(kr - qr, +-mr) + mr + 1     horizontal: clamp(kc - qc, +-mr) + mr + 1
 //   bucket 0 when i == 0 or j == 0.
-// Slots of a key: [0, gh) = grid row, gh = "class token key", [gh+1, gh+1+gw) = grid column;
-// the fused kernels need gh + gw + 1 <= 32 and 2*mr + 2 <= 32.
+// Slots of a key: [0, gh) = grid row, gh = "class token key", [CB, CB+gw) = grid column with
+// CB = 16 (so the first 16-slot contraction step is the vertical table, the second one the
+// horizontal table); the fused kernels need gh <= 15, gw <= 16 and 2*mr + 2 <= 32.
 struct RelGeom {
     int n;          // tokens (gh*gw + 1)
     int gh, gw;     // grid
     int mr;         // max_relative_position
 };
 
+constexpr int CB = 16;      // first grid-column slot
+
 // slot mask of key j (0 for padding keys j >= n)
 __device__ __forceinline__ uint32_t key_mask(int j, const RelGeom& G) {
     if (j >= G.n) return 0u;
     if (j == 0) return 1u << G.gh;
     const int r = (j - 1) / G.gw, c = (j - 1) - r * G.gw;
-    return (1u << r) | (1u << (G.gh + 1 + c));
+    return (1u << r) | (1u << (CB + c));
 }
 
-constexpr int LP = 65;      // pitch (floats) of the per-wave [32][64] shift scratch rows
+constexpr int LP = 71;      // pitch (floats) of the per-wave shift scratch rows: [32][64] bucket
+                            // lookups, or the zero-padded slot windows of slots_to_buckets14
 
 // x_i[c]: extension of query i for slot c, from its bucket lookups row[0..31] (vertical
 // table) and row[32..63] (horizontal table).  Used for the key-side bias (row = q.T_k^T)
@@ -175,10 +179,10 @@ constexpr int LP = 65;      // pitch (floats) of the per-wave [32][64] shift scr
 __device__ __forceinline__ float ext_gather(const float* row, float cls, int c, int qi, int qr, int qc,
                                             const RelGeom& G) {
     const int iv = clampi(c - qr, -G.mr, G.mr) + G.mr + 1;
-    const int ih = 32 + clampi(c - G.gh - 1 - qc, -G.mr, G.mr) + G.mr + 1;
-    float x = row[c < G.gh ? iv : ih];
+    const int ih = 32 + clampi(c - CB - qc, -G.mr, G.mr) + G.mr + 1;
+    float x = row[c < CB ? iv : ih];
     x = c == G.gh ? cls : x;
-    x = c > G.gh + G.gw ? 0.f : x;
+    x = ((c > G.gh && c < CB) || c >= CB + G.gw) ? 0.f : x;
     const float x0 = c <= G.gh ? cls : 0.f;          // class-token query: every key has bucket 0
     return qi == 0 ? x0 : x;
 }
@@ -189,7 +193,7 @@ __device__ __forceinline__ float ext_gather(const float* row, float cls, int c, 
 //   u = d + mr + 1   : the slot at relative distance d, plus everything clamped onto it
 __device__ __forceinline__ float bucket_from_slots(const float* slot, int u, int tab, int qi, int qr, int qc,
                                                    const RelGeom& G) {
-    const int lim = tab == 0 ? G.gh : G.gw, base = tab == 0 ? 0 : G.gh + 1, pos0 = tab == 0 ? qr : qc;
+    const int lim = tab == 0 ? G.gh : G.gw, base = tab == 0 ? 0 : CB, pos0 = tab == 0 ? qr : qc;
     const int d = u - G.mr - 1;
     const int pos = pos0 + d;
     const bool inside = u >= 1 && u <= 2 * G.mr + 1 && pos >= 0 && pos < lim;
@@ -210,6 +214,94 @@ __device__ __forceinline__ float bucket_from_slots(const float* slot, int u, int
 __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---- the AutoFormer geometry (14 x 14 grid, max_relative_position 14, N = 197) ---------------
+// No relative distance is clamped (13 <= 14), so the slot <-> bucket shift of a query is a pure
+// WINDOW: x_i[row slot c] = Lv[i][c - qr + 15] — 14 consecutive lookups starting at 15 - qr — and
+// the adjoint is a window of the zero-padded slot vector.  With one per-lane base address all
+// index arithmetic folds into the immediate offsets of ds_read_b32: the generic gathers above
+// cost ~8 VALU instructions per element, and these kernels are VALU-issue-bound.
+constexpr int G14 = 14;
+
+// 16 slot values (one 16-slot half: kh = 0 vertical incl. the class-token slot, kh = 1
+// horizontal) of this lane's query: lane group g supplies slots kh*16 + 8g + e, e = 0..7.
+// `row` holds the bucket lookups (row[u] vertical, row[32 + u] horizontal table).
+__device__ __forceinline__ void ext_window14(float (&x)[8], const float* row, float cls, int kh, int g, int qr, int qc) {
+    const float* p = row + (kh == 0 ? 15 - qr : 32 + 15 - qc) + 8 * g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p[e];
+    // slots 14 (class token key), 15 and 30, 31 (unused) sit in lane group 1, e = 6, 7
+    x[6] = g ? (kh == 0 ? cls : 0.f) : x[6];
+    x[7] = g ? 0.f : x[7];
+}
+
+// class-token query (query 0: lane pair 0 of the first query tile): every key has bucket 0, so
+// x_0[c] = cls for the row slots and the class-token slot, 0 for the column slots.  Rewrites
+// that query's lookup row so that ext_window14 returns exactly this.  Call between the cls read
+// and the window reads, wave-uniformly for the first query tile only.
+__device__ __forceinline__ void ext_fix_query0(float* row, float cls, int lane) {
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            row[15 + u] = cls;
+            row[32 + 15 + u] = 0.f;
+        }
+    }
+}
+
+// Adjoint: slot tile (accumulator layout: this lane holds slots acc_row(r, g) of its query) ->
+// the 32 bucket values of table g (0 vertical / 1 horizontal) of this lane's query.
+// Row layout (floats): [0,14) zeros | [14,28) row slots | [28,42) zeros | [42,56) column slots |
+// [56,70) zeros | [70] class-token slot.   bucket u = d + 15 of a query at grid position pos0 is
+// the slot at pos0 + d: index 14 + pos0 + d = pos0 + u - 1 (+28 for the horizontal table).
+__device__ __forceinline__ void slots_to_buckets14(float (&bk)[32], float* scr, const f32x16& x, int lane, bool tile0,
+                                                   int qr, int qc) {
+    const int g = lane >> 5;
+    float* row = scr + (lane & 31) * LP;
+    // zero pads: lane group 0 writes [0,14) and [28,42), lane group 1 [56,70) and (again) [28,42)
+    {
+        float* z = row + (g ? 56 : 0);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) { z[i] = 0.f; row[28 + i] = 0.f; }
+    }
+    wave_lds_fence();                  // the two lane groups of a query write overlapping zeros first
+    // slots c = c0 + 4g, c0 = (r & 3) + 8 * (r >> 2): r < 8 -> vertical half, r >= 8 -> horizontal
+    {
+        float* wv = row + 14 + 4 * g;                  // slot c -> index 14 + c      (c = 0..13)
+        float* wh = row + 42 - 16 + 4 * g;             // slot c -> index 42 + c - 16 (c = 16..29)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c0 = (r & 3) + 8 * (r >> 2);
+            // slot 14 (c0 = 10, g = 1) is the class-token key slot; slot 15 (c0 = 11, g = 1) is
+            // never set in a key mask, its value is exactly 0 and lands in the zero pad
+            if (c0 == 10) *(g ? row + 70 : wv + c0) = x[r];
+            else wv[c0] = x[r];
+        }
+#pragma unroll
+        for (int r = 8; r < 16; ++r) {
+            const int c0 = (r & 3) + 8 * (r >> 2);     // 16..19, 24..27 (+4g): slots 30, 31 are exactly 0
+            wh[c0] = x[r];
+        }
+    }
+    wave_lds_fence();
+    {
+        const float* p = row + (g ? 28 + qc : qr);
+        bk[0] = row[70];
+#pragma unroll
+        for (int u = 1; u < 30; ++u) bk[u] = p[u - 1];
+        bk[30] = 0.f;
+        bk[31] = 0.f;
+    }
+    if (tile0) {                        // class-token query: bucket 0 collects every key (row slots + cls)
+        float sum = row[70];
+#pragma unroll
+        for (int c = 0; c < G14; ++c) sum += row[14 + c];
+        const bool q0 = (lane & 31) == 0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bk[u] = q0 ? (u == 0 ? sum : 0.f) : bk[u];
+    }
+    wave_lds_fence();                  // the row is reused by the caller
 }
 
 }  // namespace cream

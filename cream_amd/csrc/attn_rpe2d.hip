@@ -158,6 +158,23 @@ __device__ __forceinline__ void build_ext(typename Tr<T>::frag (&xe)[32 / Tr<T>:
     }
 }
 
+// fast geometry (attn_common.hpp): window reads with immediate offsets; bf16 fragments only
+__device__ __forceinline__ void build_ext14(bf16x8 (&xe)[2], float* scr, int lane, bool tile0, int qr, int qc) {
+    const int g = lane >> 5;
+    float* row = scr + (lane & 31) * LP;
+    const float cls = row[0] + row[32];
+    if (tile0) {
+        ext_fix_query0(row, cls, lane);
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        float x[8];
+        ext_window14(x, row, cls, kh, g, qr, qc);
+        xe[kh] = __builtin_bit_cast(bf16x8, __builtin_convertvector((f32x8v{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}), hwbf16x8));
+    }
+}
+
 // slot tile (accumulator, lane = query, rows = slots) -> this lane's 32 bucket values of table
 // g (0 vertical / 1 horizontal) in `bk`, and the full bucket rows row[q][0..63] in scratch
 __device__ __forceinline__ void slots_to_buckets(float (&bk)[32], float* scr, const f32x16& x, int lane, int qi,
@@ -170,9 +187,6 @@ __device__ __forceinline__ void slots_to_buckets(float (&bk)[32], float* scr, co
 #pragma unroll
     for (int u = 0; u < 32; ++u) bk[u] = bucket_from_slots(row, u, g, qi, qr, qc, G);
     wave_lds_fence();
-#pragma unroll
-    for (int u = 0; u < 32; ++u) row[g * 32 + u] = bk[u];
-    wave_lds_fence();
 }
 
 // bucket rows^T (64 buckets x NP queries, dtype T) for the second backward launch
@@ -183,22 +197,30 @@ __device__ __forceinline__ void store_buckets_T(typename Tr<T>::elem* dst /* + q
     for (int u = 0; u < 32; ++u) dst[(int64_t)(g * 32 + u) * NP] = Tr<T>::from_f(bk[u]);
 }
 
-// acc^T(64 x 32 queries) += Tab^T(64 x 64 buckets) . rows^T  with Tab^T in LDS ([64][tp]) and the
-// bucket rows in the wave's fp32 scratch
+// acc^T(64 x 32 queries) += Tab^T(64 x 64 buckets) . rows^T  with Tab^T in LDS ([64][tp], columns
+// 0..31 vertical / 32..63 horizontal table) and the bucket rows still in registers: lane (q, g)
+// holds the 32 buckets of table g of its query, so in contraction step ks lane group g supplies
+// the elements (table g, bucket ks*EPL + e) — the order of the contraction index is free as
+// long as both operands agree.  No LDS round trip for the bucket rows.
 template <typename T>
 __device__ __forceinline__ void add_bucket_product(f32x16 (&o)[2], const typename Tr<T>::elem* tabT,
-                                                   const float* scr, int lane) {
+                                                   const float (&bk)[32], int lane) {
     using TT = Tr<T>;
     constexpr int tp = table_pitch<T>();
     const int g = lane >> 5;
-    const float* row = scr + (lane & 31) * LP;
 #pragma unroll
-    for (int ks = 0; ks < 64 / TT::KI; ++ks) {
-        const int k0 = ks * TT::KI + g * TT::EPL;
-        const typename TT::frag b = TT::load_f32(row + k0, true);
+    for (int ks = 0; ks < 32 / TT::EPL; ++ks) {
+        typename TT::frag b;
+        if constexpr (TT::EPL == 1) b = bk[ks];
+        else {
+            f32x8v x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = bk[ks * 8 + e];
+            b = __builtin_bit_cast(bf16x8, __builtin_convertvector(x, hwbf16x8));
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            o[dt] = TT::mma(TT::load(tabT + ((lane & 31) + 32 * dt) * tp + k0), b, o[dt]);
+            o[dt] = TT::mma(TT::load(tabT + ((lane & 31) + 32 * dt) * tp + g * 32 + ks * TT::EPL), b, o[dt]);
     }
 }
 
@@ -295,6 +317,41 @@ __device__ __forceinline__ void fill_tables_R(typename Tr<T>::elem* tabR, const 
     }
 }
 
+// ---- one-hot key operands as ready-made bf16 MFMA fragments (fast path) ------------------------
+// ohr[j][c]  ([NP][OHP])     : rows = keys, contraction = slots  (S^T += E . X^T)
+// oht[c][j]  ([32][NP + 4])  : rows = slots, contraction = keys  (slot sums += E^T . P^T), read
+//                              with load_perm like a transposed V tile
+// Built once per workgroup from the geometry; the bit-twiddled operands (Tr::onehot_row /
+// onehot_perm, ~45 VALU instructions per key tile and wave) disappear from the tile loops.
+constexpr int OHP = 40;
+__host__ __device__ constexpr int oht_pitch(int NP) { return NP + 4; }
+__host__ __device__ constexpr size_t onehot_bytes(int NP) { return (size_t)NP * OHP * 2 + (size_t)32 * oht_pitch(NP) * 2; }
+
+__device__ __forceinline__ void fill_onehot(short* ohr, short* oht, const uint32_t* masks, int NP) {
+    // masks[] must be visible (barrier) before this call
+    for (int i = threadIdx.x; i < NP * 4; i += blockDim.x) {          // 8 slots of one key
+        const int j = i >> 2, cc = i & 3;
+        const uint32_t m = masks[j] >> (8 * cc);
+        u32x4v w;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) w[p] = ((m >> (2 * p)) & 1u) * 0x3F80u + ((m >> (2 * p + 1)) & 1u) * 0x3F800000u;
+        *reinterpret_cast<u32x4v*>(ohr + j * OHP + cc * 8) = w;
+    }
+    const int tpo = oht_pitch(NP);
+    for (int i = threadIdx.x; i < 32 * (NP >> 3); i += blockDim.x) {  // 8 keys of one slot
+        const int c = i / (NP >> 3), j0 = (i - c * (NP >> 3)) * 8;
+        const u32x4v lo = *reinterpret_cast<const u32x4v*>(masks + j0);
+        const u32x4v hi = *reinterpret_cast<const u32x4v*>(masks + j0 + 4);
+        u32x2v w0, w1;
+        w0[0] = ((lo[0] >> c) & 1u) * 0x3F80u + ((lo[1] >> c) & 1u) * 0x3F800000u;
+        w0[1] = ((lo[2] >> c) & 1u) * 0x3F80u + ((lo[3] >> c) & 1u) * 0x3F800000u;
+        w1[0] = ((hi[0] >> c) & 1u) * 0x3F80u + ((hi[1] >> c) & 1u) * 0x3F800000u;
+        w1[1] = ((hi[2] >> c) & 1u) * 0x3F80u + ((hi[3] >> c) & 1u) * 0x3F800000u;
+        *reinterpret_cast<u32x2v*>(oht + c * tpo + j0) = w0;
+        *reinterpret_cast<u32x2v*>(oht + c * tpo + j0 + 4) = w1;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_ext_rows(typename Tr<T>::elem* dst /* row of 32 */,
                                                const typename Tr<T>::frag (&xe)[32 / Tr<T>::KI], int g) {
@@ -336,14 +393,16 @@ template <typename T> __host__ __device__ constexpr size_t t_tile_bytes() { retu
 // forward
 // ---------------------------------------------------------------------------------------
 // LDS: [2 x max(K tile, V^T tile)] | value tables^T [64][tp] | key table rows [64][tp] (bf16) | masks [NP] | scratch
-template <typename T> size_t fwd_lds_bytes(int NP, int waves) {
+template <typename T> size_t fwd_lds_bytes(int NP, int waves, bool fast) {
     using E = typename Tr<T>::elem;
     const size_t tile = rm_tile_bytes<T>(64) > t_tile_bytes<T>() ? rm_tile_bytes<T>(64) : t_tile_bytes<T>();
     return 2 * tile + (size_t)(64 + tabr_rows<T>(2)) * table_pitch<T>() * sizeof(E) + (size_t)NP * 4 +
-           (size_t)waves * 32 * LP * 4;
+           (size_t)waves * 32 * LP * 4 + (fast ? onehot_bytes(NP) : 0);
 }
 
-template <typename T, int NT>
+// FAST: the AutoFormer geometry (14 x 14 grid, max_relative_position 14, bf16): compile-time
+// shapes, window-read shifts and one-hot operands staged in LDS (see attn_common.hpp)
+template <typename T, int NT, bool FAST>
 __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(const FwdArgs a) {
     using TT = Tr<T>;
     using E = typename TT::elem;
@@ -351,8 +410,9 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     constexpr int KI = TT::KI, EPL = TT::EPL, S64 = 64 / KI, S32 = 32 / KI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const RelGeom G = a.G;
-    const int N = G.n, NP = a.NP;
+    static_assert(!FAST || (sizeof(E) == 2 && NT == 7), "fast path: bf16, N = 197");
+    const RelGeom G = FAST ? RelGeom{197, G14, G14, G14} : a.G;
+    const int N = G.n, NP = FAST ? 224 : a.NP;
     const int nt = NP >> 5;
     constexpr int tp = table_pitch<T>(), kp = rm_pitch<T>(64), vp = t_pitch<T>();
     constexpr size_t tile_b = rm_tile_bytes<T>(64) > t_tile_bytes<T>() ? rm_tile_bytes<T>(64) : t_tile_bytes<T>();
@@ -362,6 +422,9 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     E* tkr = tvt + 64 * tp;                                               // key table rows [64][tp] (bf16)
     uint32_t* masks = reinterpret_cast<uint32_t*>(tkr + tabr_rows<T>(2) * tp);   // [NP]
     float* scratch = reinterpret_cast<float*>(masks + NP);                // [waves][32][LP]
+    short* ohr = reinterpret_cast<short*>(scratch + (blockDim.x >> 6) * 32 * LP);   // fast path: one-hot operands
+    short* oht = ohr + NP * OHP;
+    const int otp = oht_pitch(NP);
 
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -386,6 +449,10 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     fill_tables_T<T>(tvt, a.tvv, a.tvh, a.ldt, a.nb);
     if constexpr (tables_in_lds<T>()) fill_tables_R<T>(tkr, a.tkv, a.tkh, a.ldt, a.nb);
     for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
+    if constexpr (FAST) {
+        __syncthreads();
+        fill_onehot(ohr, oht, masks, NP);
+    }
     tile_store<T, 32, 64, true, false>(st, buf0, kp, nullptr, 0);
     __syncthreads();
     PROF_MARK();
@@ -397,7 +464,8 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     if (active) {
         table_lookups<T>(scr, qb, tkr, a.tkv, a.tkh, a.ldt, a.nb, lane);
         wave_lds_fence();
-        build_ext<T>(qe, scr, lane, qi, qr, qc, G);
+        if constexpr (FAST) build_ext14(qe, scr, lane, wave == 0, qr, qc);
+        else build_ext<T>(qe, scr, lane, qi, qr, qc, G);
     }
     PROF_MARK();
 
@@ -414,9 +482,15 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
 #pragma unroll
                 for (int ks = 0; ks < S64; ++ks)
                     s[t] = TT::mma(TT::load(kb + c32 * kp + ks * KI + g * EPL), qb[ks], s[t]);
-                const uint32_t km = masks[t * 32 + c32];
+                if constexpr (FAST) {
 #pragma unroll
-                for (int ks = 0; ks < S32; ++ks) s[t] = TT::mma(TT::onehot_row(km, ks, g), qe[ks], s[t]);
+                    for (int ks = 0; ks < S32; ++ks)
+                        s[t] = TT::mma(TT::load(ohr + (t * 32 + c32) * OHP + ks * KI + g * EPL), qe[ks], s[t]);
+                } else {
+                    const uint32_t km = masks[t * 32 + c32];
+#pragma unroll
+                    for (int ks = 0; ks < S32; ++ks) s[t] = TT::mma(TT::onehot_row(km, ks, g), qe[ks], s[t]);
+                }
             }
             if (t + 1 < nt) {
                 tile_store<T, 32, 64, true, false>(st, (t & 1) ? buf0 : buf1, kp, nullptr, 0);
@@ -455,7 +529,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
         if (t < nt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[t][r] * sc - msc);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sc, -msc));
                 s[t][r] = p;
                 l4[r & 3] += p;
             }
@@ -482,7 +556,8 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
                     const F pb = TT::from_acc(s[t], st2);
                     o[0] = TT::mma(TT::load_perm(vb + c32 * vp, st2, g), pb, o[0]);
                     o[1] = TT::mma(TT::load_perm(vb + (c32 + 32) * vp, st2, g), pb, o[1]);
-                    ox = TT::mma(TT::onehot_perm(masks + t * 32, st2, g, c32), pb, ox);
+                    if constexpr (FAST) ox = TT::mma(TT::load_perm(oht + c32 * otp + t * 32, st2, g), pb, ox);
+                    else ox = TT::mma(TT::onehot_perm(masks + t * 32, st2, g, c32), pb, ox);
                 }
             }
             if (t + 1 < nt) {
@@ -497,10 +572,11 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
 
     // ---- value-side relative position term: slot sums -> bucket sums -> . tables ---------
     float bk[32];
-    slots_to_buckets(bk, scr, ox, lane, qi, qr, qc, G);
+    if constexpr (FAST) slots_to_buckets14(bk, scr, ox, lane, wave == 0, min(qr, G14 - 1), qc);
+    else slots_to_buckets(bk, scr, ox, lane, qi, qr, qc, G);
     // S'^T (64 buckets x NP queries) for backward (dTvv / dTvh)
     store_buckets_T<T>(reinterpret_cast<E*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);
-    add_bucket_product<T>(o, tvt, scr, lane);
+    add_bucket_product<T>(o, tvt, bk, lane);
     PROF_MARK();
 
     // ---- store O (b, n, h, :) ----------------------------------------------------------------
@@ -509,11 +585,13 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     PROF_FLUSH();
 }
 
-template <typename T, int NT>
+bool fast_geometry(const RelGeom& G) { return G.n == 197 && G.gh == G14 && G.gw == G14 && G.mr == G14; }
+
+template <typename T, int NT, bool FAST = false>
 int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     const int waves = a.NP / 32 < 4 ? 4 : a.NP / 32;
-    const size_t lds = fwd_lds_bytes<T>(a.NP, waves);
-    auto kern = attn_rpe2d_fwd_kernel<T, NT>;
+    const size_t lds = fwd_lds_bytes<T>(a.NP, waves, FAST);
+    auto kern = attn_rpe2d_fwd_kernel<T, NT, FAST>;
     static bool attr_done = false;           // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -530,6 +608,9 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     const int nt = a.NP / 32;
     if (nt <= 2) return launch_fwd_nt<T, 2>(a, B, st);
     if (nt <= 4) return launch_fwd_nt<T, 4>(a, B, st);
+    if constexpr (sizeof(typename Tr<T>::elem) == 2) {
+        if (fast_geometry(a.G)) return launch_fwd_nt<T, 7, true>(a, B, st);
+    }
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);
 }
@@ -550,13 +631,13 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
 //   B  wave = key tile (lanes own keys): dK, dV (contraction over queries, so Q^T and dO^T
 //      live in LDS), then the four table gradients of this (b,h) as eight 32x32 MFMA jobs.
 // LDS of the dQ kernel: 2 x [K tile | V tile | K^T tile] | key tables^T | table rows (bf16) | masks | scratch
-template <typename T> size_t bwd_q_lds_bytes(int NP, int waves) {
+template <typename T> size_t bwd_q_lds_bytes(int NP, int waves, bool fast) {
     using E = typename Tr<T>::elem;
     return 2 * (2 * rm_tile_bytes<T>(64) + t_tile_bytes<T>()) + (size_t)(64 + tabr_rows<T>(4)) * table_pitch<T>() * sizeof(E) +
-           (size_t)NP * 4 + (size_t)waves * 32 * LP * 4;
+           (size_t)NP * 4 + (size_t)waves * 32 * LP * 4 + (fast ? onehot_bytes(NP) : 0);
 }
 
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) {
     using TT = Tr<T>;
     using E = typename TT::elem;
@@ -564,8 +645,9 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     constexpr int KI = TT::KI, EPL = TT::EPL, S64 = 64 / KI, S32 = 32 / KI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const RelGeom G = a.G;
-    const int N = G.n, NP = a.NP;
+    static_assert(!FAST || sizeof(E) == 2, "fast path: bf16");
+    const RelGeom G = FAST ? RelGeom{197, G14, G14, G14} : a.G;
+    const int N = G.n, NP = FAST ? 224 : a.NP;
     const int nt = NP >> 5;
     constexpr int tp = table_pitch<T>(), rp = rm_pitch<T>(64), ktp = t_pitch<T>();
     constexpr size_t set_b = 2 * rm_tile_bytes<T>(64) + t_tile_bytes<T>();
@@ -578,6 +660,9 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     E* tvr = tkr + tabr_rows<T>(2) * tp;
     uint32_t* masks = reinterpret_cast<uint32_t*>(tkr + tabr_rows<T>(4) * tp);
     float* scratch = reinterpret_cast<float*>(masks + NP);
+    short* ohr = reinterpret_cast<short*>(scratch + (blockDim.x >> 6) * 32 * LP);   // fast path: one-hot operands
+    short* oht = ohr + NP * OHP;
+    const int otp = oht_pitch(NP);
 
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int64_t bh = (int64_t)b * a.H + h;
@@ -615,6 +700,10 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
             fill_tables_R<T>(tvr, a.tvv, a.tvh, a.ldt, a.nb);
         }
         for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
+        if constexpr (FAST) {
+            __syncthreads();
+            fill_onehot(ohr, oht, masks, NP);
+        }
 
         // delta_i = dO_i . O_i  (this lane holds half of the 64 d-values; the partner the rest)
         if (!qok) { zero_frags<T, S64>(qb); zero_frags<T, S64>(dob); }
@@ -639,11 +728,13 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     if (active) {
         table_lookups<T>(scr, qb, tkr, a.tkv, a.tkh, a.ldt, a.nb, lane);
         wave_lds_fence();
-        build_ext<T>(qe, scr, lane, qi, qr, qc, G);
+        if constexpr (FAST) build_ext14(qe, scr, lane, wave == 0, qr, qc);
+        else build_ext<T>(qe, scr, lane, qi, qr, qc, G);
         wave_lds_fence();
         table_lookups<T>(scr, dob, tvr, a.tvv, a.tvh, a.ldt, a.nb, lane);
         wave_lds_fence();
-        build_ext<T>(de, scr, lane, qi, qr, qc, G);
+        if constexpr (FAST) build_ext14(de, scr, lane, wave == 0, qr, qc);
+        else build_ext<T>(de, scr, lane, qi, qr, qc, G);
         wave_lds_fence();
         store_ext_rows<T>(reinterpret_cast<E*>(a.qe) + (bh * NP + qi) * 32, qe, g);
         store_ext_rows<T>(reinterpret_cast<E*>(a.de) + (bh * NP + qi) * 32, de, g);
@@ -670,10 +761,13 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
                 sacc = TT::mma(TT::load(kb + ks * KI + g * EPL), qb[ks], sacc);
                 pacc = TT::mma(TT::load(vb + ks * KI + g * EPL), dob[ks], pacc);
             }
-            const uint32_t km = masks[t * 32 + c32];
+            uint32_t km = 0;
+            if constexpr (!FAST) km = masks[t * 32 + c32];
 #pragma unroll
             for (int ks = 0; ks < S32; ++ks) {
-                const F oh = TT::onehot_row(km, ks, g);
+                F oh;
+                if constexpr (FAST) oh = TT::load(ohr + (t * 32 + c32) * OHP + ks * KI + g * EPL);
+                else oh = TT::onehot_row(km, ks, g);
                 sacc = TT::mma(oh, qe[ks], sacc);
                 pacc = TT::mma(oh, de[ks], pacc);
             }
@@ -681,7 +775,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = t * 32 + acc_row(r, g) < N;
-                const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * sc - m2) : 0.f;
+                const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m2)) : 0.f;
                 sacc[r] = p * (pacc[r] - delta) * a.scale;
             }
             const E* ktb = ktbuf(cur);
@@ -690,7 +784,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
                 const F db = TT::from_acc(sacc, st);
                 dq[0] = TT::mma(TT::load_perm(ktb + c32 * ktp, st, g), db, dq[0]);
                 dq[1] = TT::mma(TT::load_perm(ktb + (c32 + 32) * ktp, st, g), db, dq[1]);
-                dx = TT::mma(TT::onehot_perm(masks + t * 32, st, g, c32), db, dx);
+                if constexpr (FAST) dx = TT::mma(TT::load_perm(oht + c32 * otp + t * 32, st, g), db, dx);
+                else dx = TT::mma(TT::onehot_perm(masks + t * 32, st, g, c32), db, dx);
             }
         }
         if (t + 1 < nt) {
@@ -703,10 +798,11 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     if (!active) return;
 
     float bk[32];
-    slots_to_buckets(bk, scr, dx, lane, qi, qr, qc, G);
+    if constexpr (FAST) slots_to_buckets14(bk, scr, dx, lane, wave == 0, min(qr, G14 - 1), qc);
+    else slots_to_buckets(bk, scr, dx, lane, qi, qr, qc, G);
     // dL'^T (64 buckets x NP queries) for the table gradients of launch B
     store_buckets_T<T>(reinterpret_cast<E*>(a.dlt) + bh * 64 * NP + qi, NP, bk, g);
-    add_bucket_product<T>(dq, tkt, scr, lane);
+    add_bucket_product<T>(dq, tkt, bk, lane);
     if (qok)
         store_rows_64<T>(reinterpret_cast<E*>(a.dq) + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh,
                          dq, g);
@@ -833,7 +929,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = t * 32 + acc_row(r, g);
-                const float p = kok ? __builtin_amdgcn_exp2f(sacc[r] * sc - lse2[qq]) : 0.f;
+                const float p = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -lse2[qq])) : 0.f;
                 sacc[r] = p;
                 pacc[r] = p * (pacc[r] - dlt_s[qq]) * a.scale;
             }
@@ -889,9 +985,9 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     PROF_FLUSH();
 }
 
-template <typename T>
-int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
-    auto kq = attn_rpe2d_bwd_q_kernel<T>;
+template <typename T, bool FAST>
+int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
+    auto kq = attn_rpe2d_bwd_q_kernel<T, FAST>;
     auto kkv = attn_rpe2d_bwd_kv_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -904,7 +1000,7 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
     }
     const int waves = a.NP / 32 < 4 ? 4 : a.NP / 32;
     const dim3 grid(B * a.H), block(waves * 64);
-    hipLaunchKernelGGL(kq, grid, block, bwd_q_lds_bytes<T>(a.NP, waves), st, a);
+    hipLaunchKernelGGL(kq, grid, block, bwd_q_lds_bytes<T>(a.NP, waves, FAST), st, a);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
 #ifdef PROBE_SKIP_KV                     // tools/probes/attn_probe.hip: keep the dQ kernel's phase stamps
     (void)kkv;
@@ -914,8 +1010,16 @@ int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+template <typename T>
+int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
+    if constexpr (sizeof(typename Tr<T>::elem) == 2) {
+        if (fast_geometry(a.G)) return launch_bwd_impl<T, true>(a, B, st);
+    }
+    return launch_bwd_impl<T, false>(a, B, st);
+}
+
 bool geom_ok(int N, int gh, int gw, int mr, int nb) {
-    return N >= 1 && N <= 256 && gh >= 0 && gw >= 1 && gh * gw + 1 == N && gh + gw + 1 <= 32 && mr >= 0 &&
+    return N >= 1 && N <= 256 && gh >= 0 && gw >= 1 && gh * gw + 1 == N && gh < CB && gw <= 32 - CB && mr >= 0 &&
            nb == 2 * mr + 2 && nb <= 32;
 }
 
