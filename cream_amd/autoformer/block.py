@@ -269,105 +269,165 @@ def supported(blk, x):
             and blk.sample_out_dim == blk.sample_embed_dim)
 
 
-class BlockFunction(torch.autograd.Function):
-    """x (B, N, E) fp32 -> x2 (B, N, E) fp32.  dp1 / dp2: per-sample drop-path scales (B,) or None."""
+def _tables(at):
+    return (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
+            at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
+
+
+def _block_forward(blk, x2d, pend, dp1, B, N):
+    """One block up to (not including) its last residual add.
+    x2d   (M, E) fp32 residual stream entering the block — or, with pend = (f_prev, s_prev), the
+          stream BEFORE the previous block's last residual add: that add rides on this block's
+          first LayerNorm pass (x = x2d + s_prev * f_prev).
+    -> (x1, f, saved): the block's output is x1 + s2 * f, left pending for the next consumer."""
+    M, E = x2d.shape
+    at = blk.attn
+    H = at.sample_num_heads
+    Q = at.sample_qk_embed_dim
+    F_ = blk.sample_ffn_embed_dim_this_layer
+    mr = at.max_relative_position
+    mir = MIRROR.get
+    ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
+
+    if pend is None:
+        x = x2d
+        a, mean1, rstd1 = ln_fwd(x, ln1.weight[:E], ln1.bias[:E], ln1.eps)
+    else:
+        x, a, mean1, rstd1 = add_ln_fwd(x2d, pend[0], pend[1], N, ln1.weight[:E], ln1.bias[:E], ln1.eps)
+    # qkv rows regrouped [q | k | v] from the interleaved super weight (qkv_super.py:72-77);
+    # bias is the plain prefix (qkv_super.py:80-83)
+    wqkv = mir(at.qkv.weight)[:3 * Q, :E].view(Q, 3, E).transpose(0, 1).reshape(3 * Q, E)
+    qkv = torch.addmm(mir(at.qkv.bias)[:3 * Q], a, wqkv.t())
+    tabs = tuple(t.detach() for t in _tables(at))
+    o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
+    p = torch.addmm(mir(at.proj.bias)[:E], o.view(M, Q), mir(at.proj.weight)[:E, :Q].t())
+    x1, c, mean2, rstd2 = add_ln_fwd(x, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
+    h = torch.addmm(mir(blk.fc1.bias)[:F_], c, mir(blk.fc1.weight)[:F_, :E].t())
+    g = gelu_fwd(h)
+    f = torch.addmm(mir(blk.fc2.bias)[:E], g, mir(blk.fc2.weight)[:E, :F_].t())
+    dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
+    return x1, f, dims, (x, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
+
+
+def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
+    """Backward of one block.  dx2 (M, E) fp32: gradient of the block's output stream;
+    df (M, E) bf16 = s2 * dx2: gradient of the fc2 output, pb2 its per-slab column sums as
+    (tensor, nparts, pstride, offset) — both produced by whoever consumed this block's output.
+    want_prev: the block's input was itself a pending sum x_prev1 + s_prev * f_prev (the previous
+    block of the stack): then the last pass also emits df_prev = bf16(prev_scale * dx) and its
+    column sums, i.e. the previous block's (df, pb2).   -> (dx, df_prev, pb2_prev)"""
+    at = blk.attn
+    B, N, E, H, Q, F_, mr, scale = dims
+    M = B * N
+    x, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g = saved
+    mir = MIRROR.get
+    ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
+
+    jobs = GradJobs()
+    # ---- MLP branch -----------------------------------------------------------------------
+    pw2 = wgrad_parts(df, g)
+    jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
+    jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
+    dg = df @ mir(blk.fc2.weight)[:E, :F_]
+    dh, pb1 = gelu_bwd_colsum(dg, h)
+    pw1 = wgrad_parts(dh, c)
+    jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
+    jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
+    dc = dh @ mir(blk.fc1.weight)[:F_, :E]
+    # dx1 = dx2 + dLN2(dc); dp = s1 * dx1 is the gradient of the proj output, and its column sums
+    # (proj bias) come out of the same pass
+    dx1, dp, pl2 = ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
+    P = pl2.shape[0]
+    jobs.add(ln2.weight, pl2, P, 3 * E, 1, E)
+    jobs.add(ln2.bias, pl2, P, 3 * E, 1, E, src_offset=E)
+    jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
+
+    # ---- attention branch ---------------------------------------------------------------------
+    pwp = wgrad_parts(dp, o.view(M, Q))
+    jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
+    do = dp @ mir(at.proj.weight)[:E, :Q]
+    tabs_p = _tables(at)
+    dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
+                                              *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
+                                              reduce_tables=False)
+    nb = tabs_p[0].shape[0]
+    for i, t in enumerate(tabs_p):                                     # dtab (B*H, 4, 32, 64)
+        jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
+    dqkv2d = dqkv.view(M, 3 * Q)
+    pwq = wgrad_parts(dqkv2d, a)                                       # rows [q | k | v]
+    jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
+    pbq = colsum128(dqkv2d)
+    jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
+    da = dqkv2d @ wqkv
+    dx, df_prev, pl1 = ln_bwd_raw(da, x, mean1, rstd1, ln1.weight[:E], dx1, prev_scale, N, want_prev)
+    jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
+    jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
+    jobs.launch()
+
+    if _grad_ready_hooks:
+        params = [p for p in blk.parameters() if p.requires_grad]
+        for fn in _grad_ready_hooks:
+            fn(params)
+    return dx, df_prev, (pl1, P, 3 * E, 2 * E)
+
+
+class StackFunction(torch.autograd.Function):
+    """A run of supernet blocks as ONE autograd node: x (B, N, E) fp32 -> (B, N, E) fp32.
+    scales: (L, 2, B) per-sample drop-path scales of the L blocks, or None.
+    Besides saving autograd bookkeeping, keeping the blocks together lets the passes at a block
+    boundary merge: the last residual add of block i rides on the first LayerNorm of block i+1,
+    and that LayerNorm's backward emits block i's fc2-output gradient and fc2 bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, dp1, dp2, blk):
+    def forward(ctx, x, scales, blks):
         B, N, E = x.shape
         M = B * N
-        at = blk.attn
-        H = at.sample_num_heads
-        Q = at.sample_qk_embed_dim
-        F_ = blk.sample_ffn_embed_dim_this_layer
-        mr = at.max_relative_position
-        mir = MIRROR.get
-        x2d = x.contiguous().view(M, E)
-        ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
-
-        a, mean1, rstd1 = ln_fwd(x2d, ln1.weight[:E], ln1.bias[:E], ln1.eps)
-        # qkv rows regrouped [q | k | v] from the interleaved super weight (qkv_super.py:72-77);
-        # bias is the plain prefix (qkv_super.py:80-83)
-        wqkv = mir(at.qkv.weight)[:3 * Q, :E].view(Q, 3, E).transpose(0, 1).reshape(3 * Q, E)
-        qkv = torch.addmm(mir(at.qkv.bias)[:3 * Q], a, wqkv.t())
-        tabs = (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
-                at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
-        tabs = tuple(t.detach() for t in tabs)
-        o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
-        o2d = o.view(M, Q)
-        wproj = mir(at.proj.weight)[:E, :Q]
-        p = torch.addmm(mir(at.proj.bias)[:E], o2d, wproj.t())
-        x1, c, mean2, rstd2 = add_ln_fwd(x2d, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
-        w1 = mir(blk.fc1.weight)[:F_, :E]
-        h = torch.addmm(mir(blk.fc1.bias)[:F_], c, w1.t())
-        g = gelu_fwd(h)
-        w2 = mir(blk.fc2.weight)[:E, :F_]
-        f = torch.addmm(mir(blk.fc2.bias)[:E], g, w2.t())
-        x2 = residual_add(x1, f, dp2, N * E)
-
-        ctx.blk = blk
-        ctx.dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
-        ctx.dp = (dp1, dp2)
-        ctx.save_for_backward(x2d, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
-        return x2.view(B, N, E)
+        cur = x.contiguous().view(M, E)
+        pend = None
+        saved, dims = [], []
+        for i, blk in enumerate(blks):
+            dp1 = scales[i, 0] if scales is not None else None
+            dp2 = scales[i, 1] if scales is not None else None
+            x1, f, d, sv = _block_forward(blk, cur, pend, dp1, B, N)
+            saved.extend(sv)
+            dims.append(d)
+            cur, pend = x1, (f, dp2)
+        out = residual_add(cur, pend[0], pend[1], N * E)
+        ctx.blks = list(blks)
+        ctx.dims = dims
+        ctx.nsaved = len(saved) // len(blks)
+        ctx.has_scales = scales is not None
+        ctx.save_for_backward(*saved, *([scales] if scales is not None else []))
+        return out.view(B, N, E)
 
     @staticmethod
-    def backward(ctx, dx2):
-        blk = ctx.blk
-        at = blk.attn
-        B, N, E, H, Q, F_, mr, scale = ctx.dims
-        dp1, dp2 = ctx.dp
-        M = B * N
-        x2d, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g = ctx.saved_tensors
-        mir = MIRROR.get
-        ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
-        dx2 = dx2.contiguous().view(M, E)
+    def backward(ctx, dout):
+        blks = ctx.blks
+        tens = ctx.saved_tensors
+        scales = tens[-1] if ctx.has_scales else None
+        ns = ctx.nsaved
+        B, N, E = ctx.dims[0][:3]
+        dx = dout.contiguous().view(B * N, E)
+        L = len(blks)
+        # gradient of the last block's fc2 output: s2 * dout (+ its column sums)
+        df, part = scale_cast_colsum(dx, scales[L - 1, 1] if scales is not None else None, N)
+        pb2 = (part, part.shape[0], E, 0)
+        for i in range(L - 1, -1, -1):
+            dp1 = scales[i, 0] if scales is not None else None
+            prev_scale = scales[i - 1, 1] if (scales is not None and i > 0) else None
+            dx, df, pb2 = _block_backward(blks[i], ctx.dims[i], dp1, tens[i * ns:(i + 1) * ns], dx, df, pb2,
+                                          prev_scale, i > 0)
+        return dx.view(B, N, E), None, None
 
-        jobs = GradJobs()
-        # ---- MLP branch -----------------------------------------------------------------------
-        df, pb2 = scale_cast_colsum(dx2, dp2, N)                           # d(fc2 out) = s_b * dx2
-        pw2 = wgrad_parts(df, g)
-        jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
-        jobs.add(blk.fc2.bias, pb2, pb2.shape[0], E, 1, E)
-        dg = df @ mir(blk.fc2.weight)[:E, :F_]
-        dh, pb1 = gelu_bwd_colsum(dg, h)
-        pw1 = wgrad_parts(dh, c)
-        jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
-        jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
-        dc = dh @ mir(blk.fc1.weight)[:F_, :E]
-        # dx1 = dx2 + dLN2(dc); dp = s_b * dx1 is the gradient of the proj output, and its
-        # column sums (proj bias) come out of the same pass
-        dx1, dp, pl2 = ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
-        P = pl2.shape[0]
-        jobs.add(ln2.weight, pl2, P, 3 * E, 1, E)
-        jobs.add(ln2.bias, pl2, P, 3 * E, 1, E, src_offset=E)
-        jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
 
-        # ---- attention branch ---------------------------------------------------------------------
-        pwp = wgrad_parts(dp, o.view(M, Q))
-        jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
-        do = dp @ mir(at.proj.weight)[:E, :Q]
-        tabs_p = (at.rel_pos_embed_k.embeddings_table_v, at.rel_pos_embed_k.embeddings_table_h,
-                  at.rel_pos_embed_v.embeddings_table_v, at.rel_pos_embed_v.embeddings_table_h)
-        dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
-                                                  *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
-                                                  reduce_tables=False)
-        nb = tabs_p[0].shape[0]
-        for i, t in enumerate(tabs_p):                                     # dtab (B*H, 4, 32, 64)
-            jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
-        dqkv2d = dqkv.view(M, 3 * Q)
-        pwq = wgrad_parts(dqkv2d, a)                                       # rows [q | k | v]
-        jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
-        pbq = colsum128(dqkv2d)
-        jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
-        da = dqkv2d @ wqkv
-        dx, _, pl1 = ln_bwd_raw(da, x2d, mean1, rstd1, ln1.weight[:E], dx1, None, N, False)
-        jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
-        jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
-        jobs.launch()
+class BlockFunction:
+    """One block = a stack of one.  apply(x, dp1, dp2, blk); dp1 / dp2: per-sample drop-path
+    scales (B,) or None."""
 
-        if _grad_ready_hooks:
-            params = [p for p in blk.parameters() if p.requires_grad]
-            for fn in _grad_ready_hooks:
-                fn(params)
-        return dx.view(B, N, E), None, None, None
+    @staticmethod
+    def apply(x, dp1, dp2, blk):
+        scales = None
+        if dp1 is not None or dp2 is not None:
+            ones = torch.ones(x.shape[0], device=x.device, dtype=torch.float32)
+            scales = torch.stack([dp1 if dp1 is not None else ones, dp2 if dp2 is not None else ones]).unsqueeze(0)
+        return StackFunction.apply(x, scales, [blk])

@@ -263,6 +263,14 @@ class Vision_TransformerSuper(nn.Module):
         flops += self.head.get_complexity(sequence_length + 1)
         return flops
 
+    def _keep_prob(self, probs, device):
+        """(L, 1, 1) keep probabilities of the active blocks' DropPath, cached per configuration."""
+        key = (probs, str(device))
+        cache = self.__dict__.setdefault('_keep_cache', {})
+        if key not in cache:
+            cache[key] = 1.0 - torch.tensor(probs, device=device).view(-1, 1, 1)
+        return cache[key]
+
     def forward_features(self, x):
         B = x.shape[0]
         E = self.sample_embed_dim[0]
@@ -272,16 +280,19 @@ class Vision_TransformerSuper(nn.Module):
         if self.abs_pos:
             x = x + self.pos_embed[..., :E]
         x = F.dropout(x, p=self.sample_dropout, training=self.training)
-        if self.training and _bf16_autocast(x):
-            # all drop-path draws of this forward in three launches instead of 3 per block
-            keep = 1.0 - torch.tensor([getattr(b.drop_path, 'drop_prob', 0.0) or 0.0 for b in self.blocks],
-                                      device=x.device).view(-1, 1, 1)
-            scales = torch.floor(keep + torch.rand(len(self.blocks), 2, B, device=x.device)) / keep
-            for i, blk in enumerate(self.blocks):
-                if getattr(blk.drop_path, 'drop_prob', None):
-                    blk._dp = (scales[i, 0], scales[i, 1])
-        for blk in self.blocks:
-            x = blk(x)
+        active = [blk for blk in self.blocks if not blk.is_identity_layer]
+        if active and _bf16_autocast(x) and all(b.fused and _block.supported(b, x) for b in active):
+            # bf16 throughput mode: the whole run of blocks is ONE autograd node on the HIP kernels
+            scales = None
+            probs = [(getattr(b.drop_path, 'drop_prob', 0.0) or 0.0) if self.training else 0.0 for b in active]
+            if any(probs):
+                # all drop-path draws of this forward in three launches instead of 3 per block
+                keep = self._keep_prob(tuple(probs), x.device)
+                scales = torch.floor(keep + torch.rand(len(active), 2, B, device=x.device)) / keep
+            x = _block.StackFunction.apply(x, scales, active)
+        else:
+            for blk in self.blocks:
+                x = blk(x)
         if self.pre_norm:
             x = self.norm(x)
         if self.gp:

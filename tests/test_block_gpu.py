@@ -186,6 +186,42 @@ def test_fused_block_matches_module_path_and_oracle():
     assert torch.count_nonzero(res[True][1]["blocks.0.fc1.weight"][int(384 * 3.5):]) == 0
 
 
+def test_block_stack_equals_block_by_block_with_drop_path():
+    """The run of blocks as one node (boundary passes merged: residual add on the next LayerNorm,
+    fc2-output gradient out of the next LayerNorm's backward) against the same blocks applied one
+    by one with the same drop-path scales: same arithmetic per element, so bit-identical output
+    and input gradient, parameter gradients to summation-order noise."""
+    from cream_amd.autoformer import block as K
+    m = _supernet(depth=3).to(DEV)
+    cfg = dict(layer_num=3, embed_dim=[384] * 3, num_heads=[6, 5, 7], mlp_ratio=[3.5, 3.0, 4.0])
+    m.set_sample_config(cfg)
+    m.train()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B = 4
+    x0 = torch.randn(B, 197, 384, device=DEV, generator=g)
+    scales = (torch.rand(3, 2, B, device=DEV, generator=g) > 0.3).float() / 0.7
+    dout = torch.randn(B, 197, 384, device=DEV, generator=g)
+    blks = list(m.blocks)
+    res = []
+    for stacked in (True, False):
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        if stacked:
+            y = K.StackFunction.apply(x, scales, blks)
+        else:
+            y = x
+            for i, blk in enumerate(blks):
+                y = K.BlockFunction.apply(y, scales[i, 0], scales[i, 1], blk)
+        y.backward(dout)
+        res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                         if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert set(res[0][2]) == set(res[1][2]) and len(res[0][2]) >= 3 * 16
+    for k, v in res[0][2].items():
+        assert _rel(v, res[1][2][k]) < 1e-5, k
+
+
 def test_mirror_follows_optimizer_and_droppath_runs():
     from cream_amd.autoformer import block as K, engine
     m2 = engine.build_supernet("S", drop_path_rate=0.5, depth=2).to(DEV)
