@@ -12,14 +12,17 @@ echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
 timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_' -d $OUT/${TAG}_pmc_$C -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$C.err
-  echo "pmc $C exit $?"
+# counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  N=$(echo $C | cut -d' ' -f1)
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
+  echo "pmc $N exit $?"
 done
 cd $REPO
 find $OUT -name '*.csv' | head -20
 # keep the merge small: drop raw traces, keep stats + counter csv
 find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" -delete
+find $OUT -name '*.db' -delete
 du -sh $OUT

@@ -20,7 +20,7 @@ def category(k):
         return "GEMM library (hipBLASLt)"
     if "attn_rpe2d" in k:
         return "attention (csrc/attn_rpe2d.hip)"
-    if re.search(r"(ln_fwd|ln_bwd|gelu_|residual_add|scale_cast|colsum|rpe_)", k):
+    if re.search(r"(ln_fwd|ln_bwd|gelu_|residual_add|scale_cast|colsum|grad_finalize|rpe_)", k):
         return "HBM passes (csrc/block_ops.hip, rpe_index.hip)"
     if "FusedAdam" in k or "multi_tensor_apply" in k:
         return "optimizer + bf16 operand refresh (multi-tensor)"
