@@ -43,6 +43,11 @@ __device__ long long* g_attn_prof = nullptr;
 #define PROF_MARK() do {} while (0)
 #define PROF_FLUSH() do {} while (0)
 #endif
+#ifdef ATTN_PROFILE_KVLOOP           // sub-phase stamps inside one iteration of the dK/dV tile loop
+#define PROF_LOOP(t) do { if ((t) == 3) PROF_MARK(); } while (0)
+#else
+#define PROF_LOOP(t) do {} while (0)
+#endif
 
 struct FwdArgs {
     const void* q; const void* k; const void* v;    // element (b, n, h, :) at b*sb + n*sn + h*sh
@@ -285,35 +290,101 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, ROWS, COLS>& r, typ
     }
 }
 
+// The same with a GROUP of 256 threads (4 waves) owning the tile: thread `tid` (0..255) of the group
+// moves chunks tid, tid + 256, ... — every thread of the group has work (no predicate, no
+// exec-mask branch); callers pick the group wave-uniformly.
+template <typename T, int ROWS, int COLS>
+__device__ __forceinline__ void tile_load_g(TileRegs<T, ROWS, COLS>& r, const typename Tr<T>::elem* src, int64_t rs,
+                                            int row0, int nrows, int col0, int tid) {
+    using R = TileRegs<T, ROWS, COLS>;
+    static_assert(R::CH % 256 == 0, "tile must split evenly over a 256-thread group");
+#pragma unroll
+    for (int i = 0; i < R::NI; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / R::CPR, cc = c - row * R::CPR;
+        const int rr = min(row0 + row, nrows - 1);
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (int64_t)rr * rs + col0 + cc * R::V);
+        r.v[i] = row0 + row < nrows ? v : u32x4v{0, 0, 0, 0};
+    }
+}
+
+template <typename T, int ROWS, int COLS, bool RM, bool TR>
+__device__ __forceinline__ void tile_store_g(const TileRegs<T, ROWS, COLS>& r, typename Tr<T>::elem* dst_rm, int prm,
+                                             typename Tr<T>::elem* dst_t, int pt, int tid) {
+    using R = TileRegs<T, ROWS, COLS>;
+    using E = typename Tr<T>::elem;
+#pragma unroll
+    for (int i = 0; i < R::NI; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / R::CPR, cc = c - row * R::CPR;
+        union { u32x4v v; E e[R::V]; } u;
+        u.v = r.v[i];
+        if constexpr (RM) {
+            if constexpr (sizeof(E) == 2) {
+                E* d = dst_rm + row * prm + cc * R::V;
+                if ((prm * 2) % 16 == 0) *reinterpret_cast<u32x4v*>(d) = u.v;
+                else {                                   // 8-byte aligned rows (pitch 36)
+                    *reinterpret_cast<u32x2v*>(d) = u32x2v{u.v[0], u.v[1]};
+                    *reinterpret_cast<u32x2v*>(d + 4) = u32x2v{u.v[2], u.v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < R::V; ++e) dst_rm[row * prm + cc * R::V + e] = u.e[e];
+            }
+        }
+        if constexpr (TR) {
+#pragma unroll
+            for (int e = 0; e < R::V; ++e) dst_t[(cc * R::V + e) * pt + row] = u.e[e];
+        }
+    }
+}
+
 // pitches of staged tiles: row-major [32][RMP(cols)], transposed / bucket-row tiles [rows][TPT]
 template <typename T> __host__ __device__ constexpr int rm_pitch(int cols) { return sizeof(typename Tr<T>::elem) == 2 ? cols + 8 : cols + 1; }
 template <typename T> __host__ __device__ constexpr int t_pitch() { return sizeof(typename Tr<T>::elem) == 2 ? 36 : 33; }
 
-// workgroup-cooperative: tabT[d][u] = (u < 32 ? tv[u][d] : th[u-32][d]), zero for u >= nb
-template <typename T>
-__device__ __forceinline__ void fill_tables_T(typename Tr<T>::elem* tabT, const float* tv, const float* th,
-                                              int ldt, int nb) {
-    constexpr int tp = table_pitch<T>();
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {          // float4 = 4 d-values of one bucket
-        const int d4 = (i & 15) * 4, u = i >> 4, uu = u & 31;
-        const float* t = u < 32 ? tv : th;
-        const f32x4v x = uu < nb ? *reinterpret_cast<const f32x4v*>(t + (int64_t)uu * ldt + d4) : f32x4v{0, 0, 0, 0};
+// workgroup-cooperative table staging.  Two phases so that ALL global loads of a workgroup's
+// prologue are in flight together (a load -> convert -> store loop pays one L2/HBM round trip per
+// iteration: 6-9 dependent round trips were a quarter of the forward kernel):
+//   tab_load  : this thread's float4 pieces (4 d-values of one bucket) of a (v, h) table pair
+//   tab_store_T: tabT[d][u] = (u < 32 ? tv[u][d] : th[u-32][d]), zero for u >= nb   (transposed)
+//   tab_store_R: tabR[u][d] operand rows, rows 0..31 from tv, 32..63 from th
+constexpr int TAB_IT = 4;                        // 64 buckets x 16 pieces = 1024 <= 4 x 256 threads
+struct TabRegs { f32x4v v[TAB_IT]; };
+
+__device__ __forceinline__ void tab_load(TabRegs& r, const float* tv, const float* th, int ldt, int nb) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tabT[(d4 + e) * tp + u] = Tr<T>::from_f(x[e]);
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = threadIdx.x + it * blockDim.x;
+        const int d4 = (i & 15) * 4, u = (i >> 4) & 63, uu = u & 31;
+        const float* t = u < 32 ? tv : th;
+        r.v[it] = (i < 1024 && uu < nb) ? *reinterpret_cast<const f32x4v*>(t + (int64_t)uu * ldt + d4) : f32x4v{0, 0, 0, 0};
     }
 }
-
-// workgroup-cooperative (bf16 mode): tabR[u][d] operand rows, rows 0..31 from tv, 32..63 from th
 template <typename T>
-__device__ __forceinline__ void fill_tables_R(typename Tr<T>::elem* tabR, const float* tv, const float* th,
-                                              int ldt, int nb) {
+__device__ __forceinline__ void tab_store_T(const TabRegs& r, typename Tr<T>::elem* tabT) {
     constexpr int tp = table_pitch<T>();
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-        const int d4 = (i & 15) * 4, u = i >> 4, uu = u & 31;
-        const float* t = u < 32 ? tv : th;
-        const f32x4v x = uu < nb ? *reinterpret_cast<const f32x4v*>(t + (int64_t)uu * ldt + d4) : f32x4v{0, 0, 0, 0};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tabR[u * tp + d4 + e] = Tr<T>::from_f(x[e]);
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = threadIdx.x + it * blockDim.x;
+        if (i < 1024) {
+            const int d4 = (i & 15) * 4, u = i >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tabT[(d4 + e) * tp + u] = Tr<T>::from_f(r.v[it][e]);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tab_store_R(const TabRegs& r, typename Tr<T>::elem* tabR) {
+    constexpr int tp = table_pitch<T>();
+#pragma unroll
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = threadIdx.x + it * blockDim.x;
+        if (i < 1024) {
+            const int d4 = (i & 15) * 4, u = i >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tabR[u * tp + d4 + e] = Tr<T>::from_f(r.v[it][e]);
+        }
     }
 }
 
@@ -442,18 +513,39 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
     F qb[S64];
     load_row<T>(qb, qp + (int64_t)min(qi, N - 1) * a.sn, g);
-    TileRegs<T, 32, 64> st;
-    tile_load<T, 32, 64>(st, kpg, a.sn, 0, N);
+    // K tiles 0..nt-1 and then V tiles 0..nt-1 form ONE stream of 2*nt staged tiles: tile u is
+    // loaded into register set u % PF a full PF tile-iterations before it is written to LDS buffer
+    // u & 1 (one iteration of ~1.3k cycles is shorter than an HBM round trip under load: with
+    // a single tile in flight every iteration ended in a wait for memory)
+    constexpr int PF = sizeof(E) == 2 ? 3 : 1;      // fp32 tiles are twice the registers: one in flight
+    TileRegs<T, 32, 64> ring[PF];
+    auto issue = [&](int u) {
+        if (u < nt) tile_load<T, 32, 64>(ring[u % PF], kpg, a.sn, u * 32, N);
+        else if (u < 2 * nt) tile_load<T, 32, 64>(ring[u % PF], vpg, a.sn, (u - nt) * 32, N);
+    };
+    auto commit = [&](int u) {
+        E* dst = (u & 1) ? buf1 : buf0;
+        if (u < nt) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
+        else if (u < 2 * nt) tile_store<T, 32, 64, false, true>(ring[u % PF], nullptr, 0, dst, vp);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) issue(u);
 
     // ---- workgroup prologue: tables, key slot masks, first K tile ---------------------------
-    fill_tables_T<T>(tvt, a.tvv, a.tvh, a.ldt, a.nb);
-    if constexpr (tables_in_lds<T>()) fill_tables_R<T>(tkr, a.tkv, a.tkh, a.ldt, a.nb);
+    {
+        TabRegs rv, rk;
+        tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
+        if constexpr (tables_in_lds<T>()) tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
+        tab_store_T<T>(rv, tvt);
+        if constexpr (tables_in_lds<T>()) tab_store_R<T>(rk, tkr);
+    }
     for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
     if constexpr (FAST) {
         __syncthreads();
         fill_onehot(ohr, oht, masks, NP);
     }
-    tile_store<T, 32, 64, true, false>(st, buf0, kp, nullptr, 0);
+    commit(0);
+    issue(PF);
     __syncthreads();
     PROF_MARK();
 
@@ -476,8 +568,6 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
         s[t] = f32x16{};
         if (t < nt) {
             const E* kb = (t & 1) ? buf1 : buf0;
-            if (t + 1 < nt) tile_load<T, 32, 64>(st, kpg, a.sn, (t + 1) * 32, N);
-            else tile_load<T, 32, 64>(st, vpg, a.sn, 0, N);                // first V tile rides along
             if (active) {
 #pragma unroll
                 for (int ks = 0; ks < S64; ++ks)
@@ -492,14 +582,11 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
                     for (int ks = 0; ks < S32; ++ks) s[t] = TT::mma(TT::onehot_row(km, ks, g), qe[ks], s[t]);
                 }
             }
-            if (t + 1 < nt) {
-                tile_store<T, 32, 64, true, false>(st, (t & 1) ? buf0 : buf1, kp, nullptr, 0);
-                __syncthreads();
-            }
+            commit(t + 1);                             // the last iteration commits V^T tile 0
+            __syncthreads();
+            issue(t + 1 + PF);
         }
     }
-    __syncthreads();                                   // everyone is done with the K tiles
-    tile_store<T, 32, 64, false, true>(st, nullptr, 0, buf0, vp);          // V^T tile 0
     PROF_MARK();
 
     // ---- softmax over keys (in-lane + one exchange with the partner lane) ---------------
@@ -539,7 +626,6 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     const float inv_l = 1.f / l;
     if (active && qok && g == 0)
         a.lse[((int64_t)b * a.H + h) * N + qi] = (msc + log2f(l)) * (1.f / LOG2E);
-    __syncthreads();                                   // V^T tile 0 visible
     PROF_MARK();
 
     // ---- [O | slot sums]^T = [V | one-hot]^T . P^T   (V^T streamed) -------------------------
@@ -548,8 +634,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (t < nt) {
-            const E* vb = (t & 1) ? buf1 : buf0;
-            if (t + 1 < nt) tile_load<T, 32, 64>(st, vpg, a.sn, (t + 1) * 32, N);
+            const E* vb = ((nt + t) & 1) ? buf1 : buf0;
             if (active) {
 #pragma unroll
                 for (int st2 = 0; st2 < S32; ++st2) {
@@ -561,8 +646,9 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
                 }
             }
             if (t + 1 < nt) {
-                tile_store<T, 32, 64, false, true>(st, nullptr, 0, (t & 1) ? buf0 : buf1, vp);
+                commit(nt + t + 1);
                 __syncthreads();
+                issue(nt + t + 1 + PF);
             }
         }
     if (!active) return;
@@ -660,7 +746,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     E* tvr = tkr + tabr_rows<T>(2) * tp;
     uint32_t* masks = reinterpret_cast<uint32_t*>(tkr + tabr_rows<T>(4) * tp);
     float* scratch = reinterpret_cast<float*>(masks + NP);
-    short* ohr = reinterpret_cast<short*>(scratch + (blockDim.x >> 6) * 32 * LP);   // fast path: one-hot operands
+    short* ohr = reinterpret_cast<short*>(scratch + nt * 32 * LP);   // fast path: one-hot operands (scratch: one slab per query tile)
     short* oht = ohr + NP * OHP;
     const int otp = oht_pitch(NP);
 
@@ -685,19 +771,27 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
     F qb[S64], dob[S64];
     float delta = 0.f;
-    TileRegs<T, 32, 64> sk, sv;
+    const int grp = wave >> 2, gt = threadIdx.x & 255;
+    TileRegs<T, 32, 64> sk;
     {
         F ob[S64];
         load_row<T>(qb, qp + (int64_t)qcl * a.sn, g);
         load_row<T>(dob, dop + (int64_t)qcl * orow, g);
         load_row<T>(ob, outp + (int64_t)qcl * orow, g);
-        tile_load<T, 32, 64>(sk, kpg, a.sn, 0, N);
-        tile_load<T, 32, 64>(sv, vpg, a.sn, 0, N);
+        // the workgroup always has 8 waves: waves 0-3 stage the K tiles (rows + transpose), waves
+        // 4-7 the V tiles — one chunk per thread, wave-uniform roles (waves >= nt only stage)
+        if (grp == 0) tile_load_g<T, 32, 64>(sk, kpg, a.sn, 0, N, 0, gt);
+        else tile_load_g<T, 32, 64>(sk, vpg, a.sn, 0, N, 0, gt);
 
-        fill_tables_T<T>(tkt, a.tkv, a.tkh, a.ldt, a.nb);
-        if constexpr (tables_in_lds<T>()) {
-            fill_tables_R<T>(tkr, a.tkv, a.tkh, a.ldt, a.nb);
-            fill_tables_R<T>(tvr, a.tvv, a.tvh, a.ldt, a.nb);
+        {
+            TabRegs rk, rv;
+            tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
+            if constexpr (tables_in_lds<T>()) tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
+            tab_store_T<T>(rk, tkt);
+            if constexpr (tables_in_lds<T>()) {
+                tab_store_R<T>(rk, tkr);
+                tab_store_R<T>(rv, tvr);
+            }
         }
         for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
         if constexpr (FAST) {
@@ -718,8 +812,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
         delta += __shfl_xor(delta, 32);
     }
     if (active && g == 0) a.delta[bh * NP + qi] = delta;
-    tile_store<T, 32, 64, true, true>(sk, kbuf(0), rp, ktbuf(0), ktp);
-    tile_store<T, 32, 64, true, false>(sv, vbuf(0), rp, nullptr, 0);
+    if (grp == 0) tile_store_g<T, 32, 64, true, true>(sk, kbuf(0), rp, ktbuf(0), ktp, gt);
+    else tile_store_g<T, 32, 64, true, false>(sk, vbuf(0), rp, nullptr, 0, gt);
     __syncthreads();                                  // tables, masks, first tiles in place
     PROF_MARK();
 
@@ -749,8 +843,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            tile_load<T, 32, 64>(sk, kpg, a.sn, (t + 1) * 32, N);
-            tile_load<T, 32, 64>(sv, vpg, a.sn, (t + 1) * 32, N);
+            if (grp == 0) tile_load_g<T, 32, 64>(sk, kpg, a.sn, (t + 1) * 32, N, 0, gt);
+            else tile_load_g<T, 32, 64>(sk, vpg, a.sn, (t + 1) * 32, N, 0, gt);
         }
         if (active) {
             const E* kb = kbuf(cur) + c32 * rp;
@@ -789,8 +883,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
             }
         }
         if (t + 1 < nt) {
-            tile_store<T, 32, 64, true, true>(sk, kbuf(cur ^ 1), rp, ktbuf(cur ^ 1), ktp);
-            tile_store<T, 32, 64, true, false>(sv, vbuf(cur ^ 1), rp, nullptr, 0);
+            if (grp == 0) tile_store_g<T, 32, 64, true, true>(sk, kbuf(cur ^ 1), rp, ktbuf(cur ^ 1), ktp, gt);
+            else tile_store_g<T, 32, 64, true, false>(sk, vbuf(cur ^ 1), rp, nullptr, 0, gt);
             __syncthreads();
         }
     }
@@ -866,29 +960,57 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     load_row<T>(kb, kpg + (int64_t)min(kj, N - 1) * a.sn, g);
     load_row<T>(vb, vpg + (int64_t)min(kj, N - 1) * a.sn, g);
 
-    TileRegs<T, 32, 64> sq, sd;
-    TileRegs<T, 32, 32> sqe, sde;
-    TileRegs<T, 64, 32> sdl, ssp;
+    // staging is split over two groups of four waves (the workgroup always has 8 waves; waves
+    // >= nt only stage): group 0 moves the Q tile (+ its transpose), the qe | de rows and the S'^T
+    // tile, group 1 the dO tile (+ transpose) and the dL'^T tile — wave-uniform roles, every
+    // thread of a group has exactly one chunk per tile
+    const int grp = wave >> 2, gt = threadIdx.x & 255;
+    TileRegs<T, 32, 64> sq;                                  // group 0: Q rows      group 1: dO rows
+    TileRegs<T, 64, 32> sdl;                                 // group 0: S'^T tile   group 1: dL'^T tile
+    constexpr int EH = TileRegs<T, 32, 32>::CH;              // chunks of one 32 x 32 extension tile
+    TileRegs<T, 32, 32> sqe;                                 // group 0 only: qe (first half of the group) | de
     auto load_set = [&](int t) {
-        tile_load<T, 32, 64>(sq, qp, a.sn, t * 32, N);
-        tile_load<T, 32, 64>(sd, dop, orow, t * 32, N);
-        tile_load<T, 32, 32>(sqe, qep, 32, t * 32, NP);
-        tile_load<T, 32, 32>(sde, dep, 32, t * 32, NP);
-        tile_load<T, 64, 32>(sdl, dltp, NP, 0, 64, t * 32);
-        tile_load<T, 64, 32>(ssp, spp, NP, 0, 64, t * 32);
+        if (grp == 0) {
+            tile_load_g<T, 32, 64>(sq, qp, a.sn, t * 32, N, 0, gt);
+            tile_load_g<T, 64, 32>(sdl, spp, NP, 0, 64, t * 32, gt);
+            if constexpr (EH == 128) {                       // bf16: 128 chunks each -> half a group per tile
+                const int c = gt & 127, row = c >> 2, cc = c & 3;
+                const E* src = (gt < 128 ? qep : dep) + (int64_t)(t * 32 + row) * 32 + cc * 8;
+                sqe.v[0] = *reinterpret_cast<const u32x4v*>(src);
+            } else {                                         // fp32: 256 chunks each -> two per thread
+                tile_load_g<T, 32, 32>(sqe, qep, 32, t * 32, NP, 0, gt);
+            }
+        } else {
+            tile_load_g<T, 32, 64>(sq, dop, orow, t * 32, N, 0, gt);
+            tile_load_g<T, 64, 32>(sdl, dltp, NP, 0, 64, t * 32, gt);
+        }
+    };
+    TileRegs<T, 32, 32> sde;                                 // fp32 only: de rows (group 0)
+    auto load_set_extra = [&](int t) {
+        if constexpr (EH != 128) { if (grp == 0) tile_load_g<T, 32, 32>(sde, dep, 32, t * 32, NP, 0, gt); }
     };
     auto store_set = [&](int i) {
-        tile_store<T, 32, 64, true, true>(sq, qbuf(i), rp, qtbuf(i), tpt);
-        tile_store<T, 32, 64, true, true>(sd, dbuf(i), rp, dtbuf(i), tpt);
-        tile_store<T, 32, 32, true, false>(sqe, qebuf(i), ep, nullptr, 0);
-        tile_store<T, 32, 32, true, false>(sde, debuf(i), ep, nullptr, 0);
-        tile_store<T, 64, 32, true, false>(sdl, dlbuf(i), tpt, nullptr, 0);
-        tile_store<T, 64, 32, true, false>(ssp, spbuf(i), tpt, nullptr, 0);
+        if (grp == 0) {
+            tile_store_g<T, 32, 64, true, true>(sq, qbuf(i), rp, qtbuf(i), tpt, gt);
+            tile_store_g<T, 64, 32, true, false>(sdl, spbuf(i), tpt, nullptr, 0, gt);
+            if constexpr (EH == 128) {
+                const int c = gt & 127, row = c >> 2, cc = c & 3;
+                E* d = (gt < 128 ? qebuf(i) : debuf(i)) + row * ep + cc * 8;
+                *reinterpret_cast<u32x4v*>(d) = sqe.v[0];
+            } else {
+                tile_store_g<T, 32, 32, true, false>(sqe, qebuf(i), ep, nullptr, 0, gt);
+                tile_store_g<T, 32, 32, true, false>(sde, debuf(i), ep, nullptr, 0, gt);
+            }
+        } else {
+            tile_store_g<T, 32, 64, true, true>(sq, dbuf(i), rp, dtbuf(i), tpt, gt);
+            tile_store_g<T, 64, 32, true, false>(sdl, dlbuf(i), tpt, nullptr, 0, gt);
+        }
     };
     load_set(0);
+    load_set_extra(0);
     for (int i = threadIdx.x; i < NP; i += blockDim.x) {
         lse2[i] = i < N ? a.lse[bh * N + i] * LOG2E : INFINITY;           // P = 0 for padding queries
-        dlt_s[i] = i < N ? a.delta[bh * NP + i] : 0.f;
+        dlt_s[i] = i < N ? a.delta[bh * NP + i] * a.scale : 0.f;
     }
     {
         const uint32_t km = key_mask(kj, G);
@@ -908,7 +1030,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) load_set(t + 1);
+        PROF_LOOP(t);
+        if (t + 1 < nt) { load_set(t + 1); load_set_extra(t + 1); }
         if (active) {
             const E* qrow = qbuf(cur) + c32 * rp;
             const E* drow = dbuf(cur) + c32 * rp;
@@ -925,14 +1048,24 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                 sacc = TT::mma(TT::load(qerow + ks * KI + g * EPL), oh[ks], sacc);
                 pacc = TT::mma(TT::load(derow + ks * KI + g * EPL), oh[ks], pacc);
             }
-            // lane = key, registers = queries t*32 + acc_row(r, g); padding queries have lse2 = +inf
+            PROF_LOOP(t);
+            // lane = key, registers = queries t*32 + acc_row(r, g) — four runs of four consecutive
+            // queries, so lse / delta come as 16-byte LDS reads; padding queries have lse2 = +inf
+            // (P = 0).  Padding KEYS (lanes kj >= N) need no masking: a key is a COLUMN of every
+            // product below, its values never mix into other lanes, and its rows are not stored.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = t * 32 + acc_row(r, g);
-                const float p = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -lse2[qq])) : 0.f;
-                sacc[r] = p;
-                pacc[r] = p * (pacc[r] - dlt_s[qq]) * a.scale;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4v l4 = *reinterpret_cast<const f32x4v*>(lse2 + t * 32 + 8 * r4 + 4 * g);
+                const f32x4v d4 = *reinterpret_cast<const f32x4v*>(dlt_s + t * 32 + 8 * r4 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * r4 + e;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -l4[e]));
+                    sacc[r] = p;
+                    pacc[r] = p * __builtin_fmaf(pacc[r], a.scale, -d4[e]);      // dlt_s holds scale * delta
+                }
             }
+            PROF_LOOP(t);
 #pragma unroll
             for (int st = 0; st < S32; ++st) {
                 const F pb = TT::from_acc(sacc, st);
@@ -944,6 +1077,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                 }
             }
         }
+        PROF_LOOP(t);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int job = jj == 0 ? job0 : job1;
@@ -956,10 +1090,13 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                     tacc[jj] = TT::mma(TT::load_perm(xT, st, g), TT::load_perm(rT, st, g), tacc[jj]);
             }
         }
+        PROF_LOOP(t);
         if (t + 1 < nt) {
             store_set(cur ^ 1);
+            PROF_LOOP(t);
             __syncthreads();
         }
+        PROF_LOOP(t);
     }
     PROF_MARK();
     if (kok) {
@@ -998,15 +1135,14 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
             return CREAM_ERR_LAUNCH;
         attr_done = true;
     }
-    const int waves = a.NP / 32 < 4 ? 4 : a.NP / 32;
-    const dim3 grid(B * a.H), block(waves * 64);
-    hipLaunchKernelGGL(kq, grid, block, bwd_q_lds_bytes<T>(a.NP, waves, FAST), st, a);
+    const dim3 grid(B * a.H);
+    hipLaunchKernelGGL(kq, grid, dim3(512), bwd_q_lds_bytes<T>(a.NP, a.NP / 32, FAST), st, a);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
 #ifdef PROBE_SKIP_KV                     // tools/probes/attn_probe.hip: keep the dQ kernel's phase stamps
     (void)kkv;
     return CREAM_OK;
 #endif
-    hipLaunchKernelGGL(kkv, grid, block, bwd_kv_lds_bytes<T>(a.NP), st, a);
+    hipLaunchKernelGGL(kkv, grid, dim3(512), bwd_kv_lds_bytes<T>(a.NP), st, a);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

@@ -77,6 +77,16 @@ int main(int argc, char** argv) {
 #ifdef PROBE_SKIP_KV
         printf("%s phases:\n", which[0]);
         for (int i = 0; i < 4; ++i) printf("  %-20s %10.0f cycles\n", nq[i], sm[i] / cnt2);
+#elif defined(ATTN_PROFILE_KVLOOP)
+        const char* nl[] = {"loads+fill+sync", "iterations 0-2", "it3: issue loads", "it3: S,dP mfma", "it3: exp/dS valu", "it3: dV,dK mfma",
+                            "it3: table jobs", "it3: store_set", "it3: barrier", "iterations 4-6", "store dk dv"};
+        double sl[11] = {0}; int c3 = 0;
+        for (int blk = 0; blk < B * H; ++blk) for (int w = 0; w < 7; ++w) {
+            long long* d = &hp[((size_t)blk * 8 + w) * 12];
+            for (int i = 0; i < 11; ++i) sl[i] += (double)(d[i + 1] - d[i]);
+            ++c3;
+        }
+        for (int i = 0; i < 11; ++i) printf("  %-20s %10.0f cycles\n", nl[i], sl[i] / c3);
 #else
         printf("%s phases:\n", which[1]);
         for (int i = 0; i < 4; ++i) printf("  %-20s %10.0f cycles\n", nkv[i], sm[i] / cnt2);
