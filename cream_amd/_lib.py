@@ -59,6 +59,17 @@ SIGNATURES = {
     "cream_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_scale_cast_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cream_grad_finalize": (_i, [_vp, _i, _vp]),
+    "cream_gemm_table_load": (_i, [_c.c_char_p]),
+    "cream_gemm_set_workspace": (_i, [_vp, _vp, _i64]),
+    "cream_gemm_plan_counts": (_i, [_vp, _vp]),
+    "cream_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "cream_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "cream_qkv_regroup": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
+    "cream_block_fwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
+    "cream_block_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cream_block_bwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
+    "cream_block_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp, _vp]),
 }
 
 MAX_GRAD_JOBS = 24
@@ -69,6 +80,23 @@ class GradJob(ctypes.Structure):
     _fields_ = [("dst", _vp), ("src", _vp), ("ld", _i64), ("pstride", _i64),
                 ("nparts", _c.c_int32), ("rows", _c.c_int32), ("cols", _c.c_int32),
                 ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("reserved", _c.c_int32)]
+
+class BlockDesc(ctypes.Structure):
+    """struct cream_block_desc of include/cream_amd.h."""
+    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "wgrad_split", "reserved")] +
+                [(n, _f) for n in ("eps1", "eps2", "attn_scale", "reserved_f")] +
+                [(n, _vp) for n in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2")] +
+                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2")] +
+                [(n, _vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
+                [("ldt", _i64)])
+
+
+class BlockGrads(ctypes.Structure):
+    """struct cream_block_grads of include/cream_amd.h."""
+    _fields_ = ([(n, _vp) for n in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2", "ln1_g", "ln1_b", "ln2_g",
+                                    "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
+                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2", "ldt")])
+
 
 _lib = None
 

@@ -45,7 +45,8 @@ def enable_gemm_selection(size='S', batch=128):
                         f'gemm_{size}_b{batch}.csv')
     if not (torch.cuda.is_available() and os.path.exists(path)):
         return False
-    tun = torch.cuda.tunable
+    _block.gemm_table_load(path)         # the native dispatcher of the fused blocks (csrc/gemm_lt.cpp)
+    tun = torch.cuda.tunable             # the GEMMs left to the framework (stem, head, module path)
     tun.enable(True)
     tun.tuning_enable(False)
     # read-only use of the committed table (8 ranks share it): whatever the library writes at

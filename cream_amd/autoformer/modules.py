@@ -37,6 +37,42 @@ def _trunc_normal_(t, std):
     return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
 
 
+class _LazySamples(dict):
+    """`module.samples` of the reference ({'weight': W[:out, :in] view, 'bias': ...}), filled on
+    first access after a `set_sample_config`: the supernet step calls set_sample_config on ~90
+    modules per step, and the fused execution never looks at these views."""
+
+    def __init__(self, fill):
+        super().__init__()
+        self._fill = fill
+        self.stale = True
+
+    def _ready(self):
+        if self.stale:
+            self.stale = False
+            self._fill()
+
+    def __getitem__(self, k):
+        self._ready()
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        self._ready()
+        return dict.__contains__(self, k)
+
+    def get(self, k, default=None):
+        self._ready()
+        return dict.get(self, k, default)
+
+    def keys(self):
+        self._ready()
+        return dict.keys(self)
+
+    def items(self):
+        self._ready()
+        return dict.items(self)
+
+
 class _SampledLinearBase(nn.Linear):
     """Shared bookkeeping of LinearSuper / qkv_super: a super (largest) weight plus the
     extents of the currently sampled sub-matrix."""
@@ -47,7 +83,7 @@ class _SampledLinearBase(nn.Linear):
         self.super_out_dim = super_out_dim
         self.sample_in_dim = None
         self.sample_out_dim = None
-        self.samples = {}
+        self.samples = _LazySamples(self._fill_samples)
         self.scale = scale
         self.profiling = False
 
@@ -60,16 +96,22 @@ class _SampledLinearBase(nn.Linear):
         return self.samples
 
     def set_sample_config(self, sample_in_dim, sample_out_dim):
-        self.sample_in_dim = sample_in_dim
-        self.sample_out_dim = sample_out_dim
-        self._sample_parameters()
+        d = self.__dict__                      # plain attributes: skip nn.Module.__setattr__ (hot: ~90 calls per step)
+        d['sample_in_dim'] = sample_in_dim
+        d['sample_out_dim'] = sample_out_dim
+        d['sample_scale'] = self.super_out_dim / sample_out_dim
+        self.samples.stale = True              # Linear_super.py:45-49 slices here; the views are built on first use
 
     def _slice_weight(self):
         raise NotImplementedError
 
+    def _fill_samples(self):
+        dict.__setitem__(self.samples, 'weight', self._slice_weight())
+        dict.__setitem__(self.samples, 'bias', self.bias[:self.sample_out_dim] if self.bias is not None else None)
+
     def _sample_parameters(self):
-        self.samples['weight'] = self._slice_weight()
-        self.samples['bias'] = self.bias[:self.sample_out_dim] if self.bias is not None else None
+        self.samples.stale = False
+        self._fill_samples()
         self.sample_scale = self.super_out_dim / self.sample_out_dim
         return self.samples
 
@@ -131,7 +173,7 @@ class LayerNormSuper(nn.LayerNorm):
         super().__init__(super_embed_dim)
         self.super_embed_dim = super_embed_dim
         self.sample_embed_dim = None
-        self.samples = {}
+        self.samples = _LazySamples(self._fill_samples)
         self.profiling = False
 
     def profile(self, mode=True):
@@ -142,14 +184,18 @@ class LayerNormSuper(nn.LayerNorm):
             return self._sample_parameters()
         return self.samples
 
+    def _fill_samples(self):
+        dict.__setitem__(self.samples, 'weight', self.weight[:self.sample_embed_dim])
+        dict.__setitem__(self.samples, 'bias', self.bias[:self.sample_embed_dim])
+
     def _sample_parameters(self):
-        self.samples['weight'] = self.weight[:self.sample_embed_dim]
-        self.samples['bias'] = self.bias[:self.sample_embed_dim]
+        self.samples.stale = False
+        self._fill_samples()
         return self.samples
 
     def set_sample_config(self, sample_embed_dim):
-        self.sample_embed_dim = sample_embed_dim
-        self._sample_parameters()
+        self.__dict__['sample_embed_dim'] = sample_embed_dim
+        self.samples.stale = True
 
     def forward(self, x):
         self.sample_parameters()
@@ -243,15 +289,20 @@ class RelativePosition2D_super(nn.Module):
         self.embeddings_table_h = nn.Parameter(torch.randn(max_relative_position * 2 + 2, num_units))
         _trunc_normal_(self.embeddings_table_v, std=.02)
         _trunc_normal_(self.embeddings_table_h, std=.02)
-        self.sample_head_dim = None
-        self.sample_embeddings_table_h = None
-        self.sample_embeddings_table_v = None
+        self.sample_head_dim = None          # (the sampled tables are properties below)
         self._index_cache = {}
 
     def set_sample_config(self, sample_head_dim):
-        self.sample_head_dim = sample_head_dim
-        self.sample_embeddings_table_h = self.embeddings_table_h[:, :sample_head_dim]
-        self.sample_embeddings_table_v = self.embeddings_table_v[:, :sample_head_dim]
+        self.__dict__['sample_head_dim'] = sample_head_dim
+
+    # multihead_super.py:32-35 slices the tables in set_sample_config; here the views are properties
+    @property
+    def sample_embeddings_table_h(self):
+        return None if self.sample_head_dim is None else self.embeddings_table_h[:, :self.sample_head_dim]
+
+    @property
+    def sample_embeddings_table_v(self):
+        return None if self.sample_head_dim is None else self.embeddings_table_v[:, :self.sample_head_dim]
 
     def calc_sampled_param_num(self):
         return self.sample_embeddings_table_h.numel() + self.sample_embeddings_table_v.numel()
@@ -320,14 +371,15 @@ class AttentionSuper(nn.Module):
         self.attention_impl = 'auto'
 
     def set_sample_config(self, sample_q_embed_dim=None, sample_num_heads=None, sample_in_embed_dim=None):
-        self.sample_in_embed_dim = sample_in_embed_dim
-        self.sample_num_heads = sample_num_heads
+        d = self.__dict__                      # plain attributes (see _SampledLinearBase.set_sample_config)
+        d['sample_in_embed_dim'] = sample_in_embed_dim
+        d['sample_num_heads'] = sample_num_heads
         if not self.change_qkv:
-            self.sample_qk_embed_dim = self.super_embed_dim
-            self.sample_scale = (sample_in_embed_dim // self.sample_num_heads) ** -0.5
+            d['sample_qk_embed_dim'] = self.super_embed_dim
+            d['sample_scale'] = (sample_in_embed_dim // sample_num_heads) ** -0.5
         else:
-            self.sample_qk_embed_dim = sample_q_embed_dim
-            self.sample_scale = (self.sample_qk_embed_dim // self.sample_num_heads) ** -0.5
+            d['sample_qk_embed_dim'] = sample_q_embed_dim
+            d['sample_scale'] = (sample_q_embed_dim // sample_num_heads) ** -0.5
         self.qkv.set_sample_config(sample_in_dim=sample_in_embed_dim, sample_out_dim=3 * self.sample_qk_embed_dim)
         self.proj.set_sample_config(sample_in_dim=self.sample_qk_embed_dim, sample_out_dim=sample_in_embed_dim)
         if self.relative_position:

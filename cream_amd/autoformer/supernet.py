@@ -86,17 +86,18 @@ class TransformerEncoderLayer(nn.Module):
     def set_sample_config(self, is_identity_layer, sample_embed_dim=None, sample_mlp_ratio=None,
                           sample_num_heads=None, sample_dropout=None, sample_attn_dropout=None,
                           sample_out_dim=None):
+        d = self.__dict__                      # plain attributes: skip nn.Module.__setattr__ (hot path of every step)
         if is_identity_layer:
-            self.is_identity_layer = True
+            d['is_identity_layer'] = True
             return
-        self.is_identity_layer = False
-        self.sample_embed_dim = sample_embed_dim
-        self.sample_out_dim = sample_out_dim
-        self.sample_mlp_ratio = sample_mlp_ratio
-        self.sample_ffn_embed_dim_this_layer = int(sample_embed_dim * sample_mlp_ratio)
-        self.sample_num_heads_this_layer = sample_num_heads
-        self.sample_dropout = sample_dropout
-        self.sample_attn_dropout = sample_attn_dropout
+        d['is_identity_layer'] = False
+        d['sample_embed_dim'] = sample_embed_dim
+        d['sample_out_dim'] = sample_out_dim
+        d['sample_mlp_ratio'] = sample_mlp_ratio
+        d['sample_ffn_embed_dim_this_layer'] = int(sample_embed_dim * sample_mlp_ratio)
+        d['sample_num_heads_this_layer'] = sample_num_heads
+        d['sample_dropout'] = sample_dropout
+        d['sample_attn_dropout'] = sample_attn_dropout
         self.attn_layer_norm.set_sample_config(sample_embed_dim=sample_embed_dim)
         # head dim fixed at 64: supernet_transformer.py:243
         self.attn.set_sample_config(sample_q_embed_dim=sample_num_heads * 64, sample_num_heads=sample_num_heads,

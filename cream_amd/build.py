@@ -70,9 +70,10 @@ def build(force=False, verbose=False):
         cmd = [hipcc] + HIPCC_FLAGS + [f"-I{INCLUDE}", f"-I{CSRC}", f'-DCREAM_BUILD_TAG="{tag}"',
                                        "-x", "hip" if src.endswith(".hip") else "c++", "-c", src, "-o", obj]
         if not src.endswith(".hip"):
-            # plain host C++: no offload needed
+            # plain host C++: no offload needed (HIP / hipBLASLt host APIs only)
             cmd = [c for c in cmd if not c.startswith("--offload-arch")]
             cmd[cmd.index("-x") + 1] = "c++"
+            cmd += ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -87,7 +88,10 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("cream_amd: HIP compilation failed")
-    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"]
+    # libhipblaslt: resolved at load time against the copy already mapped by PyTorch-ROCm (same
+    # SONAME; the offline kernel selection refers to THAT library's solution indices)
+    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipblaslt",
+                                                                                     "-lpthread"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

@@ -42,11 +42,17 @@ class GradReducer:
         self.members = {b: [] for b in names}
         for n, p in self.params:
             self.members[bucket_of(n)].append((n, p))
-        # flat buffers; p.grad become views (zero-filled)
+        # flat buffers; p.grad become views (zero-filled).  All buckets are slices of ONE allocation
+        # (bucket starts 64-element aligned): zero_grad is a single memset
         self.flat = {}
+        sizes = {b: sum(p.numel() for _, p in mem) for b, mem in self.members.items()}
+        starts, total = {}, 0
+        for b in names:
+            starts[b] = total
+            total += (sizes[b] + 63) // 64 * 64
+        self.arena = torch.zeros(total, dtype=torch.float32, device=self.device)
         for b, mem in self.members.items():
-            total = sum(p.numel() for _, p in mem)
-            buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+            buf = self.arena[starts[b]:starts[b] + sizes[b]]
             off = 0
             for _, p in mem:
                 p.grad = buf[off:off + p.numel()].view_as(p)
@@ -83,9 +89,8 @@ class GradReducer:
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
-        """Zero-fill (not None, see engine.SupernetTrainer) — one memset per bucket."""
-        for buf in self.flat.values():
-            buf.zero_()
+        """Zero-fill (not None, see engine.SupernetTrainer) — one memset for all buckets."""
+        self.arena.zero_()
 
     def prepare(self, config=None):
         """Call after zero_grad and before forward.  `config` is the sampled architecture

@@ -197,6 +197,33 @@ int cream_gelu_bwd_colsum(void* dh, float* partial, const void* dg, const void* 
 int cream_scale_cast_colsum(void* out, float* partial, const float* x, const float* sample_scale,
                             int rows_per_sample, int M, int C, void* stream);
 
+/* ---- dense projections of the weight-entangled Linear layers ---------------------------------
+ * LinearSuper.forward / qkv_super.forward = F.linear(x, W[:out, :in], b[:out])
+ * (AutoFormer/model/module/Linear_super.py:38-54,71-81; qkv_super.py:45-55) and its autograd
+ * adjoints, on the GEMM library (hipBLASLt) with OFFLINE-selected kernels.  bf16 operands, fp32
+ * accumulation.  The active block of the super weight is read in place: `w` points at W[0][0],
+ * ldw = super in-features (row stride); N = active out-features, K = active in-features.
+ *   cream_linear_fwd          out(M x N) = x(M x K) . W(N x K)^T + bias(N)      (bias may be NULL)
+ *   cream_linear_dgrad        dx(M x K)  = dy(M x N) . W(N x K)
+ *   cream_linear_wgrad_parts  parts[s](N x K) = dy_s^T x_s over S equal slices of the M rows
+ *                             (split-K; the slices are added by cream_grad_finalize)
+ * All matrices other than W are contiguous.  Launches go to `stream`, which must have a workspace
+ * registered (the library's stream-K kernels need scratch; the C ABI never allocates):
+ *   cream_gemm_set_workspace(stream, ptr, bytes)   one buffer per stream that issues GEMMs
+ *   cream_gemm_table_load(csv)                     kernel-selection table (PyTorch TunableOp CSV,
+ *                                                  tools/tune_gemms.py); returns #entries loaded.
+ *                                                  Problems without an entry use the library heuristic.
+ *   cream_gemm_plan_counts(&from_table, &heuristic)  -> number of cached plans (diagnostics) */
+int cream_gemm_table_load(const char* csv_path);
+int cream_gemm_set_workspace(void* stream, void* ptr, int64_t bytes);
+int cream_gemm_plan_counts(int* from_table, int* heuristic);
+int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
+                     int64_t ldw, void* stream);
+int cream_linear_dgrad(void* dx, const void* dy, const void* w, int M, int N, int K, int64_t ldw,
+                       void* stream);
+int cream_linear_wgrad_parts(void* parts, const void* dy, const void* x, int M, int N, int K, int S,
+                             void* stream);
+
 /* Gradient finalisation for the weight-entangled parameters: every tensor of a block gets
  *     dst[map(r)*ld + c] += sum_p src[p*pstride + r*cols + c]          r < rows, c < cols
  * in ONE launch — dst is the ACTIVE SLICE W[:out, :in] of the fp32 super-weight gradient
@@ -218,6 +245,65 @@ typedef struct cream_grad_job {
 } cream_grad_job;
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
+
+/* dst (3Q x E, contiguous) <- rows of the interleaved qkv super weight regrouped [q | k | v]:
+ * dst[j*Q + i][:E] = src[3*i + j][:E]  (the row gather of qkv_super.py:72-77); E, ld % 8 == 0. */
+int cream_qkv_regroup(void* dst, const void* src, int Q, int E, int64_t ld, void* stream);
+
+/* ---- one transformer block, sequenced natively ---------------------------------------------
+ * TransformerEncoderLayer.forward (AutoFormer/model/supernet_transformer.py:251-287) and its
+ * autograd backward as ONE call per direction: the kernels are the ones declared above, enqueued
+ * on `stream` (and, in backward, the weight-gradient GEMMs + the gradient finalisation on
+ * `side_stream` behind events).  bf16 throughput mode: fp32 residual stream, bf16 GEMM operands.
+ * The caller owns all memory: one flat workspace per call (sizes/offsets from *_workspace). */
+typedef struct cream_block_desc {
+    int32_t B, N, E, H, F;        /* batch, tokens, embed dim, heads (head dim 64), mlp hidden     */
+    int32_t gh, gw, mr;           /* token grid (N = gh*gw + 1) and max_relative_position          */
+    int32_t wgrad_split;          /* split-K factor of the weight gradients, (B*N) % split == 0     */
+    int32_t reserved;
+    float eps1, eps2, attn_scale;
+    float reserved_f;
+    /* bf16 operand copies of the SUPER weights, read in place (ld = row stride in elements) */
+    const void *wqkv, *bqkv;      /* (3*Qsuper, ld_qkv) q/k/v rows interleaved; bias: plain prefix  */
+    const void *wproj, *bproj;    /* (Esuper, ld_proj)                                             */
+    const void *w1, *b1;          /* fc1 (Fsuper, ld_w1)                                           */
+    const void *w2, *b2;          /* fc2 (Esuper, ld_w2)                                           */
+    int64_t ld_qkv, ld_proj, ld_w1, ld_w2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* attn_layer_norm / ffn_layer_norm (fp32)     */
+    const float *tkv, *tkh, *tvv, *tvh;             /* rel_pos_embed_{k,v}.embeddings_table_{v,h}  */
+    int64_t ldt;
+} cream_block_desc;
+
+/* fp32 gradients of the block's parameters (super shapes; accumulated into, never overwritten) */
+typedef struct cream_block_grads {
+    float *wqkv, *bqkv, *wproj, *bproj, *w1, *b1, *w2, *b2;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *tkv, *tkh, *tvv, *tvh;
+    int64_t ld_qkv, ld_proj, ld_w1, ld_w2, ldt;
+} cream_block_grads;
+
+/* Bytes of the forward workspace (kept by the caller for the backward); *off_x = block input after
+ * a pending residual add (valid only if pend_f was given), *off_x1 / *off_f = the two tensors whose
+ * sum x1 + s2*f is the block output — left PENDING for the next consumer (the next block's first
+ * LayerNorm pass, or cream_residual_add). */
+int64_t cream_block_fwd_workspace(const cream_block_desc* d, int64_t* off_x, int64_t* off_x1, int64_t* off_f);
+/* x_in (M x E) fp32; pend_f (bf16, M x E) / pend_scale (B, may be NULL): pending branch of the
+ * previous block, added on the fly (NULL: none); dp1: per-sample drop-path scale of the attention
+ * branch (B) or NULL. */
+int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, const void* pend_f,
+                    const float* pend_scale, const float* dp1, void* stream);
+
+/* Backward.  fws: the forward workspace; x: the block input (x_in, or fws + off_x if the forward
+ * had a pending branch); dx2 (fp32) gradient of the block output; df (bf16) = s2 * dx2 = gradient
+ * of the fc2 output and pb2 its column-sum partials (pb2_parts parts, pb2_pstride floats apart) —
+ * both produced by whoever consumed the block's output.  Outputs in ws: dx (fp32, *off_dx) and,
+ * if want_prev, df_prev = bf16(prev_scale * dx) (*off_df_prev) with its column sums as plane 2 of
+ * the (cream_ln_partials() x 3 x E) partials at *off_pl1 — i.e. (df, pb2) of the previous block.
+ * Parameter gradients are complete when `side_stream` has drained. */
+int64_t cream_block_bwd_workspace(const cream_block_desc* d, int64_t* off_dx, int64_t* off_df_prev, int64_t* off_pl1);
+int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const void* fws, const float* x,
+                    void* ws, const float* dx2, const void* df, const float* pb2, int pb2_parts,
+                    int64_t pb2_pstride, const float* dp1, const float* prev_scale, int want_prev,
+                    void* stream, void* side_stream);
 
 #ifdef __cplusplus
 }  /* extern "C" */

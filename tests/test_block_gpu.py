@@ -98,6 +98,38 @@ def test_passes_with_bias_gradient_match_torch_fp32(M, C):
     assert _rel(K.colsum128(h).sum(0), h.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,ldw", [(197 * 8, 1152, 384, 384), (197 * 8, 1344, 384, 448), (25216, 384, 1344, 1792),
+                                        (197 * 8, 320, 320, 448)])
+def test_native_linear_matches_torch_fp32(M, N, K, ldw):
+    """cream_linear_fwd / dgrad / wgrad_parts (hipBLASLt through the C ABI, active block of the super
+    weight read in place) against plain PyTorch fp32 of the same products; with and without the
+    offline kernel-selection table."""
+    import os
+    from cream_amd.autoformer import block as K_
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    wsup = (torch.randn(N + 64, ldw, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N + 64, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    W = wsup[:N, :K].float()
+    for load in (False, True):
+        if load:
+            K_.gemm_table_load(os.path.join(ROOT, "cream_amd", "tuning", "gemm_S_b128.csv"))
+        out = K_.linear_fwd(x, wsup, bias, N, K)
+        assert _rel(out.float(), x.float() @ W.t() + bias[:N].float()) < 1e-2
+        dx = K_.linear_dgrad(dy, wsup, N, K)
+        assert _rel(dx.float(), dy.float() @ W) < 1e-2
+        parts = K_.linear_wgrad_parts(dy, x)
+        assert parts.shape[1:] == (N, K)
+        assert _rel(parts.float().sum(0), dy.float().t() @ x.float()) < 2e-2
+    # nothing outside the active block was touched or read: a poisoned remainder changes nothing
+    wsup2 = wsup.clone()
+    wsup2[N:] = float("nan")
+    wsup2[:, K:] = float("nan")
+    assert torch.equal(K_.linear_fwd(x, wsup2, bias, N, K), out)
+    assert torch.equal(K_.linear_dgrad(dy, wsup2, N, K), dx)
+
+
 def test_grad_finalize_adds_partials_into_super_weight_slices():
     """cream_grad_finalize: many tensors in one launch, strided destination slices, the qkv row
     interleave (qkv_super.py:75), bf16 and fp32 partials, accumulation (+=), reproducible bits."""
@@ -220,6 +252,41 @@ def test_block_stack_equals_block_by_block_with_drop_path():
     assert set(res[0][2]) == set(res[1][2]) and len(res[0][2]) >= 3 * 16
     for k, v in res[0][2].items():
         assert _rel(v, res[1][2][k]) < 1e-5, k
+
+
+def test_native_block_sequencing_equals_op_by_op_driving():
+    """cream_block_fwd / cream_block_bwd (one C call per block and direction, weight gradients and
+    finalisation on the side stream) against the same kernels driven op by op from Python on one
+    stream: identical kernels on identical inputs in the same summation order -> identical bits."""
+    from cream_amd.autoformer import block as K
+    m = _supernet(depth=3).to(DEV)
+    cfg = dict(layer_num=3, embed_dim=[448] * 3, num_heads=[7, 5, 6], mlp_ratio=[4.0, 3.0, 3.5])
+    m.set_sample_config(cfg)
+    m.train()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    B = 4
+    x0 = torch.randn(B, 197, 448, device=DEV, generator=g)
+    scales = (torch.rand(3, 2, B, device=DEV, generator=g) > 0.3).float() / 0.7
+    dout = torch.randn(B, 197, 448, device=DEV, generator=g)
+    blks = list(m.blocks)
+    res = []
+    try:
+        for native, side, sc in ((True, True, scales), (False, False, scales), (True, False, None), (False, True, None)):
+            K.NATIVE_BLOCK, K.WGRAD_SIDE_STREAM = native, side
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            y = K.StackFunction.apply(x, sc, blks)
+            y.backward(dout)
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                             if p.grad is not None}))
+    finally:
+        K.NATIVE_BLOCK, K.WGRAD_SIDE_STREAM = True, True
+    for a, b in ((0, 1), (2, 3)):
+        assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1])
+        assert set(res[a][2]) == set(res[b][2]) and len(res[a][2]) >= 3 * 16
+        for k, v in res[a][2].items():
+            assert torch.equal(v, res[b][2][k]), k
 
 
 def test_mirror_follows_optimizer_and_droppath_runs():
