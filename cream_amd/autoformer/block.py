@@ -525,8 +525,9 @@ def _ensure_grad(p):
     return p.grad
 
 
-_desc_cache = {}      # id(blk) -> (template BlockDesc with the static pointers, version key)
-_grads_cache = {}     # id(blk) -> (BlockGrads, [(param, grad tensor)])
+# per-block caches live ON the module (blk.__dict__), so they die with it: keyed by id() they
+# would be inherited by whatever module later gets the same address
+_DESC_KEY, _GRADS_KEY = '_cream_desc_cache', '_cream_grads_cache'
 
 
 def _block_params(blk):
@@ -540,7 +541,7 @@ def _block_desc(blk, B, N):
     operand copies of the super weights, LayerNorm parameters, tables — all read in place) is
     built once per block and device; per call only the sampled extents are filled in."""
     at = blk.attn
-    ent = _desc_cache.get(id(blk))
+    ent = blk.__dict__.get(_DESC_KEY)
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
     key = (at.qkv.weight.data_ptr(), ln1.weight.data_ptr())          # moves when the module changes device / storage
     if ent is None or ent[1] != key:
@@ -558,7 +559,7 @@ def _block_desc(blk, B, N):
         t.ldt = tabs[0].stride(0)
         t.eps1, t.eps2 = ln1.eps, ln2.eps
         t.mr = at.max_relative_position
-        ent = _desc_cache[id(blk)] = (t, key, ms)
+        ent = blk.__dict__[_DESC_KEY] = (t, key, ms)
     else:
         for p, m in zip(_block_params(blk), ent[2]):                 # operand copies still current?
             MIRROR.get(p)
@@ -575,7 +576,7 @@ def _block_grads(blk):
     cached while the tensors stay the same objects — the reducer's flat-buffer views never move)."""
     at = blk.attn
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
-    ent = _grads_cache.get(id(blk))
+    ent = blk.__dict__.get(_GRADS_KEY)
     if ent is not None and all(p.grad is g for p, g in ent[1]):
         return ent[0]
     params = _block_params(blk) + (ln1.weight, ln1.bias, ln2.weight, ln2.bias) + _tables(at)
@@ -586,7 +587,7 @@ def _block_grads(blk):
     g.ln1_g, g.ln1_b, g.ln2_g, g.ln2_b = (t.data_ptr() for t in gr[8:12])
     g.tkv, g.tkh, g.tvv, g.tvh = (t.data_ptr() for t in gr[12:16])
     g.ldt = gr[12].stride(0)
-    _grads_cache[id(blk)] = (g, list(zip(params, gr)))
+    blk.__dict__[_GRADS_KEY] = (g, list(zip(params, gr)))
     return g
 
 
