@@ -62,6 +62,26 @@ def enable_gemm_selection(size='S', batch=128):
     return ok
 
 
+def prewarm(model, images, target, choices, amp_dtype=torch.bfloat16):
+    """Touch every GEMM problem of the search space once (one forward/backward of a one-block
+    sub-network per (embed_dim, num_heads, mlp_ratio) combination) so that the GEMM library's
+    lazily loaded kernels and the dispatcher's plans exist before the first measured step; the
+    sub-network shapes of a step are random, so without this first uses keep appearing for
+    hundreds of steps.  Gradients written here are discarded (zero-filled afterwards)."""
+    import itertools
+    was_training = model.training
+    model.train()
+    for E, H, R in itertools.product(choices['embed_dim'], choices['num_heads'], choices['mlp_ratio']):
+        model.set_sample_config(dict(layer_num=1, embed_dim=[E], num_heads=[H], mlp_ratio=[R]))
+        with torch.autocast(device_type=images.device.type, dtype=amp_dtype, enabled=amp_dtype != torch.float32):
+            loss = soft_target_cross_entropy(model(images), target)
+        loss.backward()
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    model.train(was_training)
+
+
 def sample_configs(choices):
     """supernet_engine.py:13-24.  Draw order: depth, mlp_ratio x depth, num_heads x depth,
     then ONE embed_dim shared by all layers."""

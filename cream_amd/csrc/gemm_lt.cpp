@@ -20,6 +20,7 @@
 #include <hipblaslt/hipblaslt-ext.hpp>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -166,6 +167,7 @@ int cream_gemm_table_load(const char* csv_path)
     std::ifstream f(csv_path);
     if (!f) return CREAM_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(g_mu);
+    if (!ensure_handle()) return CREAM_ERR_LAUNCH;
     int n = 0;
     std::string line;
     while (std::getline(f, line)) {
@@ -173,9 +175,20 @@ int cream_gemm_table_load(const char* csv_path)
         std::stringstream ss(line);
         std::string op, sig, sol;
         if (!std::getline(ss, op, ',') || !std::getline(ss, sig, ',') || !std::getline(ss, sol, ',')) continue;
-        if (op == "Validator") continue;
+        if (op == "Validator") {
+            // solution indices are only meaningful for the library build they were recorded with
+            // ("Validator,HIPBLASLT_VERSION,<int>-<build>"): another version -> ignore the table
+            if (sig == "HIPBLASLT_VERSION") {
+                int v = 0;
+                if (hipblasLtGetVersion(g_handle, &v) != HIPBLAS_STATUS_SUCCESS || v != atoi(sol.c_str())) return 0;
+            }
+            continue;
+        }
+        // "Gemm_Hipblaslt_<i>": library solution index.  Entries of other back ends ("Gemm_Rocblas_<i>",
+        // "Default") are left to the library heuristic: a rocBLAS index is NOT a valid index of this
+        // library (trying one as such hung the GPU).
         static const char* pre = "Gemm_Hipblaslt_";
-        if (sol.compare(0, strlen(pre), pre) != 0) continue;   // other back ends: leave to the heuristic
+        if (sol.compare(0, strlen(pre), pre) != 0) continue;
         g_table[op + "," + sig] = atoi(sol.c_str() + strlen(pre));
         ++n;
     }
