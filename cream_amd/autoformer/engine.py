@@ -46,6 +46,9 @@ def enable_gemm_selection(size='S', batch=128):
     if not (torch.cuda.is_available() and os.path.exists(path)):
         return False
     _block.gemm_table_load(path)         # the native dispatcher of the fused blocks (csrc/gemm_lt.cpp)
+    lt = path[:-4] + '_lt.csv'           # problems re-tuned over the library's own solutions only
+    if os.path.exists(lt):               # (tools/tune_gemms_lt_only.py); later entries override
+        _block.gemm_table_load(lt)
     tun = torch.cuda.tunable             # the GEMMs left to the framework (stem, head, module path)
     tun.enable(True)
     tun.tuning_enable(False)
