@@ -115,3 +115,42 @@ def test_trainer_step_runs_and_updates_only_with_finite_values():
     assert not torch.equal(before, model.head.weight.detach())
     # golden draw sequence of epoch 0: third config drawn last
     assert tr.config["layer_num"] in (12, 13, 14)
+
+
+def test_full_size_step_is_bit_reproducible_and_respects_sampled_slices():
+    """BASELINE size (supernet-S, B = 128, 224^2, bf16 throughput mode, native block sequencing with
+    the weight-gradient GEMMs + gradient finalisation on the side stream): two identical steps give
+    identical bits (a race between the two streams, a recycled buffer or an atomics-ordered sum
+    would show up here), gradients are exactly zero outside the sampled slices of the super
+    weights, and blocks beyond the sampled depth receive none."""
+    from cream_amd.autoformer import engine
+    dev = _dev()
+    torch.manual_seed(0)
+    m = engine.build_supernet("S", drop_path_rate=0.1).to(dev)
+    cfg = dict(layer_num=13, embed_dim=[384] * 13, num_heads=[6, 5, 7, 6, 6, 5, 7, 7, 5, 6, 6, 7, 5],
+               mlp_ratio=[3.5, 3.0, 4.0, 3.5, 3.0, 4.0, 3.5, 3.5, 3.0, 4.0, 4.0, 3.0, 3.5])
+    m.set_sample_config(cfg)
+    m.train()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(128, 3, 224, 224, device=dev, generator=g)
+    t = torch.softmax(torch.randn(128, 1000, device=dev, generator=g), -1)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=False)
+        torch.manual_seed(123)                               # same drop-path draws
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = engine.soft_target_cross_entropy(m(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert runs[0][0] == runs[1][0] and runs[0][0] == runs[0][0]
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
+    gr = runs[0][1]
+    assert torch.isfinite(gr["blocks.0.fc1.weight"]).all()
+    assert torch.count_nonzero(gr["blocks.0.fc1.weight"][int(384 * 3.5):]) == 0      # rows beyond F
+    assert torch.count_nonzero(gr["blocks.0.fc1.weight"][:, 384:]) == 0               # columns beyond E
+    assert torch.count_nonzero(gr["blocks.1.attn.qkv.weight"][3 * 320:]) == 0         # rows beyond 3Q (H = 5)
+    assert torch.count_nonzero(gr["blocks.1.attn.qkv.weight"][:3 * 320, :384]) > 0
+    assert torch.count_nonzero(gr["blocks.2.attn.proj.weight"][:384, :448]) > 0
+    assert "blocks.13.fc1.weight" not in gr or torch.count_nonzero(gr["blocks.13.fc1.weight"]) == 0
