@@ -242,7 +242,7 @@ def main():
                 ach = st["bytes"] / (st["total_ms"] * 1e-3) / 1e9
                 roof = dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-            roof["traffic"], src = pmc_traffic(name)
+            roof["traffic"], src = pmc_traffic(name) if a.supernet == "S" else (None, None)   # counters were taken on S shapes
             if src:
                 roof["traffic_unit"] = "bytes per launch (mean over H=5,6,7), rocprofv3 PMC pass: " + src
             roof["launches"] = st["launches"]
