@@ -1,6 +1,6 @@
-"""One supernet transformer block as a single autograd node on the HIP kernels — the bf16
+"""The run of supernet transformer blocks as a single autograd node on the native path — the bf16
 throughput execution of TransformerEncoderLayer.forward
-(AutoFormer/model/supernet_transformer.py:251-287):
+(AutoFormer/model/supernet_transformer.py:251-287), per block:
 
     x1 = x  + drop_path(proj(attn(LN1(x))))
     x2 = x1 + drop_path(fc2(gelu(fc1(LN2(x1)))))
@@ -10,13 +10,17 @@ What runs where:
     sums: the fused HBM passes of csrc/block_ops.hip (fp32 residual stream, bf16 GEMM operands,
     every activation crosses HBM once per direction);
   * attention core: csrc/attn_rpe2d.hip (nothing of size N^2 in HBM);
-  * the dense projections: the GEMM library on bf16 MIRRORS of the fp32 master weights, read in
-    place through strided `W[:out, :in]` views (leading dimension = super width); weight
-    gradients are split-K batched GEMMs (K = 25k tokens is split 8 ways, partial products
-    summed in fp32) accumulated straight into the active slice of the fp32 `.grad`.
-The backward is written by hand; parameter gradients are accumulated into `p.grad` directly
-and announced through `notify_grads_ready` (the gradient reducer starts a block's all-reduce
-the moment its last gradient exists).
+  * the dense projections: the GEMM library (hipBLASLt, dispatched from the C ABI with the offline
+    kernel table: csrc/gemm_lt.cpp) on bf16 MIRRORS of the fp32 master weights, read in place as
+    `W[:out, :in]` (leading dimension = super width); weight gradients are split-K batched GEMMs
+    (K = 25k tokens split 8 ways) whose partial products `cream_grad_finalize` adds in fp32 into
+    the active slice of the fp32 `.grad`.
+Two drivers over the SAME kernels: `NATIVE_BLOCK` (default) = one call into the C ABI per block and
+direction (csrc/block_seq.cpp; weight gradients + finalisation on a side stream), or op by op from
+here (`_block_forward` / `_block_backward`; used by the kernel-timing pass of bench.py and by the
+tests that pin the native sequencing bit for bit).  The backward is written by hand; parameter
+gradients are accumulated into `p.grad` directly and announced through the `on_grads_ready` hooks
+(the gradient reducer starts a block's all-reduce the moment its last gradient exists).
 """
 import ctypes
 

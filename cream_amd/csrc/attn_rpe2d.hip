@@ -11,10 +11,14 @@
 // Nothing of size N^2 touches HBM.  One workgroup = one (b,h); wave w owns the 32-query
 // tile w and keeps the whole row block of scores in registers (N <= 256), so the softmax is
 // exact (no online rescaling).  The bias gather / slot sums ride on the MFMAs through the
-// one-hot extension described in attn_common.hpp.  Row-major operands (Q, K, dO, ...) are
-// read straight from global memory (they are L2-resident: 25 KB per head); LDS holds only
-// the transposed tiles the matrix cores need with the contraction index contiguous (V^T,
-// K^T, Q^T, dO^T), the transposed value tables and the per-wave shift scratch.
+// one-hot extension described in attn_common.hpp.  Operands shared by the waves of a
+// workgroup (K, V, Q, dO, side buffers) are streamed through LDS tile by tile (full lines,
+// fetched once per workgroup, two 4-wave staging groups); transposed tiles for the products
+// that contract over tokens (V^T, K^T, Q^T, dO^T) are produced by the staging stores.  LDS also
+// holds the bucket tables as bf16 operands, the one-hot key operands of the fast geometry and
+// the per-wave scratch of the slot <-> bucket shifts.  The AutoFormer geometry (14 x 14 grid,
+// max_relative_position 14, bf16) has its own instantiation (FAST): the kernels were
+// VALU-issue-bound on index arithmetic, see attn_common.hpp and DESIGN.md 4.2.
 //
 // dtype = bf16 (throughput mode: bf16 operands, fp32 accumulation/softmax) or fp32 (parity
 // mode: v_mfma_f32_32x32x2_f32, exact fp32 products) — one code path, Tr<T> traits.
