@@ -186,3 +186,34 @@ class SupernetTrainer:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
         self.optimizer.step()                # (its post-hook refreshes the bf16 operand copies)
         return loss
+
+
+@torch.no_grad()
+def evaluate(batches, model, amp_dtype=torch.bfloat16, choices=None, mode='super', retrain_config=None):
+    """Sub-network evaluation — host-side mirror of `evaluate` in AutoFormer/supernet_engine.py:113-160
+    (the inner loop of the evolution search, evolution.py:22-290, and of the validation pass):
+    eval mode, ONE sub-network (sampled from `choices` when mode == 'super', else `retrain_config`),
+    cross entropy + top-1 / top-5 accuracy averaged over the samples of `batches` (an iterable of
+    (images, labels) already on the model's device).  The statistics are accumulated on the device:
+    one host synchronisation at the end instead of the reference's three `.item()` per batch.
+    Returns {'loss', 'acc1', 'acc5', 'config', 'params'}."""
+    model.eval()
+    config = sample_configs(choices) if mode == 'super' else retrain_config
+    model.set_sample_config(config)
+    params = model.get_sampled_params_numel(config)
+    dev = next(model.parameters()).device
+    tot = torch.zeros(4, dtype=torch.float64, device=dev)        # loss*n, top1 hits, top5 hits, n
+    use_amp = amp_dtype is not None and amp_dtype != torch.float32 and dev.type == 'cuda'
+    for images, labels in batches:
+        with torch.autocast(device_type=dev.type, dtype=amp_dtype if use_amp else torch.bfloat16, enabled=use_amp):
+            out = model(images)
+        out = out.float()
+        n = images.shape[0]
+        loss = F.cross_entropy(out, labels, reduction='sum')
+        top5 = out.topk(min(5, out.shape[1]), dim=1).indices
+        hit = top5.eq(labels.view(-1, 1))
+        tot += torch.stack([loss.double(), hit[:, 0].sum().double(), hit.any(dim=1).sum().double(),
+                            torch.tensor(float(n), dtype=torch.float64, device=dev)])
+    loss_sum, h1, h5, n = tot.tolist()
+    n = max(n, 1.0)
+    return dict(loss=loss_sum / n, acc1=100.0 * h1 / n, acc5=100.0 * h5 / n, config=config, params=params)

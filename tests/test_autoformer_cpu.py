@@ -175,3 +175,34 @@ def test_dense_forward_of_relative_position_module_still_available():
     emb = rp(197, 197)
     want, _, _ = AO.rel_pos_embeddings(rp.embeddings_table_v.detach(), rp.embeddings_table_h.detach(), 197, 14)
     assert torch.equal(emb.detach(), want)
+
+
+def test_evaluate_matches_direct_computation():
+    """engine.evaluate (supernet_engine.py:113-160): one sub-network, loss / top-1 / top-5 averaged over
+    samples, accumulated without per-batch host syncs."""
+    import random
+    import torch
+    import torch.nn.functional as F
+    from cream_amd.autoformer import engine
+    torch.manual_seed(0)
+    m = engine.build_supernet("T", drop_path_rate=0.1, depth=2, num_classes=10)
+    ch = dict(engine.SEARCH_SPACES["T"]["choices"], depth=[1, 2])
+    g = torch.Generator().manual_seed(1)
+    batches = [(torch.randn(3, 3, 224, 224, generator=g), torch.randint(0, 10, (3,), generator=g)),
+               (torch.randn(2, 3, 224, 224, generator=g), torch.randint(0, 10, (2,), generator=g))]
+    random.seed(7)
+    res = engine.evaluate(batches, m, amp_dtype=torch.float32, choices=ch, mode="super")
+    random.seed(7)
+    cfg = engine.sample_configs(ch)
+    assert res["config"] == cfg and res["params"] == m.get_sampled_params_numel(cfg)
+    m.eval()
+    m.set_sample_config(cfg)
+    with torch.no_grad():
+        outs = torch.cat([m(x) for x, _ in batches])
+    labels = torch.cat([y for _, y in batches])
+    assert abs(res["loss"] - float(F.cross_entropy(outs, labels))) < 1e-5
+    top5 = outs.topk(5, dim=1).indices
+    assert abs(res["acc1"] - 100.0 * float((top5[:, 0] == labels).double().mean())) < 1e-9
+    assert abs(res["acc5"] - 100.0 * float(top5.eq(labels[:, None]).any(1).double().mean())) < 1e-9
+    res2 = engine.evaluate(batches, m, amp_dtype=torch.float32, mode="retrain", retrain_config=cfg)
+    assert res2["loss"] == res["loss"]

@@ -154,3 +154,27 @@ def test_full_size_step_is_bit_reproducible_and_respects_sampled_slices():
     assert torch.count_nonzero(gr["blocks.1.attn.qkv.weight"][:3 * 320, :384]) > 0
     assert torch.count_nonzero(gr["blocks.2.attn.proj.weight"][:384, :448]) > 0
     assert "blocks.13.fc1.weight" not in gr or torch.count_nonzero(gr["blocks.13.fc1.weight"]) == 0
+
+
+def test_subnet_evaluation_native_path_matches_module_path():
+    """engine.evaluate (supernet_engine.py:113-160) in bf16 on the GPU: the run of blocks goes through
+    the native forward sequencing (eval mode, no drop-path, no autograd graph); same sub-network and
+    batches through the module-by-module path must agree to bf16 accuracy."""
+    import random
+    from cream_amd.autoformer import engine
+    dev = _dev()
+    torch.manual_seed(0)
+    m = engine.build_supernet("S", drop_path_rate=0.1, num_classes=100).to(dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    batches = [(torch.randn(8, 3, 224, 224, device=dev, generator=g), torch.randint(0, 100, (8,), device=dev, generator=g))
+               for _ in range(2)]
+    ch = engine.SEARCH_SPACES["S"]["choices"]
+    res = {}
+    for fused in (True, False):
+        for blk in m.blocks:
+            blk.fused = fused
+        random.seed(11)
+        res[fused] = engine.evaluate(batches, m, choices=ch, mode="super")
+    assert res[True]["config"] == res[False]["config"] and res[True]["params"] == res[False]["params"]
+    assert abs(res[True]["loss"] - res[False]["loss"]) < 2e-2 * abs(res[False]["loss"])
+    assert res[True]["loss"] == res[True]["loss"]
