@@ -80,3 +80,49 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(_lib.CreamLibraryError):
         _lib.load()
+
+
+def test_block_workspace_layout_is_pure_host_arithmetic():
+    """cream_block_fwd_workspace / cream_block_bwd_workspace: sizes and offsets of the one flat
+    workspace per block and direction (no GPU needed: nothing is launched or allocated)."""
+    from cream_amd import _lib
+    lib = _lib.load()
+    d = _lib.BlockDesc()
+    d.B, d.N, d.E, d.H, d.F = 128, 197, 384, 6, 1344
+    d.gh, d.gw, d.mr, d.wgrad_split = 14, 14, 14, 8
+    for name in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv",
+                 "tkh", "tvv", "tvh"):
+        setattr(d, name, 0x1000)                                   # any non-null pointer: only checked, never read
+    o = [ctypes.c_int64() for _ in range(6)]
+    ft = lib.cream_block_fwd_workspace(ctypes.byref(d), ctypes.byref(o[0]), ctypes.byref(o[1]), ctypes.byref(o[2]))
+    bt = lib.cream_block_bwd_workspace(ctypes.byref(d), ctypes.byref(o[3]), ctypes.byref(o[4]), ctypes.byref(o[5]))
+    M, E, Q, F = 128 * 197, 384, 384, 1344
+    # everything the backward reads from the forward: x, a, qkv, o, x1, c, h, g, f (+ small stats, sp)
+    assert ft >= M * E * 4 * 2 + M * E * 2 * 4 + M * 3 * Q * 2 + M * Q * 2 + 2 * M * F * 2
+    assert ft < 1.2 * (M * E * 4 * 2 + M * E * 2 * 4 + M * 3 * Q * 2 + M * Q * 2 + 2 * M * F * 2 + 128 * 6 * 64 * 224 * 2) + (1 << 22)
+    assert bt > 0 and all(v.value % 256 == 0 for v in o)
+    assert 0 <= o[0].value < o[1].value < o[2].value < ft            # x | ... | x1 | ... | f
+    assert o[3].value < o[4].value < o[5].value < bt                 # dx | df_prev | pl1
+    d.wgrad_split = 7                                                # 25216 % 7 != 0
+    assert lib.cream_block_fwd_workspace(ctypes.byref(d), None, None, None) == -1
+    d.wgrad_split, d.E = 8, 380                                      # E % 8 != 0
+    assert lib.cream_block_bwd_workspace(ctypes.byref(d), None, None, None) == -1
+
+
+def test_new_entry_points_validate_arguments_without_launching():
+    from cream_amd import _lib
+    lib = _lib.load()
+    assert lib.cream_grad_finalize(None, 0, None) == 0               # nothing to do
+    assert lib.cream_grad_finalize(None, 1, None) == -1
+    assert lib.cream_grad_finalize(None, _lib.MAX_GRAD_JOBS + 1, None) == -1
+    j = (_lib.GradJob * 1)()
+    j[0].dst, j[0].src, j[0].ld, j[0].pstride, j[0].nparts, j[0].rows, j[0].cols = 0x1000, 0x2000, 6, 8, 2, 1, 8
+    assert lib.cream_grad_finalize(ctypes.cast(j, ctypes.c_void_p), 1, None) == -1      # ld % 4 != 0
+    assert lib.cream_linear_fwd(None, None, None, None, 0, 8, 8, 8, None) == 0          # empty problem
+    assert lib.cream_linear_fwd(None, None, None, None, 4, 8, 8, 8, None) == -1
+    assert lib.cream_linear_dgrad(0x1000, 0x1000, 0x1000, 4, 8, 16, 8, None) == -1       # ldw < K
+    assert lib.cream_linear_wgrad_parts(0x1000, 0x1000, 0x1000, 10, 8, 8, 3, None) == -1  # M % S != 0
+    assert lib.cream_qkv_regroup(0x1000, 0x1000, 64, 100, 104, None) == -1               # E % 8 != 0
+    assert lib.cream_gemm_table_load(b"/nonexistent/table.csv") == -1
+    assert lib.cream_colsum128_slabs(25216) == 197 and lib.cream_colsum128_slabs(0) == 0
+    assert lib.cream_ln_partials() > 0
