@@ -508,7 +508,9 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     const E* qp = reinterpret_cast<const E*>(a.q) + base;
     const E* kpg = reinterpret_cast<const E*>(a.k) + base;
     const E* vpg = reinterpret_cast<const E*>(a.v) + base;
-    const bool active = wave < nt;                     // waves beyond the query tiles only help staging
+    // waves beyond the query tiles only help staging; the fast instantiation is launched with exactly
+    // nt waves, and saying so lets the accumulators start from the MFMA's inline zero operand
+    const bool active = FAST ? true : wave < nt;
 
     PROF_DECL
     PROF_MARK();
