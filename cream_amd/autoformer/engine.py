@@ -217,3 +217,43 @@ def evaluate(batches, model, amp_dtype=torch.bfloat16, choices=None, mode='super
     loss_sum, h1, h5, n = tot.tolist()
     n = max(n, 1.0)
     return dict(loss=loss_sum / n, acc1=100.0 * h1 / n, acc5=100.0 * h5 / n, config=config, params=params)
+
+
+# ---- checkpoints: the on-disk format either side of the path ---------------------------
+def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, scaler=None, args=None, rank=0):
+    """Writes the dictionary of AutoFormer/supernet_train.py:363-370 ('model', 'optimizer',
+    'lr_scheduler', 'epoch', 'scaler', 'args'; `utils.save_on_master`: rank 0 only).  The 'model'
+    entry has the reference's parameter names and super shapes (the bf16 operand copies of the
+    fused path are derived data and are not stored), so the file loads into the reference too."""
+    if rank != 0:
+        return None
+    ckpt = {'model': model.state_dict(), 'epoch': epoch, 'args': args}
+    if optimizer is not None:
+        ckpt['optimizer'] = optimizer.state_dict()
+    if lr_scheduler is not None:
+        ckpt['lr_scheduler'] = lr_scheduler.state_dict()
+    if scaler is not None:
+        ckpt['scaler'] = scaler.state_dict()
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scaler=None, eval_only=False):
+    """The resume logic of supernet_train.py:316-330: 'model' always; optimizer / lr_scheduler /
+    epoch (+ scaler) only when all three are present and not `eval_only`.  Accepts published
+    `supernet-*.pth` files ({'model': state_dict}).  Returns the epoch to START from (0 when the
+    file carries no training state).  The bf16 operand copies of the fused blocks are re-derived."""
+    ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu',
+                                                                         weights_only=False)
+    model.load_state_dict(ckpt['model'])
+    _block.MIRROR.refresh_all(force=True)
+    start_epoch = 0
+    if not eval_only and all(k in ckpt for k in ('optimizer', 'lr_scheduler', 'epoch')):
+        if optimizer is not None:
+            optimizer.load_state_dict(ckpt['optimizer'])
+        if lr_scheduler is not None:
+            lr_scheduler.load_state_dict(ckpt['lr_scheduler'])
+        start_epoch = ckpt['epoch'] + 1
+        if scaler is not None and 'scaler' in ckpt:
+            scaler.load_state_dict(ckpt['scaler'])
+    return start_epoch
