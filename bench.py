@@ -109,15 +109,6 @@ def cpu_baseline_subprocess(size, seconds):
     return None
 
 
-def gemm_plans():
-    """How many GEMM plans of the native dispatcher came from the offline table / the heuristic."""
-    import ctypes
-    from cream_amd import _lib
-    a, b = ctypes.c_int(), ctypes.c_int()
-    n = _lib.load().cream_gemm_plan_counts(ctypes.byref(a), ctypes.byref(b))
-    return {"total": n, "from_table": a.value, "heuristic": b.value}
-
-
 def pmc_traffic(region):
     """HBM bytes per launch of a timed region from the committed rocprofv3 PMC passes
     (profiles/*_attention_pmc.json: FETCH_SIZE doubled per the gfx950 correction of
@@ -160,7 +151,6 @@ def main():
     if a.no_wgrad_stream:
         from cream_amd.autoformer import block as _blk
         _blk.WGRAD_SIDE_STREAM = False
-    gemm_sel = engine.enable_gemm_selection(a.supernet, a.batch) if a.dtype == "bf16" else False
     torch.manual_seed(0 + rank)                               # supernet_train.py:196-198
     model = engine.build_supernet(a.supernet, drop_path_rate=0.1).to(dev)
     for m in model.modules():
@@ -186,8 +176,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # library initialisation (not steps): every GEMM problem of the search space is touched once
-    engine.prewarm(model, images, target, engine.SEARCH_SPACES[a.supernet]["choices"], amp)
     trainer.start_epoch(0)
     for _ in range(a.warmup):
         loss = trainer.step(images, target)
@@ -262,8 +250,7 @@ def main():
                                    f"(random.seed(epoch)), per-GPU batch {a.batch}, 224x224, AdamW, "
                                    f"grad all-reduce RCCL", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "attention_impl": a.impl,
-                       "gemm_selection": "offline table" if gemm_sel else "library default",
-                       "gemm_plans": gemm_plans()},
+                       "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp), no vendor GEMM library"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -59,13 +59,17 @@ SIGNATURES = {
     "cream_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_scale_cast_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cream_grad_finalize": (_i, [_vp, _i, _vp]),
-    "cream_gemm_table_load": (_i, [_c.c_char_p]),
-    "cream_gemm_set_workspace": (_i, [_vp, _vp, _i64]),
-    "cream_gemm_plan_counts": (_i, [_vp, _vp]),
+    "cream_gemm_rows_per_colsum_slab": (_i, []),
     "cream_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "cream_linear_fwd_seg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
+    "cream_linear_gelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
-    "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "cream_qkv_regroup": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
+    "cream_linear_dgrad_seg": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
+    "cream_linear_dgrad_dgelu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "cream_linear_wgrad_splits": (_i, [_i, _i, _i]),
+    "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "cream_param_job_tiles": (_i, [_i, _i]),
+    "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
     "cream_block_fwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
     "cream_block_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cream_block_bwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
@@ -83,12 +87,21 @@ class GradJob(ctypes.Structure):
 
 class BlockDesc(ctypes.Structure):
     """struct cream_block_desc of include/cream_amd.h."""
-    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "wgrad_split", "reserved")] +
+    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "reserved0", "reserved1")] +
                 [(n, _f) for n in ("eps1", "eps2", "attn_scale", "reserved_f")] +
-                [(n, _vp) for n in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2")] +
-                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2")] +
+                [(n, _vp) for n in ("wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj", "w1", "w1_t", "b1",
+                                    "w2", "w2_t", "b2")] +
+                [(n, _i64) for n in ("ld_qkv", "ld_qkv_t", "seg_qkv", "seg_qkv_t", "ld_proj", "ld_proj_t", "ld_w1",
+                                     "ld_w1_t", "ld_w2", "ld_w2_t")] +
                 [(n, _vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
                 [("ldt", _i64)])
+
+
+class ParamJob(ctypes.Structure):
+    """struct cream_param_job of include/cream_amd.h."""
+    _fields_ = ([(n, _vp) for n in ("p", "g", "m", "v", "mir", "mir_t")] +
+                [(n, _i64) for n in ("ld", "ld_mir", "ld_mir_t", "seg_stride", "seg_stride_t")] +
+                [(n, _c.c_int32) for n in ("rows", "cols", "deinterleave")] + [("weight_decay", _f)])
 
 
 class BlockGrads(ctypes.Structure):

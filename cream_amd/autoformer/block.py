@@ -10,11 +10,13 @@ What runs where:
     sums: the fused HBM passes of csrc/block_ops.hip (fp32 residual stream, bf16 GEMM operands,
     every activation crosses HBM once per direction);
   * attention core: csrc/attn_rpe2d.hip (nothing of size N^2 in HBM);
-  * the dense projections: the GEMM library (hipBLASLt, dispatched from the C ABI with the offline
-    kernel table: csrc/gemm_lt.cpp) on bf16 MIRRORS of the fp32 master weights, read in place as
-    `W[:out, :in]` (leading dimension = super width); weight gradients are split-K batched GEMMs
-    (K = 25k tokens split 8 ways) whose partial products `cream_grad_finalize` adds in fp32 into
-    the active slice of the fp32 `.grad`.
+  * the dense projections: hand-written MFMA GEMMs (csrc/gemm_mfma.hpp) on bf16 OPERAND COPIES of
+    the fp32 master weights, read in place as `W[:out, :in]` (leading dimension = super width):
+    forward on W (qkv on its de-interleaved [q | k | v] parts), dgrad on the transposed copies,
+    fc1 with the erf-GELU and fc2's dgrad with GELU' in their epilogues; weight gradients are
+    split-K products over the 25k tokens (transpose-reads of both operands) whose fp32 partials
+    `cream_grad_finalize` adds into the active slice of the fp32 `.grad`.  The copies are written
+    by the optimizer kernel (csrc/optim.hip) in the same pass that updates the weights.
 Two drivers over the SAME kernels: `NATIVE_BLOCK` (default) = one call into the C ABI per block and
 direction (csrc/block_seq.cpp; weight gradients + finalisation on a side stream), or op by op from
 here (`_block_forward` / `_block_backward`; used by the kernel-timing pass of bench.py and by the
@@ -28,9 +30,6 @@ import torch
 
 from .. import _lib, timing
 from . import fused_attention
-
-_WGRAD_SPLIT = 8
-
 
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
@@ -159,95 +158,83 @@ def colsum128(a):
     return partial
 
 
-def wgrad_parts(dy, x):
-    """Split-K weight gradient: (s, out, in) partial products dy_s^T x_s over s slices of the
-    token dimension (the library's single-pass TN GEMM leaves most CUs idle on a 25k-deep
-    contraction); the slices are added by cream_grad_finalize."""
-    M = dy.shape[0]
-    s = _WGRAD_SPLIT
-    while M % s:
-        s //= 2
-    return torch.bmm(dy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1))
-
-
-# ---- dense projections: native dispatch (csrc/gemm_lt.cpp) ----------------------------------------
-# The GEMM library is called from the C ABI with plans cached per problem signature and the
-# offline kernel selection of cream_amd/tuning/*.csv; through the framework each GEMM cost ~27 us
-# of host time (tunable-op lookup), 24 GEMMs per block: the step was launch-bound.
-NATIVE_GEMM = True
-_GEMM_WS_BYTES = 128 << 20
-_gemm_ws = {}              # (device, stream handle) -> workspace tensor (kept alive)
-_gemm_tables = set()
-
-
-def gemm_table_load(path):
-    """Register a kernel-selection table with the native dispatcher (idempotent)."""
-    import os
-    path = os.path.abspath(path)
-    if path in _gemm_tables:
-        return 0
-    n = _lib.load().cream_gemm_table_load(path.encode())
-    if n < 0:
-        raise RuntimeError(f"cream_amd: cannot read GEMM table {path}")
-    _gemm_tables.add(path)
-    return n
-
-
-def _gemm_stream(device):
-    """Current stream handle, with a GEMM workspace registered for it."""
-    st = torch.cuda.current_stream(device)
-    h = st.cuda_stream
-    key = (device.index, h)
-    if key not in _gemm_ws:
-        ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
-        _lib.check(_lib.load().cream_gemm_set_workspace(ctypes.c_void_p(h), _p(ws), ws.numel()), "cream_gemm_set_workspace")
-        _gemm_ws[key] = ws
-    return ctypes.c_void_p(h)
-
-
+# ---- dense projections: hand-written MFMA GEMMs (csrc/gemm_mfma.hip) -------------------------------
 def linear_fwd(x, w, bias, N, K, out=None):
-    """out (M, N) = x (M, K) . W[:N, :K]^T + bias[:N]; w: bf16 (rows, ld) matrix read in place."""
+    """out (M, N) = x (M, K) . W[:N, :K]^T + bias[:N]; w: bf16 (rows, ld) operand copy read in place."""
     M = x.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    if not NATIVE_GEMM:
-        return torch.addmm(bias[:N], x, w[:N, :K].t(), out=out)
-    _lib.check(_lib.load().cream_linear_fwd(_p(out), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _gemm_stream(x.device)),
+    _lib.check(_lib.load().cream_linear_fwd(_p(out), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
                "cream_linear_fwd")
     return out
 
 
-def linear_dgrad(dy, w, N, K, out=None):
-    """dx (M, K) = dy (M, N) . W[:N, :K]"""
+def linear_fwd_seg(x, w3, bias, N, K, nseg, out=None):
+    """The same with W = the first `nseg` rows of each of the 3 parts of w3 (3, rows, ld): the
+    de-interleaved qkv operand; N = 3 * nseg."""
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().cream_linear_fwd_seg(_p(out), _p(x), _p(w3), _p(bias), M, N, K, w3.stride(1), nseg,
+                                                w3.stride(0), _stream()), "cream_linear_fwd_seg")
+    return out
+
+
+def linear_gelu_fwd(x, w, bias, N, K):
+    """-> (h, g): h = x . W^T + bias (bf16), g = gelu(float(h)) (bf16) in one pass (fc1 + activation)."""
+    M = x.shape[0]
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    g = torch.empty_like(h)
+    _lib.check(_lib.load().cream_linear_gelu_fwd(_p(h), _p(g), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
+               "cream_linear_gelu_fwd")
+    return h, g
+
+
+def linear_dgrad(dy, wt, N, K, out=None):
+    """dx (M, K) = dy (M, N) . W[:N, :K]; wt: the TRANSPOSED operand copy (in, out)."""
     M = dy.shape[0]
     if out is None:
         out = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
-    if not NATIVE_GEMM:
-        return torch.mm(dy, w[:N, :K], out=out)
-    _lib.check(_lib.load().cream_linear_dgrad(_p(out), _p(dy), _p(w), M, N, K, w.stride(0), _gemm_stream(dy.device)),
+    _lib.check(_lib.load().cream_linear_dgrad(_p(out), _p(dy), _p(wt), M, N, K, wt.stride(0), _stream()),
                "cream_linear_dgrad")
     return out
 
 
-def _wgrad_split(M):
-    s = _WGRAD_SPLIT
-    while M % s:
-        s //= 2
-    return s
+def linear_dgrad_seg(dy, wt3, N, K, kseg, out=None):
+    """dx = dy . W with W's rows = the first `kseg` rows of the 3 qkv parts; wt3 (3, in, out)."""
+    M = dy.shape[0]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(_lib.load().cream_linear_dgrad_seg(_p(out), _p(dy), _p(wt3), M, N, K, wt3.stride(1), kseg, wt3.stride(0),
+                                                  _stream()), "cream_linear_dgrad_seg")
+    return out
 
 
-def linear_wgrad_parts(dy, x, out=None):
-    """(S, N, K) partial products dy_s^T x_s over S slices of the token dimension."""
+def linear_dgrad_dgelu(dy, wt, h, N, K):
+    """-> (dh, parts): dh (M, K) = (dy . W) * gelu'(h), parts (slabs, K) its per-slab column sums."""
+    M = dy.shape[0]
+    lib = _lib.load()
+    dh = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
+    parts = torch.empty((lib.cream_colsum128_slabs(M), K), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.cream_linear_dgrad_dgelu(_p(dh), _p(parts), _p(dy), _p(wt), _p(h), M, N, K, wt.stride(0), _stream()),
+               "cream_linear_dgrad_dgelu")
+    return dh, parts
+
+
+def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None):
+    """-> (parts (S, N, K) fp32, bias_parts (S, N) fp32 or None): partial products dy_s^T x_s over S
+    slices of the token dimension (S chosen by the library) and, on request, the column sums of dy_s."""
     M, N = dy.shape
     K = x.shape[1]
-    s = _wgrad_split(M)
+    lib = _lib.load()
+    S = lib.cream_linear_wgrad_splits(M, N, K)
     if out is None:
-        out = torch.empty((s, N, K), dtype=torch.bfloat16, device=dy.device)
-    if not NATIVE_GEMM:
-        return torch.bmm(dy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1), out=out)
-    _lib.check(_lib.load().cream_linear_wgrad_parts(_p(out), _p(dy), _p(x), M, N, K, s, _gemm_stream(dy.device)),
-               "cream_linear_wgrad_parts")
-    return out
+        out = torch.empty((S, N, K), dtype=torch.float32, device=dy.device)
+    if want_bias and bias_out is None:
+        bias_out = torch.empty((S, N), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.cream_linear_wgrad_parts(_p(out), _p(bias_out) if want_bias else ctypes.c_void_p(0), _p(dy), _p(x), M, N, K,
+                                            S, _stream()), "cream_linear_wgrad_parts")
+    return out, (bias_out if want_bias else None)
 
 
 # The weight-gradient GEMMs are off the critical path of a block's backward (only the gradient
@@ -265,20 +252,23 @@ def _side_stream(device):
     return st
 
 
-def wgrad_parts_async(dy, x):
-    """wgrad_parts on the side stream: the output is allocated on the caller's stream (so the
-    caching allocator never hands it out while the side stream still writes it: the caller joins
+def wgrad_parts_async(dy, x, want_bias=False):
+    """linear_wgrad_parts on the side stream: the outputs are allocated on the caller's stream (so the
+    caching allocator never hands them out while the side stream still writes them: the caller joins
     the side stream before the partials are consumed), the operands are complete at this point of
     the caller's stream (event)."""
     if not WGRAD_SIDE_STREAM:
-        return linear_wgrad_parts(dy, x)
-    out = torch.empty((_wgrad_split(dy.shape[0]), dy.shape[1], x.shape[1]), dtype=dy.dtype, device=dy.device)
+        return linear_wgrad_parts(dy, x, want_bias)
+    M, N = dy.shape
+    S = _lib.load().cream_linear_wgrad_splits(M, N, x.shape[1])
+    out = torch.empty((S, N, x.shape[1]), dtype=torch.float32, device=dy.device)
+    bout = torch.empty((S, N), dtype=torch.float32, device=dy.device) if want_bias else None
     main = torch.cuda.current_stream(dy.device)
     side = _side_stream(dy.device)
     side.wait_event(main.record_event())
     with torch.cuda.stream(side):
-        linear_wgrad_parts(dy, x, out=out)
-    return out
+        linear_wgrad_parts(dy, x, want_bias, out=out, bias_out=bout)
+    return out, bout
 
 
 def join_side_stream(device):
@@ -346,43 +336,135 @@ class GradJobs:
 
 
 def wgrad(dy, x):
-    """dW (out, in) fp32 = dy^T x with the token dimension split _WGRAD_SPLIT ways (the
-    library's single-pass TN GEMM leaves most CUs idle on a 25k-deep contraction)."""
-    M = dy.shape[0]
-    s = _WGRAD_SPLIT
-    while M % s:
-        s //= 2
-    part = torch.bmm(dy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1))
-    return part.sum(dim=0, dtype=torch.float32)
+    """dW (out, in) fp32 = dy^T x (split-K partials added here; the block path adds them in
+    cream_grad_finalize)."""
+    return linear_wgrad_parts(dy, x)[0].sum(dim=0)
 
 
-# ---- bf16 mirrors of the fp32 master weights --------------------------------------------------
-class Mirror:
-    """bf16 copies of parameters, refreshed when the parameter's version counter moves (the
-    optimizer step bumps it).  `refresh_all` converts everything in a few fused launches."""
+# ---- bf16 operand copies of the fp32 master weights -----------------------------------------------
+def param_job(p, grad=None, exp_avg=None, exp_avg_sq=None, mir=None, mir_t=None, deinterleave=False, weight_decay=0.0):
+    """One cream_param_job: the parameter viewed as (rows, cols) = (numel / last dim, last dim)."""
+    cols = p.shape[-1] if p.dim() > 1 else p.numel()
+    rows = p.numel() // cols
+    assert p.is_contiguous()
+    j = _lib.ParamJob()
+    j.p = p.data_ptr()
+    j.g = grad.data_ptr() if grad is not None else 0
+    j.m = exp_avg.data_ptr() if exp_avg is not None else 0
+    j.v = exp_avg_sq.data_ptr() if exp_avg_sq is not None else 0
+    j.ld, j.rows, j.cols = cols, rows, cols
+    j.deinterleave = 3 if deinterleave else 0
+    j.weight_decay = weight_decay
+    if mir is not None:
+        j.mir = mir.data_ptr()
+        j.ld_mir = mir.stride(-2) if mir.dim() >= 2 else cols
+        j.seg_stride = mir.stride(0) if deinterleave else 0
+    if mir_t is not None:
+        j.mir_t = mir_t.data_ptr()
+        j.ld_mir_t = mir_t.stride(-2)
+        j.seg_stride_t = mir_t.stride(0) if deinterleave else 0
+    return j
 
-    def __init__(self):
-        self._m = {}
 
-    def get(self, p):
-        e = self._m.get(id(p))
-        if e is None or e[1] != p._version or e[0].device != p.device:
-            m = p.detach().to(torch.bfloat16) if e is None or e[0].device != p.device else e[0].copy_(p.detach())
-            self._m[id(p)] = e = (m, p._version, p)
-        return e[0]
+class JobTable:
+    """A device-resident table of cream_param_job + the prefix sums of their tile counts (the host
+    builds it once: the pointers of parameters, gradients, moments and copies never move)."""
 
-    def refresh_all(self, force=False):
-        """Re-convert the mirrored parameters.  force=True ignores the version counters: fused
-        optimizer kernels (torch._fused_adamw_) update parameters without bumping them, so the
-        optimizer-step hook installed by engine.build_optimizer always forces."""
-        stale = [e for e in self._m.values() if force or e[1] != e[2]._version]
-        if stale:
-            torch._foreach_copy_([e[0] for e in stale], [e[2].detach() for e in stale])
-            for e in stale:
-                self._m[id(e[2])] = (e[0], e[2]._version, e[2])
+    def __init__(self, jobs, device):
+        import numpy as np
+        lib = _lib.load()
+        self.n = len(jobs)
+        arr = (_lib.ParamJob * self.n)(*jobs)
+        first = [0]
+        for j in jobs:
+            first.append(first[-1] + lib.cream_param_job_tiles(j.rows, j.cols))
+        self.total = first[-1]
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.first = torch.tensor(first, dtype=torch.int32).to(device)
+
+    def launch(self, update=False, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+        _lib.check(_lib.load().cream_adamw_step(_p(self.jobs), _p(self.first), self.n, self.total, 1 if update else 0,
+                                                lr, beta1, beta2, eps, step, _stream()), "cream_adamw_step")
 
 
-MIRROR = Mirror()
+class BlockOperands:
+    """bf16 operand copies of one block's projection weights in the layouts csrc/gemm_mfma.hip reads:
+    W (out, in) and W^T (in, out) with the super widths as leading dimensions; qkv de-interleaved into
+    its three parts (3, Qmax, in) / (3, in, Qmax); biases as plain bf16 vectors."""
+
+    NAMES = ('qkv', 'proj', 'fc1', 'fc2')
+
+    def __init__(self, blk):
+        at = blk.attn
+        self.mods = (at.qkv, at.proj, blk.fc1, blk.fc2)
+        dev = at.qkv.weight.device
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self.w, self.wt, self.b = [], [], []
+        for name, m in zip(self.NAMES, self.mods):
+            out_f, in_f = m.weight.shape
+            if name == 'qkv':
+                self.w.append(torch.empty((3, out_f // 3, in_f), **bf))
+                self.wt.append(torch.empty((3, in_f, out_f // 3), **bf))
+            else:
+                self.w.append(torch.empty((out_f, in_f), **bf))
+                self.wt.append(torch.empty((in_f, out_f), **bf))
+            self.b.append(torch.empty((out_f,), **bf) if m.bias is not None else None)
+        self.key = self._key()
+        self.versions = None
+        self._table = None
+
+    def _key(self):
+        return tuple(m.weight.data_ptr() for m in self.mods)
+
+    def jobs(self, grads=False, states=None, weight_decay=0.0):
+        """cream_param_jobs of this block's 8 projection tensors (weights with both copies, biases with
+        their bf16 copy).  With `states` (parameter -> (exp_avg, exp_avg_sq)) they are update jobs."""
+        out = []
+        for name, m, w, wt, b in zip(self.NAMES, self.mods, self.w, self.wt, self.b):
+            st = states[m.weight] if states else (None, None)
+            out.append((m.weight, param_job(m.weight.detach(), m.weight.grad if grads else None, st[0], st[1], w, wt,
+                                            deinterleave=(name == 'qkv'), weight_decay=weight_decay)))
+            if m.bias is not None:
+                st = states[m.bias] if states else (None, None)
+                out.append((m.bias, param_job(m.bias.detach(), m.bias.grad if grads else None, st[0], st[1], b, None)))
+        return out
+
+    def refresh(self):
+        if self._table is None:
+            self._table = JobTable([j for _, j in self.jobs()], self.w[0].device)
+        self._table.launch(update=False)
+        self.mark_fresh()
+
+    def mark_fresh(self):
+        self.versions = tuple(p._version for m in self.mods for p in (m.weight, m.bias) if p is not None)
+
+    def stale(self):
+        return self.versions != tuple(p._version for m in self.mods for p in (m.weight, m.bias) if p is not None)
+
+
+_OPS_KEY = '_cream_operands'
+
+
+def operands(blk, fresh=True):
+    """The block's BlockOperands (created on first use, re-created when the module moved), refreshed
+    if a parameter's version counter moved since the copies were written.  The native optimizer
+    (engine.NativeAdamW) rewrites the copies in its own kernel and marks them fresh."""
+    ops = blk.__dict__.get(_OPS_KEY)
+    if ops is None or ops.key != ops._key():
+        ops = blk.__dict__[_OPS_KEY] = BlockOperands(blk)
+    if fresh and ops.stale():
+        ops.refresh()
+    return ops
+
+
+def refresh_operands(model, force=True):
+    """Re-derive the operand copies of every block that has them (checkpoint load, foreign optimizer)."""
+    for m in model.modules():
+        ops = m.__dict__.get(_OPS_KEY)
+        if ops is not None and (force or ops.stale()):
+            ops.refresh()
+
+
 _grad_ready_hooks = []
 
 
@@ -413,7 +495,9 @@ def supported(blk, x):
             and fused_attention.grid_of(x.shape[1], a.max_relative_position) is not None
             and a.rel_pos_embed_k.embeddings_table_v.shape[1] == 64
             and blk.sample_embed_dim % 8 == 0 and blk.sample_ffn_embed_dim_this_layer % 8 == 0
-            and blk.sample_out_dim == blk.sample_embed_dim)
+            and blk.sample_out_dim == blk.sample_embed_dim
+            and a.qkv.bias is not None and a.proj.bias is not None and blk.fc1.bias is not None
+            and blk.fc2.bias is not None)
 
 
 def _tables(at):
@@ -433,7 +517,8 @@ def _block_forward(blk, x2d, pend, dp1, B, N):
     Q = at.sample_qk_embed_dim
     F_ = blk.sample_ffn_embed_dim_this_layer
     mr = at.max_relative_position
-    mir = MIRROR.get
+    ops = operands(blk)
+    (wqkv, wproj, w1, w2), (bqkv, bproj, b1, b2) = ops.w, ops.b
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
 
     if pend is None:
@@ -441,19 +526,17 @@ def _block_forward(blk, x2d, pend, dp1, B, N):
         a, mean1, rstd1 = ln_fwd(x, ln1.weight[:E], ln1.bias[:E], ln1.eps)
     else:
         x, a, mean1, rstd1 = add_ln_fwd(x2d, pend[0], pend[1], N, ln1.weight[:E], ln1.bias[:E], ln1.eps)
-    # qkv rows regrouped [q | k | v] from the interleaved super weight (qkv_super.py:72-77);
-    # bias is the plain prefix (qkv_super.py:80-83)
-    wqkv = mir(at.qkv.weight)[:3 * Q, :E].view(Q, 3, E).transpose(0, 1).reshape(3 * Q, E)
-    qkv = linear_fwd(a, wqkv, mir(at.qkv.bias), 3 * Q, E)
+    # qkv rows [q | k | v] = the first Q rows of the de-interleaved parts of the super weight
+    # (qkv_super.py:72-77); bias is the plain prefix (qkv_super.py:80-83)
+    qkv = linear_fwd_seg(a, wqkv, bqkv, 3 * Q, E, Q)
     tabs = tuple(t.detach() for t in _tables(at))
     o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
-    p = linear_fwd(o.view(M, Q), mir(at.proj.weight), mir(at.proj.bias), E, Q)
+    p = linear_fwd(o.view(M, Q), wproj, bproj, E, Q)
     x1, c, mean2, rstd2 = add_ln_fwd(x, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
-    h = linear_fwd(c, mir(blk.fc1.weight), mir(blk.fc1.bias), F_, E)
-    g = gelu_fwd(h)
-    f = linear_fwd(g, mir(blk.fc2.weight), mir(blk.fc2.bias), E, F_)
+    h, g = linear_gelu_fwd(c, w1, b1, F_, E)
+    f = linear_fwd(g, w2, b2, E, F_)
     dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
-    return x1, f, dims, (x, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
+    return x1, f, dims, (x, mean1, rstd1, a, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
 
 
 def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
@@ -466,21 +549,20 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     at = blk.attn
     B, N, E, H, Q, F_, mr, scale = dims
     M = B * N
-    x, mean1, rstd1, a, wqkv, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g = saved
-    mir = MIRROR.get
+    x, mean1, rstd1, a, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g = saved
+    wqkv_t, wproj_t, w1_t, w2_t = operands(blk).wt
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
 
     jobs = GradJobs()
     # ---- MLP branch -----------------------------------------------------------------------
-    pw2 = wgrad_parts_async(df, g)
+    pw2, _ = wgrad_parts_async(df, g)
     jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
     jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
-    dg = linear_dgrad(df, mir(blk.fc2.weight), E, F_)
-    dh, pb1 = gelu_bwd_colsum(dg, h)
-    pw1 = wgrad_parts_async(dh, c)
+    dh, pb1 = linear_dgrad_dgelu(df, w2_t, h, E, F_)         # (df . W2) * gelu'(h) + fc1 bias partials
+    pw1, _ = wgrad_parts_async(dh, c)
     jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
     jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
-    dc = linear_dgrad(dh, mir(blk.fc1.weight), F_, E)
+    dc = linear_dgrad(dh, w1_t, F_, E)
     # dx1 = dx2 + dLN2(dc); dp = s1 * dx1 is the gradient of the proj output, and its column sums
     # (proj bias) come out of the same pass
     dx1, dp, pl2 = ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight[:E], dx2, dp1, N, True)
@@ -490,9 +572,9 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
 
     # ---- attention branch ---------------------------------------------------------------------
-    pwp = wgrad_parts_async(dp, o.view(M, Q))
+    pwp, _ = wgrad_parts_async(dp, o.view(M, Q))
     jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
-    do = linear_dgrad(dp, mir(at.proj.weight), E, Q)
+    do = linear_dgrad(dp, wproj_t, E, Q)
     tabs_p = _tables(at)
     dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
                                               *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
@@ -501,11 +583,10 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     for i, t in enumerate(tabs_p):                                     # dtab (B*H, 4, 32, 64)
         jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
     dqkv2d = dqkv.view(M, 3 * Q)
-    pwq = wgrad_parts_async(dqkv2d, a)                                       # rows [q | k | v]
+    pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)                  # rows [q | k | v]; bias rides along
     jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
-    pbq = colsum128(dqkv2d)
     jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
-    da = linear_dgrad(dqkv2d, wqkv, 3 * Q, E)
+    da = linear_dgrad_seg(dqkv2d, wqkv_t, 3 * Q, E, Q)
     dx, df_prev, pl1 = ln_bwd_raw(da, x, mean1, rstd1, ln1.weight[:E], dx1, prev_scale, N, want_prev)
     jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
     jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
@@ -545,17 +626,18 @@ def _block_desc(blk, B, N):
     operand copies of the super weights, LayerNorm parameters, tables — all read in place) is
     built once per block and device; per call only the sampled extents are filled in."""
     at = blk.attn
+    ops = operands(blk)                                              # (refreshes stale copies)
     ent = blk.__dict__.get(_DESC_KEY)
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
-    key = (at.qkv.weight.data_ptr(), ln1.weight.data_ptr())          # moves when the module changes device / storage
+    key = (ops.key, ops.w[0].data_ptr(), ln1.weight.data_ptr())      # moves when the module changes device / storage
     if ent is None or ent[1] != key:
-        mir = MIRROR.get
         t = _lib.BlockDesc()
-        ms = [mir(p) for p in _block_params(blk)]
-        t.wqkv, t.bqkv, t.ld_qkv = ms[0].data_ptr(), ms[1].data_ptr(), ms[0].stride(0)
-        t.wproj, t.bproj, t.ld_proj = ms[2].data_ptr(), ms[3].data_ptr(), ms[2].stride(0)
-        t.w1, t.b1, t.ld_w1 = ms[4].data_ptr(), ms[5].data_ptr(), ms[4].stride(0)
-        t.w2, t.b2, t.ld_w2 = ms[6].data_ptr(), ms[7].data_ptr(), ms[6].stride(0)
+        (wq, wp, w1, w2), (wqt, wpt, w1t, w2t), (bq, bp, b1, b2) = ops.w, ops.wt, ops.b
+        t.wqkv, t.wqkv_t, t.bqkv = wq.data_ptr(), wqt.data_ptr(), bq.data_ptr()
+        t.ld_qkv, t.ld_qkv_t, t.seg_qkv, t.seg_qkv_t = wq.stride(1), wqt.stride(1), wq.stride(0), wqt.stride(0)
+        t.wproj, t.wproj_t, t.bproj, t.ld_proj, t.ld_proj_t = wp.data_ptr(), wpt.data_ptr(), bp.data_ptr(), wp.stride(0), wpt.stride(0)
+        t.w1, t.w1_t, t.b1, t.ld_w1, t.ld_w1_t = w1.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w1.stride(0), w1t.stride(0)
+        t.w2, t.w2_t, t.b2, t.ld_w2, t.ld_w2_t = w2.data_ptr(), w2t.data_ptr(), b2.data_ptr(), w2.stride(0), w2t.stride(0)
         t.ln1_g, t.ln1_b, t.ln2_g, t.ln2_b = (ln1.weight.data_ptr(), ln1.bias.data_ptr(), ln2.weight.data_ptr(),
                                               ln2.bias.data_ptr())
         tabs = _tables(at)
@@ -563,14 +645,10 @@ def _block_desc(blk, B, N):
         t.ldt = tabs[0].stride(0)
         t.eps1, t.eps2 = ln1.eps, ln2.eps
         t.mr = at.max_relative_position
-        ent = blk.__dict__[_DESC_KEY] = (t, key, ms)
-    else:
-        for p, m in zip(_block_params(blk), ent[2]):                 # operand copies still current?
-            MIRROR.get(p)
+        ent = blk.__dict__[_DESC_KEY] = (t, key)
     d = _lib.BlockDesc.from_buffer_copy(ent[0])
     d.B, d.N, d.E, d.H, d.F = B, N, blk.sample_embed_dim, at.sample_num_heads, blk.sample_ffn_embed_dim_this_layer
     d.gh, d.gw = fused_attention.grid_of(N, d.mr)
-    d.wgrad_split = _wgrad_split(B * N)
     d.attn_scale = float(at.sample_scale)
     return d
 
@@ -597,7 +675,7 @@ def _block_grads(blk):
 
 def _ws_layout(d):
     """(fwd bytes, off_x, off_x1, off_f, bwd bytes, off_dx, off_df_prev, off_pl1) of a configuration."""
-    key = (d.B, d.N, d.E, d.H, d.F, d.wgrad_split)
+    key = (d.B, d.N, d.E, d.H, d.F)
     hit = _ws_cache.get(key)
     if hit is None:
         lib = _lib.load()
@@ -650,7 +728,7 @@ class StackFunction(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         dev = x.device
-        stream = _gemm_stream(dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         sc_ptr = scales.data_ptr() if scales is not None else 0
         cur, pend_f, pend_s = x.data_ptr(), 0, 0
         descs, wss, xptrs = [], [], []
@@ -708,11 +786,10 @@ class StackFunction(torch.autograd.Function):
         M = B * N
         lib = _lib.load()
         dev = dout.device
-        stream = _gemm_stream(dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if WGRAD_SIDE_STREAM:
             side_st = _side_stream(dev)
-            with torch.cuda.stream(side_st):
-                side = _gemm_stream(dev)
+            side = ctypes.c_void_p(side_st.cuda_stream)
         else:
             side_st, side = None, stream
         sc_ptr = scales.data_ptr() if scales is not None else 0

@@ -33,58 +33,6 @@ SEARCH_SPACES = {
 }
 
 
-def enable_gemm_selection(size='S', batch=128):
-    """Use the offline-selected GEMM-library kernels for the step's GEMM shapes
-    (cream_amd/tuning/gemm_<size>_b<batch>.csv, produced by tools/tune_gemms.py through
-    PyTorch's TunableOp over hipBLASLt / rocBLAS solutions).  Selection only — nothing is
-    tuned at run time.  Returns True when the table was loaded (its validators — library
-    versions, GPU arch — must match this machine)."""
-    import os
-    import tempfile
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning',
-                        f'gemm_{size}_b{batch}.csv')
-    if not (torch.cuda.is_available() and os.path.exists(path)):
-        return False
-    _block.gemm_table_load(path)         # the native dispatcher of the fused blocks (csrc/gemm_lt.cpp)
-    lt = path[:-4] + '_lt.csv'           # problems re-tuned over the library's own solutions only
-    if os.path.exists(lt):               # (tools/tune_gemms_lt_only.py); later entries override
-        _block.gemm_table_load(lt)
-    tun = torch.cuda.tunable             # the GEMMs left to the framework (stem, head, module path)
-    tun.enable(True)
-    tun.tuning_enable(False)
-    # read-only use of the committed table (8 ranks share it): whatever the library writes at
-    # exit goes to a per-process scratch file, never back into the package
-    if hasattr(tun, 'write_file_on_exit'):
-        tun.write_file_on_exit(False)
-    try:
-        ok = bool(tun.read_file(path))
-    except Exception:
-        ok = False
-    tun.set_filename(os.path.join(tempfile.gettempdir(), f'cream_tunableop_{os.getpid()}.csv'),
-                     insert_device_ordinal=False)
-    return ok
-
-
-def prewarm(model, images, target, choices, amp_dtype=torch.bfloat16):
-    """Touch every GEMM problem of the search space once (one forward/backward of a one-block
-    sub-network per (embed_dim, num_heads, mlp_ratio) combination) so that the GEMM library's
-    lazily loaded kernels and the dispatcher's plans exist before the first measured step; the
-    sub-network shapes of a step are random, so without this first uses keep appearing for
-    hundreds of steps.  Gradients written here are discarded (zero-filled afterwards)."""
-    import itertools
-    was_training = model.training
-    model.train()
-    for E, H, R in itertools.product(choices['embed_dim'], choices['num_heads'], choices['mlp_ratio']):
-        model.set_sample_config(dict(layer_num=1, embed_dim=[E], num_heads=[H], mlp_ratio=[R]))
-        with torch.autocast(device_type=images.device.type, dtype=amp_dtype, enabled=amp_dtype != torch.float32):
-            loss = soft_target_cross_entropy(model(images), target)
-        loss.backward()
-    for p in model.parameters():
-        if p.grad is not None:
-            p.grad.zero_()
-    model.train(was_training)
-
-
 def sample_configs(choices):
     """supernet_engine.py:13-24.  Draw order: depth, mlp_ratio x depth, num_heads x depth,
     then ONE embed_dim shared by all layers."""
@@ -126,15 +74,86 @@ def param_groups(model, weight_decay=0.05):
     return [{'params': no_decay, 'weight_decay': 0.0}, {'params': decay, 'weight_decay': weight_decay}]
 
 
+class NativeAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias-corrected moments, no amsgrad) for a
+    CUDA model as ONE kernel launch per step over every tensor (csrc/optim.hip), which also rewrites
+    the bf16 operand copies (and their transposes) the block GEMMs read.  State layout = torch's
+    (`exp_avg`, `exp_avg_sq`, `step` per parameter), so checkpoints move between the two.
+
+    Every parameter must have a `.grad` tensor when `step()` runs (the trainer zero-fills instead of
+    setting None — SURVEY 8e: under the reference's torch 1.7 every tensor that was active once keeps
+    receiving weight decay and moment decay); the device-resident job table is rebuilt only if a
+    gradient tensor was replaced (e.g. when a GradReducer re-homes them into its arena)."""
+
+    def __init__(self, model, param_groups, lr, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0))
+        self.model = model
+        self._steps = 0
+        self._table = None
+        self._grads = ()
+        self._plist = ()
+        self._ops = []
+        for g in self.param_groups:
+            for p in g['params']:
+                self.state[p] = dict(exp_avg=torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                     exp_avg_sq=torch.zeros_like(p, memory_format=torch.contiguous_format))
+
+    def _build(self):
+        wd = {p: g['weight_decay'] for g in self.param_groups for p in g['params']}
+        states = {p: (st['exp_avg'], st['exp_avg_sq']) for p, st in self.state.items()}
+        for p in wd:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        jobs, done, self._ops = [], set(), []
+        for m in self.model.modules():
+            if hasattr(m, 'attn') and hasattr(m, 'fc1') and hasattr(m, 'fc2'):
+                ops = _block.operands(m, fresh=False)
+                self._ops.append(ops)
+                for p, j in ops.jobs(grads=True, states=states):
+                    j.weight_decay = wd[p]
+                    jobs.append(j)
+                    done.add(p)
+        for p in wd:
+            if p not in done:
+                jobs.append(_block.param_job(p.detach(), p.grad, states[p][0], states[p][1], weight_decay=wd[p]))
+        self._table = _block.JobTable(jobs, next(iter(wd)).device)
+        self._plist = tuple(wd)
+        self._grads = tuple(p.grad for p in wd)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        if self._table is None or any(p.grad is not g for p, g in zip(self._plist, self._grads)):
+            self._build()
+        g0 = self.param_groups[0]
+        lr = g0['lr']
+        assert all(g['lr'] == lr for g in self.param_groups), "NativeAdamW: one learning rate for all groups"
+        self._steps += 1
+        self._table.launch(update=True, lr=float(lr), beta1=g0['betas'][0], beta2=g0['betas'][1], eps=g0['eps'],
+                           step=self._steps)
+        for ops in self._ops:
+            ops.mark_fresh()                 # the kernel rewrote every operand copy
+
+    def state_dict(self):
+        for st in self.state.values():
+            st['step'] = torch.tensor(float(self._steps))
+        return super().state_dict()
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        steps = [int(st['step']) for st in self.state.values() if 'step' in st]
+        self._steps = max(steps) if steps else 0
+        self._table = None                   # moments were re-created: new pointers
+
+
 def build_optimizer(model, lr=5e-4, batch_size=128, world_size=1, weight_decay=0.05):
-    """AdamW with the linear lr scaling of supernet_train.py:294: lr * batch * world / 512."""
+    """AdamW with the linear lr scaling of supernet_train.py:294: lr * batch * world / 512.  On the
+    GPU the native single-launch optimizer; on the CPU (host-logic tests) torch.optim.AdamW."""
     scaled = lr * batch_size * world_size / 512.0
-    fused = next(model.parameters()).is_cuda
-    opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=scaled, betas=(0.9, 0.999), eps=1e-8,
-                            fused=fused)
-    # the fused blocks read bf16 operand copies of the master weights: re-convert after every step
-    opt.register_step_post_hook(lambda *_: _block.MIRROR.refresh_all(force=True))
-    return opt
+    groups = param_groups(model, weight_decay)
+    if next(model.parameters()).is_cuda:
+        return NativeAdamW(model, groups, lr=scaled, betas=(0.9, 0.999), eps=1e-8)
+    return torch.optim.AdamW(groups, lr=scaled, betas=(0.9, 0.999), eps=1e-8)
 
 
 class SupernetTrainer:
@@ -184,7 +203,7 @@ class SupernetTrainer:
         loss = self.forward_backward(images, target)
         if self.max_norm and self.max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
-        self.optimizer.step()                # (its post-hook refreshes the bf16 operand copies)
+        self.optimizer.step()                # (the native optimizer also rewrites the bf16 operand copies)
         return loss
 
 
@@ -246,7 +265,7 @@ def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scal
     ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu',
                                                                          weights_only=False)
     model.load_state_dict(ckpt['model'])
-    _block.MIRROR.refresh_all(force=True)
+    _block.refresh_operands(model, force=True)
     start_epoch = 0
     if not eval_only and all(k in ckpt for k in ('optimizer', 'lr_scheduler', 'epoch')):
         if optimizer is not None:

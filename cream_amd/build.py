@@ -70,7 +70,7 @@ def build(force=False, verbose=False):
         cmd = [hipcc] + HIPCC_FLAGS + [f"-I{INCLUDE}", f"-I{CSRC}", f'-DCREAM_BUILD_TAG="{tag}"',
                                        "-x", "hip" if src.endswith(".hip") else "c++", "-c", src, "-o", obj]
         if not src.endswith(".hip"):
-            # plain host C++: no offload needed (HIP / hipBLASLt host APIs only)
+            # plain host C++: no offload needed (HIP host APIs only)
             cmd = [c for c in cmd if not c.startswith("--offload-arch")]
             cmd[cmd.index("-x") + 1] = "c++"
             cmd += ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
@@ -88,10 +88,8 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("cream_amd: HIP compilation failed")
-    # libhipblaslt: resolved at load time against the copy already mapped by PyTorch-ROCm (same
-    # SONAME; the offline kernel selection refers to THAT library's solution indices)
-    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipblaslt",
-                                                                                     "-lpthread"]
+    # no vendor GEMM library: every kernel of the path is in csrc/
+    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

@@ -443,18 +443,6 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J) {
     }
 }
 
-// ---- qkv weight regrouping: dst[(j*Q + i)][:E] = src[3*i + j][:E]  (qkv_super.py:72-77) -----------
-__global__ __launch_bounds__(256) void qkv_regroup_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src,
-                                                          int Q, int E8, int64_t ld) {
-    const int total = 3 * Q * E8;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int row = i / E8, c8 = i - row * E8;            // dst row = j*Q + q
-        const int j = row / Q, q = row - j * Q;
-        *reinterpret_cast<u32x4v*>(dst + (int64_t)row * E8 * 8 + c8 * 8) =
-            *reinterpret_cast<const u32x4v*>(src + (int64_t)(3 * q + j) * ld + c8 * 8);
-    }
-}
-
 int grid_for(int64_t n_items, int per_block) {
     const int64_t b = (n_items + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
@@ -565,14 +553,6 @@ int cream_colsum(float* partial, const void* a, int M, int C, void* stream)
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
-int cream_qkv_regroup(void* dst, const void* src, int Q, int E, int64_t ld, void* stream)
-{
-    if (Q <= 0 || E <= 0 || E % 8 || ld < E || ld % 8) return CREAM_ERR_BAD_ARG;
-    if (!dst || !src || ((uintptr_t)dst | (uintptr_t)src) % 16) return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(qkv_regroup_kernel, dim3(grid_for((int64_t)3 * Q * (E / 8), 256)), dim3(256), 0, (hipStream_t)stream,
-                       (uint16_t*)dst, (const uint16_t*)src, Q, E / 8, ld);
-    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
-}
 
 int cream_colsum128_slabs(int M) { return M <= 0 ? 0 : (M + CS_ROWS - 1) / CS_ROWS; }
 

@@ -6,7 +6,7 @@
 // 251-287 (pre-norm block, drop-path on both branches) with AttentionSuper.forward
 // (model/module/multihead_super.py:133-160) and the weight-entangled Linear/LayerNorm supers; the
 // backward is what autograd derives for it.  Every kernel is the one the per-op C ABI exposes
-// (csrc/block_ops.hip, attn_rpe2d.hip, gemm_lt.cpp); this file only sequences them over two HIP
+// (csrc/block_ops.hip, attn_rpe2d.hip, gemm_mfma.hip); this file only sequences them over two HIP
 // streams: the weight-gradient GEMMs and the gradient finalisation run on `side_stream` behind
 // events, overlapping the HBM-bound passes of the main chain.
 //
@@ -32,23 +32,28 @@ struct Bump {
 };
 
 struct Dims {
-    int64_t B, N, E, H, F, Q, M, NP, slabs, P, S;
+    int64_t B, N, E, H, F, Q, M, NP, slabs, P;
+    int64_t S2, S1, Sp, Sq;                                       // split factors of the four weight gradients
 };
 Dims dims_of(const cream_block_desc* d) {
     Dims x;
     x.B = d->B; x.N = d->N; x.E = d->E; x.H = d->H; x.F = d->F;
     x.Q = 64 * x.H; x.M = x.B * x.N; x.NP = cream_attn_rpe2d_padded_len(d->N);
-    x.slabs = cream_colsum128_slabs((int)x.M); x.P = cream_ln_partials(); x.S = d->wgrad_split;
+    x.slabs = cream_colsum128_slabs((int)x.M); x.P = cream_ln_partials();
+    x.S2 = cream_linear_wgrad_splits((int)x.M, (int)x.E, (int)x.F);
+    x.S1 = cream_linear_wgrad_splits((int)x.M, (int)x.F, (int)x.E);
+    x.Sp = cream_linear_wgrad_splits((int)x.M, (int)x.E, (int)x.Q);
+    x.Sq = cream_linear_wgrad_splits((int)x.M, 3 * (int)x.Q, (int)x.E);
     return x;
 }
 bool desc_ok(const cream_block_desc* d) {
-    return d && d->B > 0 && d->N > 0 && d->E > 0 && d->H > 0 && d->F > 0 && d->E % 8 == 0 && d->F % 8 == 0 && d->wgrad_split > 0 &&
-           ((int64_t)d->B * d->N) % d->wgrad_split == 0 && d->wqkv && d->bqkv && d->wproj && d->bproj && d->w1 && d->b1 && d->w2 &&
-           d->b2 && d->ln1_g && d->ln1_b && d->ln2_g && d->ln2_b && d->tkv && d->tkh && d->tvv && d->tvh;
+    return d && d->B > 0 && d->N > 0 && d->E > 0 && d->H > 0 && d->F > 0 && d->E % 8 == 0 && d->F % 8 == 0 && d->wqkv &&
+           d->wqkv_t && d->bqkv && d->wproj && d->wproj_t && d->bproj && d->w1 && d->w1_t && d->b1 && d->w2 && d->w2_t && d->b2 &&
+           d->ln1_g && d->ln1_b && d->ln2_g && d->ln2_b && d->tkv && d->tkh && d->tvv && d->tvh;
 }
 
 struct FwdLayout {
-    int64_t xsum, mean1, rstd1, mean2, rstd2, a, wqkv, qkv, o, lse, sp, p, x1, c, h, g, f, total;
+    int64_t xsum, mean1, rstd1, mean2, rstd2, a, qkv, o, lse, sp, p, x1, c, h, g, f, total;
 };
 FwdLayout fwd_layout(const Dims& x) {
     Bump b;
@@ -56,7 +61,6 @@ FwdLayout fwd_layout(const Dims& x) {
     L.xsum = b.take(x.M * x.E * 4);
     L.mean1 = b.take(x.M * 4); L.rstd1 = b.take(x.M * 4); L.mean2 = b.take(x.M * 4); L.rstd2 = b.take(x.M * 4);
     L.a = b.take(x.M * x.E * 2);
-    L.wqkv = b.take(3 * x.Q * x.E * 2);
     L.qkv = b.take(x.M * 3 * x.Q * 2);
     L.o = b.take(x.M * x.Q * 2);
     L.lse = b.take(x.B * x.H * x.N * 4);
@@ -72,12 +76,11 @@ FwdLayout fwd_layout(const Dims& x) {
 }
 
 struct BwdLayout {
-    int64_t dg, dh, pb1, dc, dx1, dp, pl2, dout, dqkv, dlt, qe, de, delta, dtab, pbq, da, dx, df_prev, pl1, pw2, pw1, pwp, pwq, total;
+    int64_t dh, pb1, dc, dx1, dp, pl2, dout, dqkv, dlt, qe, de, delta, dtab, pbq, da, dx, df_prev, pl1, pw2, pw1, pwp, pwq, total;
 };
 BwdLayout bwd_layout(const Dims& x) {
     Bump b;
     BwdLayout L;
-    L.dg = b.take(x.M * x.F * 2);
     L.dh = b.take(x.M * x.F * 2);
     L.pb1 = b.take(x.slabs * x.F * 4);
     L.dc = b.take(x.M * x.E * 2);
@@ -91,15 +94,15 @@ BwdLayout bwd_layout(const Dims& x) {
     L.de = b.take(x.B * x.H * x.NP * 32 * 2);
     L.delta = b.take(x.B * x.H * x.NP * 4);
     L.dtab = b.take(x.B * x.H * 4 * 32 * 64 * 4);
-    L.pbq = b.take(x.slabs * 3 * x.Q * 4);
+    L.pbq = b.take(x.Sq * 3 * x.Q * 4);
     L.da = b.take(x.M * x.E * 2);
     L.dx = b.take(x.M * x.E * 4);
     L.df_prev = b.take(x.M * x.E * 2);
     L.pl1 = b.take(x.P * 3 * x.E * 4);
-    L.pw2 = b.take(x.S * x.E * x.F * 2);
-    L.pw1 = b.take(x.S * x.F * x.E * 2);
-    L.pwp = b.take(x.S * x.E * x.Q * 2);
-    L.pwq = b.take(x.S * 3 * x.Q * x.E * 2);
+    L.pw2 = b.take(x.S2 * x.E * x.F * 4);
+    L.pw1 = b.take(x.S1 * x.F * x.E * 4);
+    L.pwp = b.take(x.Sp * x.E * x.Q * 4);
+    L.pwq = b.take(x.Sq * 3 * x.Q * x.E * 4);
     L.total = b.off;
     return L;
 }
@@ -162,9 +165,10 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
         TRY(cream_ln_fwd(at<void>(ws, L.a), at<float>(ws, L.mean1), at<float>(ws, L.rstd1), x_in, d->ln1_g, d->ln1_b, M, E, d->eps1,
                          stream));
     }
-    // qkv: rows regrouped [q | k | v] from the interleaved super weight, bias = plain prefix
-    TRY(cream_qkv_regroup(at<void>(ws, L.wqkv), d->wqkv, Q, E, d->ld_qkv, stream));
-    TRY(cream_linear_fwd(at<void>(ws, L.qkv), at<void>(ws, L.a), at<void>(ws, L.wqkv), d->bqkv, M, 3 * Q, E, E, stream));
+    // qkv: rows [q | k | v] = the first Q rows of the three de-interleaved parts, bias = plain prefix
+    // (qkv_super.py:72-83)
+    TRY(cream_linear_fwd_seg(at<void>(ws, L.qkv), at<void>(ws, L.a), d->wqkv, d->bqkv, M, 3 * Q, E, d->ld_qkv, Q, d->seg_qkv,
+                             stream));
     const uint16_t* qkv = at<uint16_t>(ws, L.qkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
     TRY(cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
@@ -174,8 +178,8 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     // x1 = x + s1 * p ; c = LN2(x1)
     TRY(cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
                          at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
-    TRY(cream_linear_fwd(at<void>(ws, L.h), at<void>(ws, L.c), d->w1, d->b1, M, F, E, d->ld_w1, stream));
-    TRY(cream_gelu_fwd(at<void>(ws, L.g), at<void>(ws, L.h), (int64_t)M * F, stream));
+    // fc1 + gelu in one pass (h kept for the backward)
+    TRY(cream_linear_gelu_fwd(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F, E, d->ld_w1, stream));
     TRY(cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
 }
@@ -198,24 +202,26 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     const Dims D = dims_of(d);
     const FwdLayout FL = fwd_layout(D);
     const BwdLayout L = bwd_layout(D);
-    const int M = (int)D.M, E = (int)D.E, Q = (int)D.Q, F = (int)D.F, N = (int)D.N, S = (int)D.S, P = (int)D.P, slabs = (int)D.slabs;
+    const int M = (int)D.M, E = (int)D.E, Q = (int)D.Q, F = (int)D.F, N = (int)D.N, P = (int)D.P, slabs = (int)D.slabs;
+    const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
     hipStream_t main = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : main;
 
     // ---- MLP branch ----------------------------------------------------------------------------
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // df, g complete on main
-    TRY(cream_linear_wgrad_parts(at<void>(ws, L.pw2), df, at<void>(fws, FL.g), M, E, F, S, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.dg), df, d->w2, M, E, F, d->ld_w2, main));
-    TRY(cream_gelu_bwd_colsum(at<void>(ws, L.dh), at<float>(ws, L.pb1), at<void>(ws, L.dg), at<void>(fws, FL.h), M, F, main));
+    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
+    // dh = (df . W2) * gelu'(h) and the fc1 bias partials in the dgrad's epilogue
+    TRY(cream_linear_dgrad_dgelu(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+                                 main));
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    TRY(cream_linear_wgrad_parts(at<void>(ws, L.pw1), at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1, M, F, E, d->ld_w1, main));
+    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
+    TRY(cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
     TRY(cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    TRY(cream_linear_wgrad_parts(at<void>(ws, L.pwp), at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, S, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj, M, E, Q, d->ld_proj, main));
+    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+    TRY(cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
@@ -224,9 +230,9 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    TRY(cream_linear_wgrad_parts(at<void>(ws, L.pwq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, S, side));
-    TRY(cream_colsum128(at<float>(ws, L.pbq), dqkv, M, 3 * Q, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.da), dqkv, at<void>(fws, FL.wqkv), M, 3 * Q, E, E, main));
+    // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
+    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
+    TRY(cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
     TRY(cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
                      at<float>(fws, FL.mean1), at<float>(fws, FL.rstd1), d->ln1_g, at<float>(ws, L.dx1), prev_scale, N, M, E, main));
 
@@ -240,20 +246,20 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         J[n].cols = cols; J[n].interleave = interleave; J[n].src_bf16 = bf16; J[n].reserved = 0;
         ++n;
     };
-    job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S, (int64_t)E * F, E, F, 0, 1);
+    job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, 0);
     job(G->b2, E, pb2, pb2_parts, pb2_pstride, 1, E, 0, 0);
-    job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S, (int64_t)F * E, F, E, 0, 1);
+    job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, 0);
     job(G->b1, F, at<void>(ws, L.pb1), slabs, F, 1, F, 0, 0);
     job(G->ln2_g, E, at<float>(ws, L.pl2), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln2_b, E, at<float>(ws, L.pl2) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->bproj, E, at<float>(ws, L.pl2) + 2 * E, P, 3 * (int64_t)E, 1, E, 0, 0);
-    job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), S, (int64_t)E * Q, E, Q, 0, 1);
+    job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, 0);
     const int nb = 2 * d->mr + 2;
     float* tabs[4] = {G->tkv, G->tkh, G->tvv, G->tvh};
     for (int t = 0; t < 4; ++t)
         job(tabs[t], G->ldt, at<float>(ws, L.dtab) + t * 32 * 64, d->B * d->H, 4 * 32 * 64, nb, 64, 0, 0);
-    job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), S, 3 * (int64_t)Q * E, 3 * Q, E, Q, 1);
-    job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), slabs, 3 * Q, 1, 3 * Q, 0, 0);
+    job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, 0);
+    job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     job(G->ln1_g, E, at<float>(ws, L.pl1), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     return cream_grad_finalize(J, n, side);

@@ -1,0 +1,158 @@
+// gemm_mfma.hip — C entry points of the hand-written MFMA GEMMs (kernels: gemm_mfma.hpp).
+//
+// Reference semantics: LinearSuper.forward / qkv_super.forward = F.linear on the active block
+// W[:out, :in] of the super weight (AutoFormer/model/module/Linear_super.py:38-54, :71-81;
+// qkv_super.py:45-55, :72-83), erf-GELU between fc1 and fc2 (supernet_transformer.py:14-16,
+// :275-285) and what autograd derives for them.  The weight operands are bf16 COPIES of the fp32
+// master weights laid out for these kernels by cream_adamw_step (csrc/optim.hip):
+//   * W    (out x in, ld = super in)        forward operand, read in place as W[:N, :K];
+//   * W^T  (in x out, ld = super out)       dgrad operand (makes dgrad the same K-contiguous product);
+//   * qkv: the interleaved super weight (row 3 i + j = output i of q/k/v part j, qkv_super.py:75)
+//     de-interleaved ONCE per optimizer step into three (Qmax x in) matrices [q | k | v] and their
+//     transposes — the sampled row gather of every forward becomes plain segment addressing.
+//
+// Tile choice (measured on the MI355X, profiles/r02_gemm_probe.txt): 128x128 tiles (2 workgroups
+// per CU) for wide outputs, 128x64 (3 per CU) for N < 640 where 128-wide tiles leave CUs idle in
+// the last round (M = 197 x 128 rows against 256 CUs).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cream_amd.h"
+#include "gemm_mfma.hpp"
+
+namespace {
+using namespace cream;
+using namespace cream::gemm;
+
+template <int EPI>
+int launch_nt(const NtParams& p, hipStream_t st)
+{
+    if (p.N >= 640) {
+        constexpr int BM = 128, BN = 128;
+        const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, 2>), dim3(grid), dim3(256), 0, st, p);
+    } else {
+        constexpr int BM = 128, BN = 64;
+        const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, 3>), dim3(grid), dim3(256), 0, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// common argument checks of the NT products: C(M x N) = A(M x K) . B(N x K)^T
+int check_nt(const void* out, const void* a, const void* b, int M, int N, int K, int64_t ldb, int kmin_ld)
+{
+    if (M < 0 || N <= 0 || K <= 0 || ldb < kmin_ld) return CREAM_ERR_BAD_ARG;
+    if (N % 8 || K % 8 || ldb % 8) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return 1;                                       // empty problem: nothing to do
+    if (!out || !a || !b || !aligned16(out) || !aligned16(a) || !aligned16(b)) return CREAM_ERR_BAD_ARG;
+    return CREAM_OK;
+}
+
+NtParams plain(void* out, const void* a, const void* b, int M, int N, int K, int64_t ldb)
+{
+    NtParams p{};
+    p.A = (const uint16_t*)a; p.lda = K;
+    p.B = (const uint16_t*)b; p.ldb = ldb;
+    p.nseg = N; p.kseg = K; p.nseg_stride = 0; p.kseg_stride = 0;
+    p.M = M; p.N = N; p.K = K;
+    p.out = (uint16_t*)out; p.ldo = N;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cream_gemm_rows_per_colsum_slab(void) { return 128; }
+
+int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K, int64_t ldw,
+                     void* stream)
+{
+    const int rc = check_nt(out, x, w, M, N, K, ldw, K);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    NtParams p = plain(out, x, w, M, N, K, ldw);
+    p.bias = (const uint16_t*)bias;
+    return launch_nt<EPI_BIAS>(p, (hipStream_t)stream);
+}
+
+int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K, int64_t ldw,
+                         int nseg, int64_t nseg_stride, void* stream)
+{
+    const int rc = check_nt(out, x, w, M, N, K, ldw, K);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    if (nseg <= 0 || nseg % 8 || (int64_t)3 * nseg < N || nseg_stride % 8) return CREAM_ERR_BAD_ARG;
+    NtParams p = plain(out, x, w, M, N, K, ldw);
+    p.bias = (const uint16_t*)bias;
+    p.nseg = nseg; p.nseg_stride = nseg_stride;
+    return launch_nt<EPI_BIAS>(p, (hipStream_t)stream);
+}
+
+int cream_linear_gelu_fwd(void* h, void* g, const void* x, const void* w, const void* bias, int M, int N, int K,
+                          int64_t ldw, void* stream)
+{
+    const int rc = check_nt(h, x, w, M, N, K, ldw, K);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    if (!g || !bias || !aligned16(g)) return CREAM_ERR_BAD_ARG;
+    NtParams p = plain(h, x, w, M, N, K, ldw);
+    p.bias = (const uint16_t*)bias;
+    p.out2 = (uint16_t*)g;
+    return launch_nt<EPI_BIAS_GELU>(p, (hipStream_t)stream);
+}
+
+int cream_linear_dgrad(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt, void* stream)
+{
+    // dx(M x K) = dy(M x N) . W(N x K)  ==  NT product with B = W^T (K rows, N contiguous)
+    const int rc = check_nt(dx, dy, wt, M, K, N, ldwt, N);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    const NtParams p = plain(dx, dy, wt, M, K, N, ldwt);
+    return launch_nt<EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt, int kseg,
+                           int64_t kseg_stride, void* stream)
+{
+    const int rc = check_nt(dx, dy, wt, M, K, N, ldwt, kseg);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    if (kseg <= 0 || kseg % 64 || N % kseg || kseg_stride % 8) return CREAM_ERR_BAD_ARG;
+    NtParams p = plain(dx, dy, wt, M, K, N, ldwt);
+    p.kseg = kseg; p.kseg_stride = kseg_stride;
+    return launch_nt<EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int cream_linear_dgrad_dgelu(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* h, int M, int N,
+                             int K, int64_t ldwt, void* stream)
+{
+    const int rc = check_nt(dh, dy, wt, M, K, N, ldwt, N);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    if (!colsum_parts || !h || !aligned16(h)) return CREAM_ERR_BAD_ARG;
+    NtParams p = plain(dh, dy, wt, M, K, N, ldwt);
+    p.aux = (const uint16_t*)h; p.ldaux = K;
+    p.colsum = colsum_parts;
+    return launch_nt<EPI_DGELU_COLSUM>(p, (hipStream_t)stream);
+}
+
+int cream_linear_wgrad_splits(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128), steps = (M + 63) / 64;
+    int s = (512 + tiles - 1) / tiles;                          // ~2 workgroups per CU in flight
+    if (s > 32) s = 32;
+    if (s > steps) s = steps;
+    return s < 1 ? 1 : s;
+}
+
+int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S,
+                             void* stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || S <= 0 || N % 8 || K % 8) return CREAM_ERR_BAD_ARG;
+    if (!parts || !dy || !x || !aligned16(dy) || !aligned16(x) || !aligned16(parts)) return CREAM_ERR_BAD_ARG;
+    TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts};
+    const int grid = ((N + 127) / 128) * ((K + 127) / 128) * S;
+    hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+}  // extern "C"

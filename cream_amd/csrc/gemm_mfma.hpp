@@ -1,0 +1,483 @@
+// gemm_mfma.hpp — hand-written MFMA GEMMs of the weight-entangled projections (gfx950).
+//
+// Reference semantics: LinearSuper.forward / qkv_super.forward = F.linear on the active block
+// W[:out, :in] of the super weight (AutoFormer/model/module/Linear_super.py:38-54, :71-81;
+// qkv_super.py:45-55, :72-83), the Mlp around them (supernet_transformer.py:275-285: fc1 -> gelu in
+// fp32 -> fc2) and what autograd derives (dgrad dx = dy . W, wgrad dW = dy^T x).
+//
+// Shapes of the path: M = B*N tokens = 25,216 (128 images x 197), K and N in 320..1792 — a huge M
+// against 5..28 K-steps, so prologue / epilogue / tile quantisation weigh as much as the main loop.
+//
+// "NT" kernel (forward and, on TRANSPOSED operand copies of the weights, dgrad):
+//     C(M x N) = A(M x K) . B(N x K)^T      both operands K-contiguous, bf16, fp32 accumulate
+//   * workgroup = 4 waves (2 x 2), tile BM x BN (128x128 / 128x64 / 64x128 / 64x64), BK = 64;
+//     wave tile (BM/2) x (BN/2) of v_mfma_f32_32x32x16_bf16;
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, no
+//     VGPR round trip); the LDS image is lane-linear [row][8 chunks of 16 B], bank conflicts of the
+//     ds_read_b128 fragment reads are removed by XOR-swizzling the SOURCE chunk with (row >> 1) & 7
+//     (two 128-B rows share one 256-B bank row: with this term the 16 lanes of every b128 lane group
+//     hit 16 distinct 16-B slots) and the same XOR on the read;
+//   * two LDS stages: the loads of K-step s+1 are in flight while step s is multiplied, one barrier
+//     per K-step; 2 (128x128) to 3 (128x64) workgroups per CU overlap each other's barriers,
+//     prologues and epilogues;
+//   * swapped product D^T = B_tile . A_tile^T: a lane owns ONE output row and 4 runs of 4 columns, so
+//     the accumulators leave through LDS as fp32 with 16-byte writes, and every epilogue works on
+//     (row, 8 consecutive columns) chunks: 16-byte coalesced loads of the side inputs (bias, the
+//     pre-GELU activations) and 16-byte row-contiguous stores;
+//   * 1-D grid, XCD-aware tile order (column tiles of one row panel adjacent and on one XCD: the
+//     A panel is fetched from HBM once and re-read from that XCD's L2);
+//   * B addressing covers the weight-entangled layouts without copies: rows may be split in `nseg`
+//     row segments (the q / k / v thirds of the de-interleaved qkv weight) and the contraction in
+//     `kseg` segments (the same thirds on the transposed copy used by dgrad); leading dimension =
+//     super width (the active block W[:N, :K] is read in place).
+// Epilogues (EPI_*): plain store; + bias; + bias, erf-GELU with both h and gelu(h) written (fc1);
+// x gelu'(h) with column sums of the result (fc2 dgrad -> fc1 bias gradient).
+//
+// M, N arbitrary (N % 8 == 0), K % 8 == 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "attn_common.hpp"
+
+namespace cream {
+namespace gemm {
+
+enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU_COLSUM = 3 };
+
+struct NtParams {
+    const uint16_t* A;      // (M x K) bf16, row stride lda
+    const uint16_t* B;      // element (n, k) at B[(n / nseg) * nseg_stride + (n % nseg) * ldb + (k / kseg) * kseg_stride + k % kseg]
+    int64_t lda, ldb, nseg_stride, kseg_stride;
+    int nseg, kseg;         // nseg >= N and kseg >= K for a plain matrix; kseg % 64 == 0 when kseg < K; N <= 3 nseg
+    int M, N, K;
+    uint16_t* out;          // (M x N) bf16, row stride ldo
+    uint16_t* out2;         // EPI_BIAS_GELU: gelu(out), same layout
+    int64_t ldo;
+    const uint16_t* bias;   // (N) bf16 or nullptr                      (EPI_BIAS, EPI_BIAS_GELU)
+    const uint16_t* aux;    // EPI_DGELU_COLSUM: h (M x N) bf16, row stride ldaux
+    int64_t ldaux;
+    float* colsum;          // EPI_DGELU_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
+};
+
+// erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute — three orders below the bf16 resolution of the values written; the
+// library erff costs ~3x the instructions and made the fc1 epilogue as long as the product itself).
+// e = exp(-x^2 / 2) is shared with the density needed by the derivative.
+__device__ __forceinline__ void phi_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float h = 0.5f * q * t * e;                           // 0.5 erfc(z)
+    cdf = x < 0.f ? h : 1.f - h;
+}
+__device__ __forceinline__ float gelu_f(float x) { float c, e; phi_parts(x, c, e); return x * c; }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float c, e;
+    phi_parts(x, c, e);
+    return fmaf(x * 0.3989422804014327f, e, c);
+}
+
+// XCD-aware tile order (bijective for any grid size): workgroup ids are dealt round-robin to the 8
+// XCDs; the remap gives every XCD a CONTIGUOUS range of tiles.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+}
+
+__host__ __device__ constexpr int nt_lds_bytes(int BM, int BN, int NST) {
+    return NST * (BM + BN) * 64 * 2 > BM * (BN + 4) * 4 ? NST * (BM + BN) * 64 * 2 : BM * (BN + 4) * 4;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM x BN tile, WM x WN waves, NST LDS stages (prefetch distance NST - 1 K-steps, counted vmcnt: the
+// loads of later steps stay in flight across the per-step barrier), OCC = workgroups per CU wanted.
+template <int BM, int BN, int WM, int WN, int NST, int EPI, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const NtParams p)
+{
+    constexpr int BK = 64;
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;                 // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;                 // MFMA tiles per wave
+    constexpr int STAGE = (BM + BN) * BK;                       // bf16 elements per stage
+    constexpr int NPIECE = (BM + BN) / 8 / NW;                  // 1-KB pieces (8 rows) per wave and stage
+    constexpr int CP = BN + 4;                                  // fp32 pitch of the epilogue tile
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
+    static_assert(NST >= 2 && NST <= 4, "stages");
+    __shared__ __attribute__((aligned(1024))) char smem[nt_lds_bytes(BM, BN, NST)];
+    uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
+    float* const ctile = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+    const int K = p.K;
+
+    // ---- per-lane sources of this wave's pieces (row + this lane's k-chunk; the K offset moves per step)
+    const uint16_t* src[NPIECE];
+    int cch[NPIECE];                                            // the k-chunk (8 values) this lane fetches
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int piece = wave + NW * i, row = piece * 8 + (lane >> 3);
+        cch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        if (row < BM) {
+            src[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + cch[i];
+        } else {
+            const int n = min(n0 + row - BM, p.N - 1);
+            const int seg = (n >= p.nseg) + (n >= 2 * p.nseg);  // at most 3 row segments (q | k | v): no division
+            src[i] = p.B + seg * p.nseg_stride + (int64_t)(n - seg * p.nseg) * p.ldb + cch[i];
+        }
+    }
+    // TAIL: the last K-step of a K that is not a multiple of 64 — chunks beyond K re-read the last
+    // valid chunk (their products are zeroed in `step`), so no load leaves the row.
+    // kb: wave-uniform K offset of the B operand for the step being issued (contraction segments)
+    int64_t kb = 0;
+    int kin = 0;                                                // position inside the current segment
+    auto issue = [&](int k0, int buf, auto tail) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const bool isA = i < BM / 8 / NW;                    // pieces wave + NW i < BM / 8 hold A rows
+            const uint16_t* s = src[i] + (isA ? (int64_t)k0 : kb);
+            if constexpr (decltype(tail)::value) s += min(0, K - 8 - (k0 + cch[i]));
+            __builtin_amdgcn_global_load_lds(
+                s, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                       reinterpret_cast<uintptr_t>(lds + buf * STAGE + (wave + NW * i) * 8 * BK)), 16, 0, 0);
+        }
+        kb += BK;
+        kin += BK;
+        if (kin >= p.kseg) { kin = 0; kb += p.kseg_stride - p.kseg; }
+    };
+    const int sw = (c32 >> 1) & 7;
+    auto frag = [&](const uint16_t* tile, int row, int chunk) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(tile + row * BK + ((chunk ^ sw) << 3));
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // one K-step from stage `buf`; vc = valid 8-wide chunks (8 unless TAIL).  Fragments are double
+    // buffered in registers: the reads of sub-step ks+1 are issued BEFORE the MFMAs of sub-step ks
+    // (pinned with sched_group_barrier), so LDS latency hides behind matrix work instead of being
+    // paid four times per K-step by an in-order wave.
+    auto step = [&](int buf, int vc, auto tail) {
+        constexpr bool T = decltype(tail)::value;
+        const uint16_t* At = lds + buf * STAGE;
+        const uint16_t* Bt = At + BM * BK;
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto load = [&](int ks, int slot) {
+            const bool dead = T && (ks * 2 + g) >= vc;          // half of a 16-wide sub-step beyond K
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fa[slot][i] = frag(At, wm * WTM + i * 32 + c32, ks * 2 + g);
+                if (T && dead) fa[slot][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                fb[slot][i] = frag(Bt, wn * WTN + i * 32 + c32, ks * 2 + g);
+                if (T && dead) fb[slot][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (T && ks * 2 >= vc) break;
+            if (ks + 1 < BK / 16) load(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][tn], fa[ks & 1][tm], acc[tn][tm], 0, 0, 0);
+        }
+        if constexpr (!T) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);      // reads of sub-steps 0 and 1
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);        // MFMAs of sub-step ks
+                if (ks + 2 < BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // reads of ks + 2
+            }
+        }
+    };
+    using No = std::integral_constant<bool, false>;
+    using Yes = std::integral_constant<bool, true>;
+
+    // ---- main loop: at the top of step s the loads of steps s .. s+D-1 are in flight (D = NST - 1);
+    //      wait for step s only (counted vmcnt), barrier (stage (s-1) % NST is then free for everyone),
+    //      issue step s+D into it, multiply step s.  Raw s_barrier: __syncthreads() would drain vmcnt.
+    constexpr int D = NST - 1;
+    const int nfull = K / BK, rem = K % BK, nk = nfull + (rem ? 1 : 0);
+    auto issue_step = [&](int s) {                              // s < nk
+        if (s < nfull) issue(s * BK, s % NST, No{}); else issue(s * BK, s % NST, Yes{});
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nk) issue_step(s);
+    auto top_of_step = [&](int s) {
+        const int later = min(D - 1, nk - 1 - s);               // load groups younger than step s's
+        if (later >= 2) wait_vmcnt<2 * NPIECE>();
+        else if (later == 1) wait_vmcnt<NPIECE>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + D < nk) issue_step(s + D);
+    };
+    for (int s = 0; s < nfull; ++s) {                           // (the tail step lives outside the loop: one
+        top_of_step(s);                                         //  accumulator live range, no phi copies)
+        step(s % NST, 8, No{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (rem) {
+        top_of_step(nfull);
+        step(nfull % NST, rem >> 3, Yes{});
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, [BM][BN + 4]) -> (row, 8 columns) chunks -------------
+    __syncthreads();                                            // every wave is done with the stages
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int ml = wm * WTM + tm * 32 + c32;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nl = wn * WTN + tn * 32 + 8 * r4 + 4 * g;
+                *reinterpret_cast<f32x4v*>(ctile + ml * CP + nl) =
+                    f32x4v{acc[tn][tm][4 * r4], acc[tn][tm][4 * r4 + 1], acc[tn][tm][4 * r4 + 2], acc[tn][tm][4 * r4 + 3]};
+            }
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                                 // chunks per tile row
+    constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+    const bool ncol_ok = n < p.N;                               // N % 8 == 0: a chunk is all in or all out
+    float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        if (p.bias && ncol_ok) {
+            const u32x4v b = *reinterpret_cast<const u32x4v*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bv[2 * e] = __uint_as_float(b[e] << 16);
+                bv[2 * e + 1] = __uint_as_float(b[e] & 0xFFFF0000u);
+            }
+        }
+    }
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int j = 0; j < BM / RPP; ++j) {
+        const int row = r0 + j * RPP, m = m0 + row;
+        if (m >= p.M || !ncol_ok) continue;
+        const f32x4v lo = *reinterpret_cast<const f32x4v*>(ctile + row * CP + cc * 8);
+        const f32x4v hi = *reinterpret_cast<const f32x4v*>(ctile + row * CP + cc * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        uint16_t* o = p.out + (int64_t)m * p.ldo + n;
+        if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            *reinterpret_cast<u32x4v*>(o) =
+                u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])};
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+            // fc1 under autocast yields bf16 h; gelu runs in fp32 ON that bf16 value and casts back
+            // (supernet_transformer.py:14-16, :276-277)
+            u32x4v hb, gb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hb[e] = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
+                gb[e] = f2bf_pair(gelu_f(__uint_as_float(hb[e] << 16)), gelu_f(__uint_as_float(hb[e] & 0xFFFF0000u)));
+            }
+            *reinterpret_cast<u32x4v*>(o) = hb;
+            *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
+        } else {   // EPI_DGELU_COLSUM
+            const u32x4v hb = *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n);
+            u32x4v db;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                db[e] = f2bf_pair(v[2 * e] * gelu_grad_f(__uint_as_float(hb[e] << 16)),
+                                  v[2 * e + 1] * gelu_grad_f(__uint_as_float(hb[e] & 0xFFFF0000u)));
+                cs[2 * e] += __uint_as_float(db[e] << 16);              // sums of the ROUNDED values written
+                cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
+            }
+            *reinterpret_cast<u32x4v*>(o) = db;
+        }
+    }
+    if constexpr (EPI == EPI_DGELU_COLSUM) {
+        __syncthreads();                                        // the fp32 tile has been consumed
+        float* red = ctile;                                     // [RPP][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[r0 * BN + cc * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) s += red[r * BN + tid];   // fixed order
+            p.colsum[(int64_t)(m0 / BM) * p.N + n0 + tid] = s;
+        }
+    }
+}
+
+
+// =================================================================================================
+// "TN" kernel — weight gradients:  dW(N x K) = dY(M x N)^T . X(M x K), contraction over the M tokens,
+// split S ways over workgroups (fp32 partial tiles; cream_grad_finalize adds them in fixed order —
+// no atomics).  Both operands are stored with the CONTRACTION index as the row index, so the MFMA
+// fragments (8 consecutive m per lane) are columns of the staged tiles: they are read with
+// ds_read_b64_tr_b16 (a 16-lane group fetches a 4(m) x 16(col) block, lane c receives column c — lane
+// mapping pinned on the MI355X by tools/probes/gemm_nt_probe.hip), two reads per fragment.
+//   * tile 128(n) x 128(k) of dW, 4 waves (2 x 2, wave tile 64 x 64), 64 tokens per step;
+//   * operands go global -> LDS directly as full 256-byte rows ([m][128 cols] images); the 16-byte
+//     chunk index is XOR-swizzled with (m & 3) << 2 on the source side and on the read, which spreads
+//     the four rows of a transpose-read block over distinct bank ranges;
+//   * two LDS stages, one barrier per step; rows beyond M (only possible in the last step of the
+//     last split) are zeroed in LDS before use;
+//   * bias gradient for free: workgroups of the first k-tile also multiply their dY fragments with a
+//     ones fragment — the column sums of dY (= F.linear's bias gradient) leave with the partials.
+struct TnParams {
+    const uint16_t* dY;     // (M x N) bf16, row stride ldy
+    const uint16_t* X;      // (M x K) bf16, row stride ldx
+    int64_t ldy, ldx;
+    int M, N, K, S;         // S splits of the token dimension (in 64-token steps, as even as possible)
+    float* parts;           // [S][N][K] fp32
+    float* bias_parts;      // [S][N] fp32 or nullptr
+};
+
+__device__ __forceinline__ bf16x4 tr16(const uint16_t* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p)));
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
+{
+    constexpr int BT = 128, BM = 64;                            // output tile edge, tokens per step
+    constexpr int STAGE = 2 * BM * BT;                          // bf16 elements per stage ([dY | X] tiles)
+    constexpr int NPIECE = 2 * BM / 4 / 4;                      // 1-KB pieces (4 rows of 256 B) per wave and stage
+    __shared__ __attribute__((aligned(1024))) uint16_t lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int ntk = (p.K + BT - 1) / BT, ntn = (p.N + BT - 1) / BT;
+    const int tile = blockIdx.x % (ntk * ntn), split = blockIdx.x / (ntk * ntn);
+    const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
+    const int tsteps = (p.M + BM - 1) / BM;
+    const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
+    const bool want_bias = p.bias_parts && k0 == 0;
+
+    // sources: piece j of a stage = rows 4j..4j+3 of [dY tile (pieces 0..15) | X tile (16..31)]
+    const uint16_t* src[NPIECE];
+    int rowin[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int piece = wave + 4 * i, r = (piece & 15) * 4 + (lane >> 4);     // token row inside the step
+        const int c = (lane & 15) ^ ((r & 3) << 2);                             // source chunk of this LDS position
+        rowin[i] = r;
+        if (piece < 16) src[i] = p.dY + min(n0 + c * 8, p.N - 8);               // N, K % 8 == 0: whole chunks
+        else src[i] = p.X + min(k0 + c * 8, p.K - 8);
+    }
+    auto issue = [&](int step, int buf) {
+        const int m0 = step * BM;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const bool isY = i < 4;                                               // pieces wave + 4 i < 16
+            const int m = min(m0 + rowin[i], p.M - 1);
+            const uint16_t* s = src[i] + (int64_t)m * (isY ? p.ldy : p.ldx);
+            __builtin_amdgcn_global_load_lds(
+                s, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                       reinterpret_cast<uintptr_t>(lds + buf * STAGE + (wave + 4 * i) * 4 * BT)), 16, 0, 0);
+        }
+    };
+    // fragment of 32 columns starting at `col` for contraction rows mb + 8 g .. + 7 of a [64][128] tile:
+    // lane group q = lane >> 4: column block 16 (q & 1), contraction half g = q >> 1
+    const int gi = lane & 15, q = lane >> 4;
+    auto frag = [&](const uint16_t* tile_, int col, int mb) -> bf16x8 {
+        const int cc = col + 16 * (q & 1) + (gi & 3) * 4;                       // first of this lane's 4 columns
+        const int m = mb + 8 * (q >> 1) + (gi >> 2);                            // row supplied by this lane (first read)
+        // (m & 3) is the same for m and m + 4: one swizzle term for both reads
+        const int off = m * BT + ((((cc >> 3) ^ ((m & 3) << 2)) << 3) | (cc & 7));
+        const bf16x4 lo = tr16(tile_ + off), hi = tr16(tile_ + off + 4 * BT);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    f32x16 acc[2][2], bacc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        bacc[a] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const bf16x8 ones = bf16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    if (s_lo < s_hi) issue(s_lo, 0);
+    for (int st = s_lo; st < s_hi; ++st) {
+        const int buf = (st - s_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < s_hi) issue(st + 1, buf ^ 1);
+        uint16_t* Yt = lds + buf * STAGE;
+        uint16_t* Xt = Yt + BM * BT;
+        if ((st + 1) * BM > p.M) {                              // token tail: zero the rows beyond M
+            const int valid = p.M - st * BM;
+            for (int i = tid; i < 2 * BM * BT / 8; i += 256) {
+                const int r = (i / 16) & (BM - 1);
+                if (r >= valid) *reinterpret_cast<u32x4v*>(Yt + i * 8) = u32x4v{0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ms = 0; ms < BM / 16; ++ms) {
+            bf16x8 fy[2], fx[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fy[i] = frag(Yt, wn * 64 + i * 32, ms * 16);
+                fx[i] = frag(Xt, wk * 64 + i * 32, ms * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+            if (want_bias && wk == 0) {
+                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[0], ones, bacc[0], 0, 0, 0);
+                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[1], ones, bacc[1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial tile: D[n][k], lane = column k (l & 31), registers = rows n -------------------------
+    const int g = lane >> 5, c32 = lane & 31;
+    float* out = p.parts + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int k = k0 + wk * 64 + b * 32 + c32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + a * 32 + acc_row(r, g);
+                if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[a][b][r];
+            }
+        }
+    if (want_bias && wk == 0 && c32 == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + a * 32 + acc_row(r, g);
+                if (n < p.N) p.bias_parts[(int64_t)split * p.N + n] = bacc[a][r];
+            }
+    }
+}
+
+}  // namespace gemm
+}  // namespace cream

@@ -199,30 +199,71 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
 
 /* ---- dense projections of the weight-entangled Linear layers ---------------------------------
  * LinearSuper.forward / qkv_super.forward = F.linear(x, W[:out, :in], b[:out])
- * (AutoFormer/model/module/Linear_super.py:38-54,71-81; qkv_super.py:45-55) and its autograd
- * adjoints, on the GEMM library (hipBLASLt) with OFFLINE-selected kernels.  bf16 operands, fp32
- * accumulation.  The active block of the super weight is read in place: `w` points at W[0][0],
- * ldw = super in-features (row stride); N = active out-features, K = active in-features.
- *   cream_linear_fwd          out(M x N) = x(M x K) . W(N x K)^T + bias(N)      (bias may be NULL)
- *   cream_linear_dgrad        dx(M x K)  = dy(M x N) . W(N x K)
- *   cream_linear_wgrad_parts  parts[s](N x K) = dy_s^T x_s over S equal slices of the M rows
- *                             (split-K; the slices are added by cream_grad_finalize)
- * All matrices other than W are contiguous.  Launches go to `stream`, which must have a workspace
- * registered (the library's stream-K kernels need scratch; the C ABI never allocates):
- *   cream_gemm_set_workspace(stream, ptr, bytes)   one buffer per stream that issues GEMMs
- *   cream_gemm_table_load(csv)                     kernel-selection table (PyTorch TunableOp CSV,
- *                                                  tools/tune_gemms.py); returns #entries loaded.
- *                                                  Problems without an entry use the library heuristic.
- *   cream_gemm_plan_counts(&from_table, &heuristic)  -> number of cached plans (diagnostics) */
-int cream_gemm_table_load(const char* csv_path);
-int cream_gemm_set_workspace(void* stream, void* ptr, int64_t bytes);
-int cream_gemm_plan_counts(int* from_table, int* heuristic);
+ * (AutoFormer/model/module/Linear_super.py:38-54,71-81; qkv_super.py:45-55,72-83), the erf-GELU of
+ * the Mlp (supernet_transformer.py:14-16,275-285) and their autograd adjoints, on hand-written MFMA
+ * kernels (csrc/gemm_mfma.hpp: direct-to-LDS operand loads, v_mfma_f32_32x32x16_bf16, fused
+ * epilogues).  bf16 operands, fp32 accumulation, bf16 results.  The active block of a super weight is
+ * read in place: `w` points at element [0][0] of the operand copy, ld = its row stride; N = active
+ * out-features, K = active in-features.  Activations are contiguous (row stride = width).
+ * N % 8 == K % 8 == ld % 8 == 0, 16-byte aligned pointers.
+ *   cream_linear_fwd          out(M x N) = x(M x K) . W(N x K)^T + bias(N)          (bias may be NULL)
+ *   cream_linear_fwd_seg      the same with the rows of W in up to 3 segments of `nseg` rows,
+ *                             `nseg_stride` elements apart: the de-interleaved [q | k | v] copy of
+ *                             the qkv super weight (row n of the product = row n % nseg of segment
+ *                             n / nseg) — replaces the torch.cat row gather of qkv_super.py:75
+ *   cream_linear_gelu_fwd     h = x . W^T + bias (bf16) and g = gelu(float(h)) in one pass (fc1 + the
+ *                             fp32 gelu of supernet_transformer.py:14-16; gelu on the bf16-rounded h,
+ *                             exactly as under the reference's autocast)
+ *   cream_linear_dgrad        dx(M x K) = dy(M x N) . W(N x K); `wt` is the TRANSPOSED copy W^T
+ *                             (K rows, N contiguous, row stride ldwt)
+ *   cream_linear_dgrad_seg    the same with the contraction index in segments of `kseg` (the
+ *                             transposed [q | k | v] copies, `kseg_stride` elements apart; kseg % 64 == 0)
+ *   cream_linear_dgrad_dgelu  dh(M x K) = (dy . W) * gelu'(h) and the column sums of dh per 128-row
+ *                             slab: colsum_parts[slab][K] (fc2 dgrad + GELU backward + fc1 bias
+ *                             gradient partials, cream_gemm_rows_per_colsum_slab() rows per slab)
+ *   cream_linear_wgrad_parts  parts[s](N x K) fp32 = dy_s^T x_s over S slices of the M rows (slices of
+ *                             whole 64-row steps, as even as possible; added by cream_grad_finalize);
+ *                             bias_parts[s](N) = column sums of dy_s — the bias gradient rides on the
+ *                             same kernel (NULL: not wanted).  cream_linear_wgrad_splits gives the S
+ *                             this library uses for a problem (~2 workgroups per CU). */
+int cream_gemm_rows_per_colsum_slab(void);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
-int cream_linear_dgrad(void* dx, const void* dy, const void* w, int M, int N, int K, int64_t ldw,
+int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
+                         int64_t ldw, int nseg, int64_t nseg_stride, void* stream);
+int cream_linear_gelu_fwd(void* h, void* g, const void* x, const void* w, const void* bias, int M, int N,
+                          int K, int64_t ldw, void* stream);
+int cream_linear_dgrad(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
                        void* stream);
-int cream_linear_wgrad_parts(void* parts, const void* dy, const void* x, int M, int N, int K, int S,
-                             void* stream);
+int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
+                           int kseg, int64_t kseg_stride, void* stream);
+int cream_linear_dgrad_dgelu(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* h,
+                             int M, int N, int K, int64_t ldwt, void* stream);
+int cream_linear_wgrad_splits(int M, int N, int K);
+int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N,
+                             int K, int S, void* stream);
+
+/* ---- parameter update + operand copies ------------------------------------------------------
+ * torch.optim.AdamW as created by timm's create_optimizer (AutoFormer/supernet_train.py:294-296;
+ * decoupled weight decay, bias-corrected moments) over EVERY tensor of the model in one launch, which
+ * also writes the bf16 operand copies the GEMM kernels read: `mir` = the tensor as (rows x cols) bf16
+ * with row stride ld_mir, `mir_t` = its transpose (cols x rows, row stride ld_mir_t) or NULL;
+ * deinterleave != 0 (the qkv super weight, qkv_super.py:75): row 3 i + j of the tensor is row i of
+ * part j — parts seg_stride (seg_stride_t) elements apart in the copies.  g == NULL or update == 0:
+ * copies only (initialisation, checkpoint load).  The job table and the prefix sums of
+ * cream_param_job_tiles(rows, cols) over the jobs (njobs + 1 entries) live in DEVICE memory. */
+typedef struct cream_param_job {
+    float* p;              /* fp32 master tensor viewed as (rows x cols), row stride ld          */
+    const float* g;        /* gradient (same layout) or NULL                                    */
+    float *m, *v;          /* exp_avg, exp_avg_sq                                               */
+    void *mir, *mir_t;     /* bf16 copies or NULL                                               */
+    int64_t ld, ld_mir, ld_mir_t, seg_stride, seg_stride_t;
+    int32_t rows, cols, deinterleave;
+    float weight_decay;
+} cream_param_job;
+int cream_param_job_tiles(int rows, int cols);
+int cream_adamw_step(const cream_param_job* jobs_dev, const int32_t* first_tile_dev, int njobs, int total_tiles,
+                     int update, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 /* Gradient finalisation for the weight-entangled parameters: every tensor of a block gets
  *     dst[map(r)*ld + c] += sum_p src[p*pstride + r*cols + c]          r < rows, c < cols
@@ -246,10 +287,6 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
-/* dst (3Q x E, contiguous) <- rows of the interleaved qkv super weight regrouped [q | k | v]:
- * dst[j*Q + i][:E] = src[3*i + j][:E]  (the row gather of qkv_super.py:72-77); E, ld % 8 == 0. */
-int cream_qkv_regroup(void* dst, const void* src, int Q, int E, int64_t ld, void* stream);
-
 /* ---- one transformer block, sequenced natively ---------------------------------------------
  * TransformerEncoderLayer.forward (AutoFormer/model/supernet_transformer.py:251-287) and its
  * autograd backward as ONE call per direction: the kernels are the ones declared above, enqueued
@@ -259,16 +296,17 @@ int cream_qkv_regroup(void* dst, const void* src, int Q, int E, int64_t ld, void
 typedef struct cream_block_desc {
     int32_t B, N, E, H, F;        /* batch, tokens, embed dim, heads (head dim 64), mlp hidden     */
     int32_t gh, gw, mr;           /* token grid (N = gh*gw + 1) and max_relative_position          */
-    int32_t wgrad_split;          /* split-K factor of the weight gradients, (B*N) % split == 0     */
-    int32_t reserved;
+    int32_t reserved0, reserved1;
     float eps1, eps2, attn_scale;
     float reserved_f;
-    /* bf16 operand copies of the SUPER weights, read in place (ld = row stride in elements) */
-    const void *wqkv, *bqkv;      /* (3*Qsuper, ld_qkv) q/k/v rows interleaved; bias: plain prefix  */
-    const void *wproj, *bproj;    /* (Esuper, ld_proj)                                             */
-    const void *w1, *b1;          /* fc1 (Fsuper, ld_w1)                                           */
-    const void *w2, *b2;          /* fc2 (Esuper, ld_w2)                                           */
-    int64_t ld_qkv, ld_proj, ld_w1, ld_w2;
+    /* bf16 operand copies of the SUPER weights (written by cream_adamw_step), read in place:
+     * w* = (out x in) row stride ld_*, w*_t = transposed (in x out) row stride ld_*_t;
+     * qkv: three de-interleaved parts [q | k | v], seg_qkv / seg_qkv_t elements apart */
+    const void *wqkv, *wqkv_t, *bqkv;
+    const void *wproj, *wproj_t, *bproj;
+    const void *w1, *w1_t, *b1;
+    const void *w2, *w2_t, *b2;
+    int64_t ld_qkv, ld_qkv_t, seg_qkv, seg_qkv_t, ld_proj, ld_proj_t, ld_w1, ld_w1_t, ld_w2, ld_w2_t;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* attn_layer_norm / ffn_layer_norm (fp32)     */
     const float *tkv, *tkh, *tvv, *tvh;             /* rel_pos_embed_{k,v}.embeddings_table_{v,h}  */
     int64_t ldt;

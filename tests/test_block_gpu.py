@@ -76,7 +76,7 @@ def test_gelu_residual_scale_colsum_match_torch_fp32():
     assert torch.equal(K.residual_add(x, h, None, rows * C), x + h.float())
     assert _rel(K.scale_cast(x, s, rows * C).float(), x * srow) < 1e-2
     assert _rel(K.colsum(h), h.float().sum(0)) < 1e-5
-    assert _rel(K.wgrad(dg, h), dg.float().t() @ h.float()) < 2e-2
+    assert _rel(K.wgrad(dg, h), dg.float().t() @ h.float()) < 1e-3
 
 
 @pytest.mark.parametrize("M,C", [(197 * 4, 1344), (130, 320), (25216, 448)])
@@ -99,12 +99,12 @@ def test_passes_with_bias_gradient_match_torch_fp32(M, C):
 
 
 @pytest.mark.parametrize("M,N,K,ldw", [(197 * 8, 1152, 384, 384), (197 * 8, 1344, 384, 448), (25216, 384, 1344, 1792),
-                                        (197 * 8, 320, 320, 448)])
+                                        (197 * 8, 320, 320, 448), (25216, 1344, 448, 448), (1000, 200, 136, 144),
+                                        (197 * 8, 320, 1120, 1792)])
 def test_native_linear_matches_torch_fp32(M, N, K, ldw):
-    """cream_linear_fwd / dgrad / wgrad_parts (hipBLASLt through the C ABI, active block of the super
-    weight read in place) against plain PyTorch fp32 of the same products; with and without the
-    offline kernel-selection table."""
-    import os
+    """cream_linear_fwd / dgrad / wgrad_parts (hand-written MFMA kernels through the C ABI, active
+    block of the super weight read in place) against plain PyTorch fp32 of the same products:
+    every tile variant (N above / below 640), row / column edges, K tails (136, 1120 % 64 != 0)."""
     from cream_amd.autoformer import block as K_
     g = torch.Generator(device=DEV).manual_seed(4)
     x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
@@ -112,22 +112,127 @@ def test_native_linear_matches_torch_fp32(M, N, K, ldw):
     bias = torch.randn(N + 64, device=DEV, generator=g).bfloat16()
     dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
     W = wsup[:N, :K].float()
-    for load in (False, True):
-        if load:
-            K_.gemm_table_load(os.path.join(ROOT, "cream_amd", "tuning", "gemm_S_b128.csv"))
-        out = K_.linear_fwd(x, wsup, bias, N, K)
-        assert _rel(out.float(), x.float() @ W.t() + bias[:N].float()) < 1e-2
-        dx = K_.linear_dgrad(dy, wsup, N, K)
-        assert _rel(dx.float(), dy.float() @ W) < 1e-2
-        parts = K_.linear_wgrad_parts(dy, x)
-        assert parts.shape[1:] == (N, K)
-        assert _rel(parts.float().sum(0), dy.float().t() @ x.float()) < 2e-2
+    wt = torch.zeros(ldw, N + 64, device=DEV, dtype=torch.bfloat16)          # transposed operand copy (in, out)
+    wt[:, :] = wsup.t()
+    out = K_.linear_fwd(x, wsup, bias, N, K)
+    assert _rel(out.float(), x.float() @ W.t() + bias[:N].float()) < 1e-2
+    assert _rel(K_.linear_fwd(x, wsup, None, N, K).float(), x.float() @ W.t()) < 1e-2
+    dx = K_.linear_dgrad(dy, wt, N, K)
+    assert _rel(dx.float(), dy.float() @ W) < 1e-2
+    parts, bparts = K_.linear_wgrad_parts(dy, x, want_bias=True)
+    assert parts.shape[1:] == (N, K) and parts.dtype == torch.float32
+    assert _rel(parts.sum(0), dy.float().t() @ x.float()) < 1e-3           # fp32 partials: only bf16 operand rounding left
+    assert _rel(bparts.sum(0), dy.float().sum(0)) < 1e-4
+    assert torch.equal(K_.linear_wgrad_parts(dy, x)[0], parts)             # bit-reproducible, bias output optional
     # nothing outside the active block was touched or read: a poisoned remainder changes nothing
     wsup2 = wsup.clone()
     wsup2[N:] = float("nan")
     wsup2[:, K:] = float("nan")
+    wt2 = wt.clone()
+    wt2[K:] = float("nan")
+    wt2[:, N:] = float("nan")
     assert torch.equal(K_.linear_fwd(x, wsup2, bias, N, K), out)
-    assert torch.equal(K_.linear_dgrad(dy, wsup2, N, K), dx)
+    assert torch.equal(K_.linear_dgrad(dy, wt2, N, K), dx)
+    # outputs are exactly M x N: a guard band after the buffer stays untouched
+    buf = torch.full((M * N + 4096,), -7.0, device=DEV).bfloat16()
+    K_.linear_fwd(x, wsup, bias, N, K, out=buf[:M * N].view(M, N))
+    assert torch.equal(buf[:M * N].view(M, N), out) and bool((buf[M * N:] == -7).all())
+
+
+@pytest.mark.parametrize("M,E,H", [(197 * 8, 384, 6), (25216, 320, 5), (197 * 4, 448, 7)])
+def test_qkv_segment_addressing_matches_row_gather(M, E, H):
+    """The de-interleaved [q | k | v] operand copies (written by the optimizer kernel) reproduce the
+    row gather of qkv_super.py:72-77 in forward and dgrad; contiguous-prefix bias (:80-83)."""
+    from cream_amd.autoformer import block as K_, engine
+    torch.manual_seed(0)
+    blk = engine.build_supernet("S", depth=1).to(DEV).blocks[0]
+    with torch.no_grad():
+        blk.attn.qkv.bias.normal_()
+    Q = 64 * H
+    ops = K_.operands(blk)
+    Wsup, bsup = blk.attn.qkv.weight.detach(), blk.attn.qkv.bias.detach()
+    Wg = torch.cat([Wsup[i:3 * Q:3, :E] for i in range(3)], dim=0).bfloat16().float()      # the reference's gather
+    assert torch.equal(ops.w[0][:, :Q, :E].reshape(3 * Q, E).float(), Wg)
+    assert torch.equal(ops.wt[0][:, :E, :Q].float(), ops.w[0][:, :Q, :E].transpose(1, 2).float())
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(M, E, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, 3 * Q, device=DEV, generator=g).bfloat16()
+    out = K_.linear_fwd_seg(x, ops.w[0], ops.b[0], 3 * Q, E, Q)
+    assert _rel(out.float(), x.float() @ Wg.t() + bsup[:3 * Q].bfloat16().float()) < 1e-2
+    dx = K_.linear_dgrad_seg(dy, ops.wt[0], 3 * Q, E, Q)
+    assert _rel(dx.float(), dy.float() @ Wg) < 1e-2
+
+
+@pytest.mark.parametrize("M,E,F_", [(197 * 8, 384, 1344), (25216, 448, 1792), (1000, 320, 1120), (197 * 4, 320, 960)])
+def test_fused_gelu_epilogues_match_unfused_passes(M, E, F_):
+    """fc1 with the erf-GELU in its epilogue == linear + cream_gelu_fwd on the bf16-rounded h (bits of
+    h identical; gelu(h) within one bf16 ulp: the epilogue evaluates erf by A&S 7.1.26, |err| <= 5e-7);
+    fc2's dgrad with GELU' == dgrad (fp32 accumulator, not bf16-rounded first) * gelu'(h), and the
+    column-sum partials add up to the column sums of what was written."""
+    from cream_amd.autoformer import block as K_
+    g = torch.Generator(device=DEV).manual_seed(5)
+    c = torch.randn(M, E, device=DEV, generator=g).bfloat16()
+    w1 = (torch.randn(F_, E, device=DEV, generator=g) * 0.08).bfloat16()
+    b1 = torch.randn(F_, device=DEV, generator=g).bfloat16()
+    h, gg = K_.linear_gelu_fwd(c, w1, b1, F_, E)
+    assert torch.equal(h, K_.linear_fwd(c, w1, b1, F_, E))
+    ref_g = F.gelu(h.float())
+    assert _rel(gg.float(), ref_g) < 4e-3 and float((gg.float() - ref_g).abs().max()) <= 2 ** -7 * float(ref_g.abs().max())
+    assert _rel(gg.float(), K_.gelu_fwd(h).float()) < 4e-3
+    df = torch.randn(M, E, device=DEV, generator=g).bfloat16()
+    w2 = (torch.randn(E, F_, device=DEV, generator=g) * 0.05).bfloat16()
+    w2t = w2.t().contiguous()
+    dh, parts = K_.linear_dgrad_dgelu(df, w2t, h, E, F_)
+    hr = h.float().requires_grad_()
+    F.gelu(hr).backward(df.float() @ w2.float())
+    assert _rel(dh.float(), hr.grad) < 1e-2
+    assert parts.shape == (K_._lib.load().cream_colsum128_slabs(M), F_)
+    assert _rel(parts.sum(0), dh.float().sum(0)) < 1e-5
+
+
+def test_native_adamw_matches_torch_and_writes_operand_copies():
+    """cream_adamw_step (one launch over all tensors) against torch.optim.AdamW on the same gradients
+    for several steps (both parameter groups), and the bf16 operand copies it writes: W, W^T, the
+    de-interleaved qkv parts, biases."""
+    from cream_amd.autoformer import block as K_, engine
+    torch.manual_seed(3)
+    m = engine.build_supernet("S", depth=2).to(DEV)
+    ref = engine.build_supernet("S", depth=2).to(DEV)
+    ref.load_state_dict(m.state_dict())
+    opt = engine.build_optimizer(m, lr=2e-2, batch_size=128)
+    assert isinstance(opt, engine.NativeAdamW)
+    opt_ref = torch.optim.AdamW(engine.param_groups(ref, 0.05), lr=2e-2 * 128 / 512, betas=(0.9, 0.999), eps=1e-8)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    for step in range(3):
+        for p, q in zip(m.parameters(), ref.parameters()):
+            gr = torch.randn(p.shape, device=DEV, generator=g) * 0.1
+            if p.grad is None:
+                p.grad = gr.clone()
+            else:
+                p.grad.copy_(gr)
+            q.grad = gr.clone()
+        opt.step()
+        opt_ref.step()
+    worst = 0.0
+    for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+        worst = max(worst, float((p - q).abs().max() / (q.abs().max() + 1e-12)))
+    assert worst < 2e-6, worst
+    st, st_ref = opt.state[m.blocks[1].fc1.weight], opt_ref.state[ref.blocks[1].fc1.weight]
+    assert _rel(st["exp_avg"], st_ref["exp_avg"]) < 1e-6 and _rel(st["exp_avg_sq"], st_ref["exp_avg_sq"]) < 1e-6
+    for blk in m.blocks:
+        ops = K_.operands(blk, fresh=False)
+        assert not ops.stale()
+        for mod, w, wt, b in zip(ops.mods, ops.w, ops.wt, ops.b):
+            W = mod.weight.detach().bfloat16()
+            if w.dim() == 3:
+                W = torch.stack([W[i::3] for i in range(3)])
+            assert torch.equal(w, W) and torch.equal(wt, W.transpose(-1, -2))
+            assert torch.equal(b, mod.bias.detach().bfloat16())
+    # state dict round trip through torch's format
+    sd = opt.state_dict()
+    opt2 = engine.build_optimizer(m, lr=2e-2, batch_size=128)
+    opt2.load_state_dict(sd)
+    assert opt2._steps == 3 and torch.equal(opt2.state[m.blocks[1].fc1.weight]["exp_avg"], st["exp_avg"])
 
 
 def test_grad_finalize_adds_partials_into_super_weight_slices():
@@ -299,7 +404,9 @@ def test_mirror_follows_optimizer_and_droppath_runs():
     tr.start_epoch(0)
     l0 = float(tr.step(x, t))
     w = m2.blocks[0].fc1.weight
-    assert torch.equal(K.MIRROR.get(w), w.detach().bfloat16())          # refreshed after the step
+    ops = K.operands(m2.blocks[0], fresh=False)
+    assert not ops.stale() and torch.equal(ops.w[2], w.detach().bfloat16())   # rewritten by the optimizer kernel
+    assert torch.equal(ops.wt[2], w.detach().bfloat16().t())
     l1 = float(tr.step(x, t))
     assert l0 == l0 and l1 == l1
 

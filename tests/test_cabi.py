@@ -89,9 +89,9 @@ def test_block_workspace_layout_is_pure_host_arithmetic():
     lib = _lib.load()
     d = _lib.BlockDesc()
     d.B, d.N, d.E, d.H, d.F = 128, 197, 384, 6, 1344
-    d.gh, d.gw, d.mr, d.wgrad_split = 14, 14, 14, 8
-    for name in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv",
-                 "tkh", "tvv", "tvh"):
+    d.gh, d.gw, d.mr = 14, 14, 14
+    for name in ("wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "ln1_g",
+                 "ln1_b", "ln2_g", "ln2_b", "tkv", "tkh", "tvv", "tvh"):
         setattr(d, name, 0x1000)                                   # any non-null pointer: only checked, never read
     o = [ctypes.c_int64() for _ in range(6)]
     ft = lib.cream_block_fwd_workspace(ctypes.byref(d), ctypes.byref(o[0]), ctypes.byref(o[1]), ctypes.byref(o[2]))
@@ -103,9 +103,8 @@ def test_block_workspace_layout_is_pure_host_arithmetic():
     assert bt > 0 and all(v.value % 256 == 0 for v in o)
     assert 0 <= o[0].value < o[1].value < o[2].value < ft            # x | ... | x1 | ... | f
     assert o[3].value < o[4].value < o[5].value < bt                 # dx | df_prev | pl1
-    d.wgrad_split = 7                                                # 25216 % 7 != 0
+    d.E = 380                                                        # E % 8 != 0
     assert lib.cream_block_fwd_workspace(ctypes.byref(d), None, None, None) == -1
-    d.wgrad_split, d.E = 8, 380                                      # E % 8 != 0
     assert lib.cream_block_bwd_workspace(ctypes.byref(d), None, None, None) == -1
 
 
@@ -120,9 +119,20 @@ def test_new_entry_points_validate_arguments_without_launching():
     assert lib.cream_grad_finalize(ctypes.cast(j, ctypes.c_void_p), 1, None) == -1      # ld % 4 != 0
     assert lib.cream_linear_fwd(None, None, None, None, 0, 8, 8, 8, None) == 0          # empty problem
     assert lib.cream_linear_fwd(None, None, None, None, 4, 8, 8, 8, None) == -1
-    assert lib.cream_linear_dgrad(0x1000, 0x1000, 0x1000, 4, 8, 16, 8, None) == -1       # ldw < K
-    assert lib.cream_linear_wgrad_parts(0x1000, 0x1000, 0x1000, 10, 8, 8, 3, None) == -1  # M % S != 0
-    assert lib.cream_qkv_regroup(0x1000, 0x1000, 64, 100, 104, None) == -1               # E % 8 != 0
-    assert lib.cream_gemm_table_load(b"/nonexistent/table.csv") == -1
+    assert lib.cream_linear_fwd(0x1000, 0x1000, 0x1000, None, 4, 8, 16, 8, None) == -1   # ldw < K
+    assert lib.cream_linear_fwd(0x1000, 0x1000, 0x1000, None, 4, 12, 16, 16, None) == -1  # N % 8 != 0
+    assert lib.cream_linear_fwd(0x1000, 0x1008, 0x1000, None, 4, 8, 16, 16, None) == -1  # x not 16-byte aligned
+    assert lib.cream_linear_dgrad(0x1000, 0x1000, 0x1000, 4, 16, 8, 8, None) == -1       # ld of W^T < N
+    assert lib.cream_linear_fwd_seg(0x1000, 0x1000, 0x1000, None, 4, 384, 64, 64, 64, 4096, None) == -1   # > 3 segments
+    assert lib.cream_linear_dgrad_seg(0x1000, 0x1000, 0x1000, 4, 192, 64, 64, 32, 4096, None) == -1       # kseg % 64 != 0
+    assert lib.cream_linear_wgrad_parts(0x1000, None, 0x1000, 0x1000, 10, 8, 8, 0, None) == -1            # S < 1
+    assert lib.cream_linear_wgrad_parts(None, None, 0x1000, 0x1000, 10, 8, 8, 1, None) == -1
+    assert lib.cream_linear_wgrad_splits(25216, 384, 384) == 32 and lib.cream_linear_wgrad_splits(64, 384, 384) == 1
+    assert 1 <= lib.cream_linear_wgrad_splits(25216, 1344, 384) <= 32
+    assert lib.cream_gemm_rows_per_colsum_slab() == 128
+    assert lib.cream_param_job_tiles(96, 64) == 1 and lib.cream_param_job_tiles(97, 65) == 4 and lib.cream_param_job_tiles(0, 5) == 0
+    assert lib.cream_adamw_step(None, None, 0, 0, 1, 1e-3, 0.9, 0.999, 1e-8, 1, None) == 0      # nothing to do
+    assert lib.cream_adamw_step(None, None, 2, 5, 1, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -1
+    assert lib.cream_adamw_step(0x1000, 0x1000, 2, 5, 1, 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1  # update needs step >= 1
     assert lib.cream_colsum128_slabs(25216) == 197 and lib.cream_colsum128_slabs(0) == 0
     assert lib.cream_ln_partials() > 0

@@ -11,7 +11,6 @@ from cream_amd.autoformer import engine
 
 n_sub = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda")
-engine.enable_gemm_selection("S", 128)
 torch.manual_seed(0)
 m = engine.build_supernet("S").to(dev)
 ch = engine.SEARCH_SPACES["S"]["choices"]

@@ -7,7 +7,6 @@ from cream_amd.autoformer import engine, block
 if '--no-side' in sys.argv:
     block.WGRAD_SIDE_STREAM = False
 dev = torch.device('cuda')
-engine.enable_gemm_selection('S', 128)
 torch.manual_seed(0)
 model = engine.build_supernet('S', drop_path_rate=0.1).to(dev)
 opt = engine.build_optimizer(model, lr=5e-4, batch_size=128, world_size=1)

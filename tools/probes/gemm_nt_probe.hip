@@ -1,0 +1,322 @@
+// gemm_nt_probe.hip — development probe of the product's own MFMA GEMM (cream_amd/csrc/gemm_mfma.hpp):
+// every tile variant / epilogue is checked against a plain reference kernel on the path's shapes and timed
+// next to the GEMM library (best of the heuristic's top 16 algorithms) on the same problem and buffers.
+// Also pins the lane mapping of ds_read_b64_tr_b16 (needed by the transposing weight-gradient kernel).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icream_amd/csrc tools/probes/gemm_nt_probe.hip \
+//         -L/opt/rocm/lib -lhipblaslt -o tools/probes/gemm_nt_probe && tools/probes/gemm_nt_probe
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "gemm_mfma.hpp"
+
+using namespace cream;
+using namespace cream::gemm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ float bfv(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// reference: one thread per output element, fp32 accumulation in k order, fp32 result
+__global__ void ref_nt(float* out, NtParams p) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    const uint16_t* b = p.B + (int64_t)(n / p.nseg) * p.nseg_stride + (int64_t)(n % p.nseg) * p.ldb;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k)
+        s += bfv(p.A[(int64_t)m * p.lda + k]) * bfv(b[(int64_t)(k / p.kseg) * p.kseg_stride + k % p.kseg]);
+    out[i] = s;
+}
+// expected outputs of an epilogue from the fp32 reference product; max error against what the kernel wrote
+__global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, int bm) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = ref[i];
+    float got = bfv(p.out[(int64_t)m * p.ldo + n]);
+    float want, err;
+    if (epi == EPI_STORE) want = v;
+    else if (epi == EPI_BIAS) want = v + (p.bias ? bfv(p.bias[n]) : 0.f);
+    else if (epi == EPI_BIAS_GELU) {
+        want = v + bfv(p.bias[n]);
+        const float g = gelu_f(got), got2 = bfv(p.out2[(int64_t)m * p.ldo + n]);
+        err = fabsf(g - got2) / (1.f + fabsf(g));
+        atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
+    } else want = v * gelu_grad_f(bfv(p.aux[(int64_t)m * p.ldaux + n]));
+    err = fabsf(want - got) / (1.f + fabsf(want));
+    atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(err == err ? err : 1e30f));
+}
+__global__ void check_colsum(float* maxerr, NtParams p, int bm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ntm = (p.M + bm - 1) / bm;
+    if (i >= ntm * p.N) return;
+    const int tm = i / p.N, n = i % p.N;
+    float s = 0.f;
+    for (int m = tm * bm; m < min(p.M, (tm + 1) * bm); ++m) s += bfv(p.out[(int64_t)m * p.ldo + n]);
+    const float err = fabsf(s - p.colsum[i]) / (1.f + fabsf(s));
+    atomicMax(reinterpret_cast<int*>(maxerr + 2), __float_as_int(err == err ? err : 1e30f));
+}
+
+struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); };
+#define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
+static const Variant VARIANTS[] = {
+    V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3), V(256, 128, 4, 2, 2, EPI_BIAS, 1),
+    V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_DGELU_COLSUM, 2),
+};
+static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
+    const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm;
+    hipLaunchKernelGGL(v.kern, dim3(ntn * ntm), dim3(v.nt), 0, st, p);
+}
+__global__ void gelu_accuracy(float* out) {
+    float worst_g = 0.f, worst_d = 0.f;
+    for (int i = threadIdx.x; i < 200000; i += blockDim.x) {
+        const float x = -10.f + i * 1e-4f;
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        worst_g = fmaxf(worst_g, fabsf(gelu_f(x) - x * cdf));
+        worst_d = fmaxf(worst_d, fabsf(gelu_grad_f(x) - (cdf + x * 0.3989422804014327f * expf(-0.5f * x * x))));
+    }
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(worst_g));
+    atomicMax(reinterpret_cast<int*>(out + 1), __float_as_int(worst_d));
+}
+
+static uint16_t f2bf_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float ms(hipEvent_t a, hipEvent_t b) { float t; hipEventElapsedTime(&t, a, b); return t; }
+
+// ---- ds_read_b64_tr_b16 lane mapping ----------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__global__ void tr16_probe(uint16_t* out, int pitch, int blk) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (uint16_t)i;
+    __syncthreads();
+    const int l = threadIdx.x;
+    // hypothesis H1: lane i of a 16-lane group supplies the address of 4 consecutive elements (row i>>2,
+    // columns 4*(i&3)..+3) of a 4 x 16 block; lane c receives column c, rows 0..3
+    const int e = ((l & 15) >> 2) * pitch + (l & 3) * 4 + (l >> 4) * blk;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + e));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
+}
+static void tr16_semantics() {
+    uint16_t* d; CK(hipMalloc(&d, 512));
+    const int cfg[3][2] = {{16, 64}, {128, 16}, {72, 1024}};
+    for (auto& c : cfg) {
+        tr16_probe<<<1, 64>>>(d, c[0], c[1]);
+        uint16_t h[256]; CK(hipMemcpy(h, d, 512, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
+            const int want = j * c[0] + (l & 15) + (l >> 4) * c[1];      // row j, column l & 15 of the group's block
+            if (h[l * 4 + j] != want) ++bad;
+        }
+        printf("tr16 pitch %4d blk %4d: H1 (lane c <- column c, rows 0..3; addresses supplied per (row, 4-col piece)) %s",
+               c[0], c[1], bad ? "FAILS" : "holds\n");
+        if (bad) { printf(" (%d mismatches) lane0: %d %d %d %d  lane1: %d %d %d %d  lane5: %d %d %d %d  lane17: %d %d %d %d\n", bad,
+               h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[20], h[21], h[22], h[23], h[68], h[69], h[70], h[71]); }
+    }
+    hipFree(d);
+}
+
+// ---- weight-gradient (TN) kernel: parts[s] summed == dY^T X, bias parts summed == column sums ------
+__global__ void ref_tn(float* out, float* bout, TnParams p) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.N * p.K) return;
+    const int n = (int)(i / p.K), k = (int)(i % p.K);
+    float s = 0.f, b = 0.f;
+    for (int m = 0; m < p.M; ++m) {
+        const float y = bfv(p.dY[(int64_t)m * p.ldy + n]);
+        s += y * bfv(p.X[(int64_t)m * p.ldx + k]);
+        b += y;
+    }
+    out[i] = s;
+    if (k == 0) bout[n] = b;
+}
+__global__ void check_tn(float* maxerr, const float* ref, const float* bref, TnParams p) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.N * p.K) return;
+    float s = 0.f;
+    for (int q = 0; q < p.S; ++q) s += p.parts[(int64_t)q * p.N * p.K + i];
+    float err = fabsf(s - ref[i]) / (1.f + fabsf(ref[i]));
+    atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(err == err ? err : 1e30f));
+    if (i < p.N) {
+        float b = 0.f;
+        for (int q = 0; q < p.S; ++q) b += p.bias_parts[(int64_t)q * p.N + i];
+        err = fabsf(b - bref[i]) / (1.f + fabsf(bref[i]));
+        atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
+    }
+}
+static void tn_tests(const char* only) {
+    struct T { int M, N, K, S; const char* what; };
+    const T ts[] = {{394, 200, 136, 3, "wgrad ragged (M tail, N/K edges)"}, {25216, 1152, 384, 16, "wgrad qkv  E384 H6"},
+                    {25216, 384, 384, 32, "wgrad proj E384"}, {25216, 1344, 384, 16, "wgrad fc1  E384 R3.5"},
+                    {25216, 384, 1344, 16, "wgrad fc2  E384 R3.5"}, {25216, 1792, 448, 8, "wgrad fc1  E448 R4"},
+                    {25216, 1792, 448, 16, "wgrad fc1  E448 R4"}, {25216, 320, 320, 32, "wgrad proj E320"},
+                    {25216, 320, 320, 64, "wgrad proj E320"}};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float* dmax; CK(hipMalloc(&dmax, 16));
+    for (const T& t : ts) {
+        if (only && !strstr(t.what, only)) continue;
+        const size_t ny = (size_t)t.M * t.N, nx = (size_t)t.M * t.K, nw = (size_t)t.N * t.K;
+        std::vector<uint16_t> hy(ny), hx(nx);
+        srand(2);
+        for (auto& v : hy) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 0.5f);
+        for (auto& v : hx) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+        uint16_t *dy, *dx; float *dparts, *dbias, *dref, *dbref;
+        CK(hipMalloc(&dy, ny * 2)); CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dparts, nw * 4 * t.S)); CK(hipMalloc(&dbias, (size_t)t.N * 4 * t.S));
+        CK(hipMalloc(&dref, nw * 4)); CK(hipMalloc(&dbref, t.N * 4));
+        CK(hipMemcpy(dy, hy.data(), ny * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+        TnParams p{dy, dx, t.N, t.K, t.M, t.N, t.K, t.S, dparts, dbias};
+        ref_tn<<<(unsigned)((nw + 255) / 256), 256>>>(dref, dbref, p);
+        CK(hipMemset(dparts, 0xFF, nw * 4 * t.S)); CK(hipMemset(dbias, 0xFF, (size_t)t.N * 4 * t.S)); CK(hipMemset(dmax, 0, 16));
+        const int grid = ((t.N + 127) / 128) * ((t.K + 127) / 128) * t.S;
+        hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
+        check_tn<<<(unsigned)((nw + 255) / 256), 256>>>(dmax, dref, dbref, p);
+        float hm[4]; CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        const double us = ms(e0, e1) / 20 * 1e3, fl = 2.0 * t.M * t.N * t.K;
+        printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  %7.1f us %6.0f TF/s  err dW %.2e bias %.2e %s\n", t.what, t.M, t.N, t.K, t.S, grid, us,
+               fl / us / 1e6, hm[0], hm[1], (hm[0] > 1e-3f || hm[1] > 1e-3f) ? " <-- WRONG" : "");
+        hipFree(dy); hipFree(dx); hipFree(dparts); hipFree(dbias); hipFree(dref); hipFree(dbref);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const char* only_shape = argc > 1 ? argv[1] : nullptr;
+    const char* only_var = argc > 2 ? argv[2] : nullptr;
+    if (!only_shape) tr16_semantics();
+    if (!only_shape || strstr(only_shape, "wgrad")) tn_tests(only_shape);
+    if (only_shape && strstr(only_shape, "wgrad")) return 0;
+    { float* d; CK(hipMalloc(&d, 8)); CK(hipMemset(d, 0, 8)); gelu_accuracy<<<1, 256>>>(d); float h[2]; CK(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+      printf("fast erf-GELU vs libm erff on [-10, 10]: max |gelu err| %.3e, max |gelu' err| %.3e\n", h[0], h[1]); }
+    struct Shape { int M, N, K, ldb, nseg, kseg; const char* what; };
+    const int M = 25216;
+    const Shape shapes[] = {
+        {1000, 200, 136, 144, 1 << 30, 1 << 30, "ragged check (M, N edges, K tail 8)"},
+        {1000, 384, 384, 448, 128, 128, "segment check (3 row segs, 3 k segs)"},
+        {M, 1152, 384, 448, 384, 1 << 30, "qkv fwd   E384 H6 (q|k|v row segs)"},
+        {M, 384, 384, 448, 1 << 30, 1 << 30, "proj fwd  E384 Q384"},
+        {M, 1344, 384, 448, 1 << 30, 1 << 30, "fc1 fwd   E384 R3.5"},
+        {M, 384, 1344, 1792, 1 << 30, 1 << 30, "fc2 fwd   E384 R3.5"},
+        {M, 384, 1152, 448, 1 << 30, 384, "qkv dgrad E384 H6 (k segs)"},
+        {M, 1344, 448, 448, 1 << 30, 1 << 30, "qkv fwd   E448 H7"},
+        {M, 448, 448, 448, 1 << 30, 1 << 30, "proj fwd  E448 Q448"},
+        {M, 1792, 448, 448, 1 << 30, 1 << 30, "fc1 fwd   E448 R4"},
+        {M, 448, 1792, 1792, 1 << 30, 1 << 30, "fc2 fwd   E448 R4"},
+        {M, 960, 320, 448, 1 << 30, 1 << 30, "fc1 fwd   E320 R3"},
+        {M, 320, 320, 448, 1 << 30, 1 << 30, "proj fwd  E320 Q320"},
+        {M, 320, 1120, 1792, 1 << 30, 1 << 30, "fc2 fwd   E320 R3.5 (K tail 32)"},
+    };
+    hipblasLtHandle_t lt;
+    hipblasLtCreate(&lt);
+    void* ws;
+    const size_t wsb = 128 << 20;
+    CK(hipMalloc(&ws, wsb));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float* dmax; CK(hipMalloc(&dmax, 16));
+    for (const Shape& s : shapes) {
+        if (only_shape && !strstr(s.what, only_shape)) continue;
+        const bool plain = s.nseg >= s.N && s.kseg >= s.K;
+        const int nsegs = s.nseg >= s.N ? 1 : (s.N + s.nseg - 1) / s.nseg, ksegs = s.kseg >= s.K ? 1 : (s.K + s.kseg - 1) / s.kseg;
+        const int64_t seg_rows = 448;                                     // super rows of one segment
+        const int64_t nseg_stride = seg_rows * s.ldb * ksegs, kseg_stride = seg_rows * s.ldb;
+        const size_t nx = (size_t)s.M * s.K, nw = (size_t)nseg_stride * nsegs + (size_t)seg_rows * s.ldb * 2 + (size_t)s.N * s.ldb,
+                     no = (size_t)s.M * s.N;
+        std::vector<uint16_t> hx(nx), hw(nw), hb(s.N), hh(no);
+        srand(1);
+        for (auto& v : hx) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+        for (auto& v : hw) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 0.2f);
+        for (auto& v : hb) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f));
+        for (auto& v : hh) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 4.f);
+        uint16_t *dx, *dw, *db, *dout, *dout2, *dlib, *dh;
+        float *dref, *dcs;
+        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&db, s.N * 2)); CK(hipMalloc(&dh, no * 2));
+        CK(hipMalloc(&dout, no * 2)); CK(hipMalloc(&dout2, no * 2)); CK(hipMalloc(&dlib, no * 2)); CK(hipMalloc(&dref, no * 4));
+        CK(hipMalloc(&dcs, (size_t)((s.M + 63) / 64) * s.N * 4));
+        CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), s.N * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dh, hh.data(), no * 2, hipMemcpyHostToDevice));
+        NtParams p{};
+        p.A = dx; p.lda = s.K; p.B = dw; p.ldb = s.ldb;
+        p.nseg = s.nseg >= s.N ? s.N : s.nseg; p.nseg_stride = nseg_stride; p.kseg = s.kseg >= s.K ? s.K : s.kseg; p.kseg_stride = kseg_stride;
+        p.M = s.M; p.N = s.N; p.K = s.K; p.out = dout; p.out2 = dout2; p.ldo = s.N; p.bias = db; p.aux = dh; p.ldaux = s.N; p.colsum = dcs;
+        ref_nt<<<(unsigned)((no + 255) / 256), 256>>>(dref, p);
+        CK(hipDeviceSynchronize());
+        // the library on the same problem (plain layouts only): col-major C(N x M) = W('t', lda = ldb) . x('n', ldb = K) + bias
+        double lib_us = -1;
+        if (plain && s.M > 2000 && !only_var) {
+            hipblasLtMatmulDesc_t d;
+            hipblasLtMatrixLayout_t la, lb, lc;
+            hipblasLtMatmulDescCreate(&d, HIPBLAS_COMPUTE_32F, HIP_R_32F);
+            const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+            hipblasLtMatmulDescSetAttribute(d, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(int32_t));
+            hipblasLtMatmulDescSetAttribute(d, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(int32_t));
+            const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+            const hipDataType bt = HIP_R_16BF;
+            const void* bp = db;
+            hipblasLtMatmulDescSetAttribute(d, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof ep);
+            hipblasLtMatmulDescSetAttribute(d, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof bt);
+            hipblasLtMatmulDescSetAttribute(d, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof bp);
+            hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, s.K, s.N, s.ldb);
+            hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, s.K, s.M, s.K);
+            hipblasLtMatrixLayoutCreate(&lc, HIP_R_16BF, s.N, s.M, s.N);
+            hipblasLtMatmulPreference_t pref;
+            hipblasLtMatmulPreferenceCreate(&pref);
+            hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof wsb);
+            hipblasLtMatmulHeuristicResult_t hr[16];
+            int n = 0;
+            if (hipblasLtMatmulAlgoGetHeuristic(lt, d, la, lb, lc, lc, pref, 16, hr, &n) == HIPBLAS_STATUS_SUCCESS) {
+                const float one = 1.f, zero = 0.f;
+                for (int a = 0; a < n; ++a) {
+                    bool ok = true;
+                    for (int i = 0; i < 2 && ok; ++i)
+                        ok = hipblasLtMatmul(lt, d, &one, dw, la, dx, lb, &zero, dlib, lc, dlib, lc, &hr[a].algo, ws, wsb, 0) == HIPBLAS_STATUS_SUCCESS;
+                    if (!ok) continue;
+                    hipEventRecord(e0);
+                    for (int i = 0; i < 10; ++i)
+                        hipblasLtMatmul(lt, d, &one, dw, la, dx, lb, &zero, dlib, lc, dlib, lc, &hr[a].algo, ws, wsb, 0);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    const double us = ms(e0, e1) / 10 * 1e3;
+                    if (lib_us < 0 || us < lib_us) lib_us = us;
+                }
+            }
+        }
+        const double fl = 2.0 * s.M * s.N * s.K;
+        printf("%-38s M=%5d N=%4d K=%4d  library best-of-16 %7.1f us %6.0f TF/s\n", s.what, s.M, s.N, s.K, lib_us, lib_us > 0 ? fl / lib_us / 1e6 : 0.0);
+        for (const Variant& v : VARIANTS) {
+            if (!plain && v.epi != EPI_BIAS) continue;
+            if (only_var && !strstr(v.name, only_var)) continue;
+            CK(hipMemset(dout, 0xFF, no * 2));
+            CK(hipMemset(dout2, 0xFF, no * 2));
+            CK(hipMemset(dmax, 0, 16));
+            launch(v, p);
+            check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
+            if (v.epi == EPI_DGELU_COLSUM) check_colsum<<<(((s.M + v.bm - 1) / v.bm) * s.N + 255) / 256, 256>>>(dmax, p, v.bm);
+            float hm[4];
+            CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 3; ++i) launch(v, p);
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) launch(v, p);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            const double us = ms(e0, e1) / 20 * 1e3;
+            const bool bad = hm[0] > 0.02f || hm[1] > 0.02f || hm[2] > 1e-3f;
+            printf("    %-34s %7.1f us %6.0f TF/s  %5.2fx lib   err out %.2e gelu %.2e colsum %.2e %s\n", v.name, us, fl / us / 1e6,
+                   lib_us > 0 ? lib_us / us : 0.0, hm[0], hm[1], hm[2], bad ? " <-- WRONG" : "");
+        }
+        hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dh); hipFree(dcs);
+        fflush(stdout);
+    }
+    return 0;
+}
