@@ -257,13 +257,24 @@ def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, sca
     return path
 
 
-def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scaler=None, eval_only=False):
+def _read_checkpoint(path, trusted):
+    """torch.load with tensors-only unpickling; full unpickling (needed for the argparse Namespace in
+    the 'args' entry of our own training checkpoints, supernet_train.py:369) only for files the caller
+    explicitly trusts — a downloaded supernet-*.pth is never executed as a pickle program."""
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception:
+        if not trusted:
+            raise
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_checkpoint(path_or_dict, model, optimizer=None, lr_scheduler=None, scaler=None, eval_only=False, trusted=False):
     """The resume logic of supernet_train.py:316-330: 'model' always; optimizer / lr_scheduler /
     epoch (+ scaler) only when all three are present and not `eval_only`.  Accepts published
     `supernet-*.pth` files ({'model': state_dict}).  Returns the epoch to START from (0 when the
     file carries no training state).  The bf16 operand copies of the fused blocks are re-derived."""
-    ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu',
-                                                                         weights_only=False)
+    ckpt = path_or_dict if isinstance(path_or_dict, dict) else _read_checkpoint(path_or_dict, trusted)
     model.load_state_dict(ckpt['model'])
     _block.refresh_operands(model, force=True)
     start_epoch = 0

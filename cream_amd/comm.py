@@ -16,9 +16,15 @@ for the CPU tests).  Design points, MI355X-first rather than DDP-reducer-first:
     so the set of parameters that receive gradients is known up front: blocks beyond the
     sampled depth are not "unused parameters" to be discovered, their buckets are simply
     not sent (their gradients stay exactly zero on every rank).  No dead bytes on xGMI.
-  * averaging = SUM all-reduce followed by an in-place 1/world scale of the flat buffer
-    (DDP semantics; lr is already scaled by the world size, supernet_train.py:294).
+  * averaging = one AVG all-reduce where the backend has it (RCCL), else SUM followed by an
+    in-place 1/world scale (gloo) — DDP semantics; lr is already scaled by the world size,
+    supernet_train.py:294;
+  * like DistributedDataParallel, construction BROADCASTS rank 0's parameters and buffers: the
+    reference seeds `torch.manual_seed(args.seed + rank)` (supernet_train.py:197-198), so without it
+    every rank would start from different weights and gradient averaging alone never reconciles them.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -64,12 +70,42 @@ class GradReducer:
         self.active = set()
         self.bytes_sent = 0
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.use_avg = False
         if self.world > 1:
+            if dist.is_initialized():
+                # what DDP does at wrap time (supernet_train.py:286-289): same weights on every rank
+                with torch.no_grad():
+                    for t in list(model.parameters()) + list(model.buffers()):
+                        dist.broadcast(t.data, src=0, group=self.pg)
+                self.use_avg = dist.get_backend(self.pg) == "nccl"
+            # hooks hold the reducer WEAKLY: a discarded reducer must not keep firing (or stay alive)
+            ref = weakref.ref(self)
+
+            def hook(p, ref=ref):
+                me = ref()
+                if me is not None:
+                    me._hook(p)
+
             for _, p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                p.register_post_accumulate_grad_hook(hook)
             # fused blocks write their parameter gradients themselves and announce them
             from .autoformer import block as _block
-            self._ready_cb = _block.on_grads_ready(lambda params: [self._hook(p) for p in params])
+
+            def ready(params, ref=ref):
+                me = ref()
+                if me is None:
+                    _block.remove_grads_ready(ready)
+                else:
+                    for p in params:
+                        me._hook(p)
+
+            self._ready_cb = _block.on_grads_ready(ready)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def close(self):
         cb = getattr(self, "_ready_cb", None)
@@ -120,8 +156,11 @@ class GradReducer:
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
-                buf.mul_(1.0 / self.world)
+                if self.use_avg:
+                    dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)      # one pass over the bucket
+                else:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+                    buf.mul_(1.0 / self.world)
         else:
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self.works.append((w, buf))

@@ -108,21 +108,25 @@ BwdLayout bwd_layout(const Dims& x) {
 }
 
 // events that order the side stream behind the main stream (re-recorded freely: a wait refers to
-// the most recent record at the time it is enqueued)
+// the most recent record at the time it is enqueued).  One pool PER DEVICE: an event belongs to the
+// device that was current when it was created, and a process may drive more than one GPU.
+constexpr int MAX_DEV = 16, EV_PER_DEV = 8;
 std::mutex g_ev_mu;
-hipEvent_t g_ev[8];
-int g_ev_n = 0, g_ev_next = 0;
+hipEvent_t g_ev[MAX_DEV][EV_PER_DEV];
+int g_ev_n[MAX_DEV] = {}, g_ev_next[MAX_DEV] = {};
 bool fork(hipStream_t main, hipStream_t side) {
     if (main == side) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
     hipEvent_t ev;
     {
         std::lock_guard<std::mutex> lock(g_ev_mu);
-        if (g_ev_n < 8) {
-            if (hipEventCreateWithFlags(&g_ev[g_ev_n], hipEventDisableTiming) != hipSuccess) return false;
-            ++g_ev_n;
+        if (g_ev_n[dev] < EV_PER_DEV) {
+            if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], hipEventDisableTiming) != hipSuccess) return false;
+            ++g_ev_n[dev];
         }
-        ev = g_ev[g_ev_next];
-        g_ev_next = (g_ev_next + 1) % g_ev_n;
+        ev = g_ev[dev][g_ev_next[dev]];
+        g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
     }
     return hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
 }

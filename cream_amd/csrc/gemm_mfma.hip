@@ -138,8 +138,10 @@ int cream_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128), steps = (M + 63) / 64;
-    int s = (512 + tiles - 1) / tiles;                          // ~2 workgroups per CU in flight
-    if (s > 32) s = 32;
+    // ~1 workgroup per CU: the weight gradients run beside the main chain on the side stream, and every
+    // extra split is another fp32 partial tile through HBM (written here, read by cream_grad_finalize)
+    int s = (256 + tiles - 1) / tiles;
+    if (s > 16) s = 16;
     if (s > steps) s = steps;
     return s < 1 ? 1 : s;
 }

@@ -19,10 +19,13 @@ def install():
     return PATH
 
 
-def install_autoformer(reference_model_dir=None):
+def install_autoformer(reference_model_dir=None, fast_path=True):
     """Make `import model.supernet_transformer` resolve the REFERENCE's unchanged
     supernet_transformer.py (from `reference_model_dir`, e.g. .../AutoFormer/model) while
-    `model.module.*` and `model.utils` resolve to the MI355X implementations here."""
+    `model.module.*` and `model.utils` resolve to the MI355X implementations here.  With
+    `fast_path` the caller's classes are patched at import (SURVEY 8b allows exactly this) so that a
+    bf16-autocast forward on the GPU runs the whole block stack as one native autograd node
+    (`enable_fast_path`); everything else keeps executing the reference's own code."""
     import importlib
     install()
     for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
@@ -30,4 +33,27 @@ def install_autoformer(reference_model_dir=None):
     pkg = importlib.import_module("model")
     if reference_model_dir and reference_model_dir not in pkg.__path__:
         pkg.__path__.append(reference_model_dir)      # searched AFTER our directory
+        if fast_path:
+            enable_fast_path(importlib.import_module("model.supernet_transformer"))
     return pkg
+
+
+def enable_fast_path(caller):
+    """Patch a caller module that defines `Vision_TransformerSuper` / `TransformerEncoderLayer` with
+    the reference's attribute names (AutoFormer/model/supernet_transformer.py:20-172, 175-294): its
+    `forward_features` is replaced by the one of cream_amd/autoformer/supernet.py, which hands the run
+    of active blocks to `block.StackFunction` (one native call per block and direction) when the
+    input is a CUDA tensor under bf16 autocast and every block is supported — and otherwise runs the
+    caller's OWN `TransformerEncoderLayer.forward` block by block, i.e. the unchanged file."""
+    from cream_amd.autoformer import supernet as ours
+    layer, model = caller.TransformerEncoderLayer, caller.Vision_TransformerSuper
+    if getattr(model, "_cream_fast_path", False):
+        return caller
+    layer.fused = True
+    layer._dp = None
+    layer.drop_path_scales = ours.TransformerEncoderLayer.drop_path_scales
+    model._keep_prob = ours.Vision_TransformerSuper._keep_prob
+    model._cream_reference_forward_features = model.forward_features
+    model.forward_features = ours.Vision_TransformerSuper.forward_features
+    model._cream_fast_path = True
+    return caller

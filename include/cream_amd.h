@@ -225,7 +225,7 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
  *                             whole 64-row steps, as even as possible; added by cream_grad_finalize);
  *                             bias_parts[s](N) = column sums of dy_s — the bias gradient rides on the
  *                             same kernel (NULL: not wanted).  cream_linear_wgrad_splits gives the S
- *                             this library uses for a problem (~2 workgroups per CU). */
+ *                             this library uses for a problem (~1 workgroup per CU, at most 16). */
 int cream_gemm_rows_per_colsum_slab(void);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);

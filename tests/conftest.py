@@ -18,9 +18,17 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     have_ref = os.path.isdir(REFERENCE)
     skip_ref = pytest.mark.skip(reason="/root/reference not present on this machine")
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    skip_gpu = pytest.mark.skip(reason="no HIP device on this machine (run with -m gpu on the MI355X box)")
     for item in items:
         if "reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+        if "gpu" in item.keywords and not have_gpu:
+            item.add_marker(skip_gpu)
 
 
 @pytest.fixture(scope="session", autouse=True)

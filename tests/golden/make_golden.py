@@ -194,6 +194,117 @@ def irpe():
          **grad_digest(grads))
 
 
+def irpe_ext():
+    """Round-2 fixtures (VERDICT r1 #1c, #5): the rest of the iRPE family the way the reference's other
+    callers use it — bias mode (shared / per head), euclidean / quant / cross methods, skip = 0 and
+    non-square maps (DETR-with-iRPE/models/transformer.py:49-69, rpe_attention_function.py:328-376) —
+    and RPEAttention at the DeiT-base-384 sequence length L = 577 (BASELINE config 4 geometry)."""
+    irpe = refshim.load_irpe_reference(with_dropin=False)
+    outs = {}
+    cases = [
+        ('bias_shared', dict(ratio=1.9, method='product', mode='bias', shared_head=True, skip=1, rpe_on='qk'), 3, 14, 14),
+        ('euc_ctx', dict(ratio=1.9, method='euc', mode='ctx', shared_head=True, skip=1, rpe_on='qkv'), 3, 14, 14),
+        ('quant_ctx', dict(ratio=1.9, method='quant', mode='ctx', shared_head=False, skip=1, rpe_on='qkv'), 2, 14, 14),
+        ('cross_ctx', dict(ratio=1.9, method='cross', mode='ctx', shared_head=True, skip=1, rpe_on='qkv'), 2, 14, 14),
+        ('cross_bias', dict(ratio=1.9, method='cross', mode='bias', shared_head=False, skip=1, rpe_on='k'), 2, 14, 14),
+        ('skip0_rect', dict(ratio=1.9, method='product', mode='ctx', shared_head=True, skip=0, rpe_on='qkv'), 2, 10, 14),
+        ('skip0_rect_bias', dict(ratio=1.9, method='product', mode='bias', shared_head=False, skip=0, rpe_on='k'), 2, 9, 5),
+    ]
+    meta = []
+    for tag, kw, heads, h, w in cases:
+        cfg = irpe.get_rpe_config(**kw)
+        mods = irpe.build_rpe(cfg, head_dim=64, num_heads=heads)
+        L = h * w + kw['skip']
+        g = torch.Generator().manual_seed(zlib_seed(tag))
+        meta.append(dict(tag=tag, kw=kw, heads=heads, h=h, w=w, L=L))
+        for which, mod in zip('qkv', mods):
+            if mod is None:
+                continue
+            with torch.no_grad():
+                for p in mod.parameters():
+                    p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            if which == 'v':
+                x = torch.randn(2, heads, L, L, generator=g).softmax(-1).requires_grad_()
+            else:
+                x = torch.randn(2, heads, L, 64, generator=g, requires_grad=True)
+            y = mod(x, height=h, width=w)
+            gy = torch.randn(y.shape, generator=g)
+            params = list(mod.parameters())
+            grads = torch.autograd.grad(y, [x] + params, gy, allow_unused=True)
+            sub = (lambda t: t[:, :, ::7, ::5] if (t.shape[-1] == L and L > 150) else t)    # keep the files small
+            outs[f'{tag}|{which}|y'] = sub(y)
+            outs[f'{tag}|{which}|ysum'] = y.double().sum().reshape(1)
+            if grads[0] is not None:
+                outs[f'{tag}|{which}|dx'] = sub(grads[0])
+            for i, gp in enumerate(grads[1:]):
+                outs[f'{tag}|{which}|dw{i}'] = gp
+    json.dump(meta, open(os.path.join(HERE, 'irpe_modules_ext.json'), 'w'), indent=1)
+    save('irpe_modules_ext.npz', **outs)
+
+    # RPEAttention at L = 577 (24 x 24 + class token), 3 heads of 64, rpe on k and on q, k, v
+    irpe2, rvt, models, rpe_models = refshim.load_irpe_models()
+    outs = {}
+    for rpe_on in ('k', 'qkv'):
+        cfg = irpe2.get_rpe_config(ratio=1.9, method='product', mode='ctx', shared_head=True, skip=1, rpe_on=rpe_on)
+        att = rvt.RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg)
+        fill_params(att, seed=29)
+        with torch.no_grad():
+            for n, p in att.named_parameters():
+                if 'lookup_table' in n:
+                    p.copy_(0.3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n) + 5)))
+        g = torch.Generator().manual_seed(43)
+        x = torch.randn(1, 577, 192, generator=g, requires_grad=True)
+        gy = torch.randn(1, 577, 192, generator=g)
+        y = att(x)
+        y.backward(gy)
+        grads = {k: p.grad for k, p in att.named_parameters()}
+        outs[f'{rpe_on}|y'] = y[:, ::3]
+        outs[f'{rpe_on}|dx'] = x.grad[:, ::3]
+        for k, v in grads.items():
+            if 'lookup' in k or k.endswith('bias'):
+                outs[f'{rpe_on}|full|{k}'] = v
+        for k, v in grad_digest(grads).items():
+            outs[f'{rpe_on}|{k}'] = v
+    save('irpe_attention_L577.npz', **outs)
+
+
+def zlib_seed(tag):
+    import zlib
+    return zlib.crc32(tag.encode()) & 0x7fffffff
+
+
+def autoformer_trace():
+    """The boundary as the reference's UNCHANGED caller drives it: every call that
+    model/supernet_transformer.py makes into `model.module.*` while it builds AutoFormer-T, applies a
+    sampled configuration and runs one forward — class, constructor arguments, set_sample_config
+    arguments, forward input shapes, in order.  The GPU box has no reference checkout: there the
+    test replays OUR caller (cream_amd/autoformer/supernet.py) under the same recorder and requires the
+    identical trace, then checks the numbers of the same step against autoformer_T_step.npz."""
+    import cream_amd.dropin as d
+    from cream_amd.dropin import trace as T
+    refshim._install_torch_six()
+    try:
+        d.install_autoformer(os.path.join(refshim.AUTOFORMER, 'model'))
+        import importlib
+        st = importlib.import_module('model.supernet_transformer')
+        assert st.__file__.startswith('/root/reference/')
+        rec = T.Recorder()
+        with rec.patch(st):
+            m = st.Vision_TransformerSuper(**model_kwargs('T'))
+            cfg = json.loads(bytes(np.load(os.path.join(HERE, 'autoformer_T_step.npz'))['config']).decode())
+            m.set_sample_config(cfg)
+            m.train()
+            images, target = make_batch(2, seed=5)
+            m(images)
+        json.dump(rec.events, open(os.path.join(HERE, 'autoformer_call_trace.json'), 'w'))
+        print(f'wrote autoformer_call_trace.json: {len(rec.events)} boundary calls')
+    finally:
+        for k in [k for k in sys.modules if k == 'model' or k.startswith('model.')]:
+            del sys.modules[k]
+        if d.PATH in sys.path:
+            sys.path.remove(d.PATH)
+
+
 if __name__ == '__main__':
     assert refshim.have_reference(), "needs the reference checkout at /root/reference"
     which = sys.argv[1:] or ['autoformer', 'irpe']
@@ -201,3 +312,7 @@ if __name__ == '__main__':
         autoformer()
     if 'irpe' in which:
         irpe()
+    if 'irpe_ext' in which:
+        irpe_ext()
+    if 'autoformer_trace' in which:
+        autoformer_trace()

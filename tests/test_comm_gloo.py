@@ -20,11 +20,19 @@ def _worker(rank, world, port, q):
     from cream_amd.autoformer import engine
     r, _, w = comm.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
-    torch.manual_seed(0)                                       # same weights on both ranks
+    torch.manual_seed(7 + rank)                                # DIFFERENT initial weights per rank, as under the reference's
+                                                               # torch.manual_seed(args.seed + rank) (supernet_train.py:197-198):
+                                                               # the reducer must broadcast rank 0's, like DDP does at wrap time
     model = engine.build_supernet("T", drop_path_rate=0.0, img_size=64, depth=3, embed_dim=128, num_heads=2)
     choices = dict(mlp_ratio=[3.5, 4], num_heads=[1, 2], depth=[2, 3], embed_dim=[64, 128])
     opt = engine.build_optimizer(model, lr=1e-3, batch_size=4, world_size=world)
+    before = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
     reducer = comm.GradReducer(model)
+    after = torch.cat([p.detach().flatten() for p in model.parameters()])
+    same = [torch.zeros_like(after) for _ in range(world)]
+    dist.all_gather(same, after)
+    assert torch.equal(same[0], same[1]), "GradReducer did not broadcast rank 0's parameters"
+    assert rank == 0 and torch.equal(before, after) or rank == 1 and not torch.equal(before, after)
     tr = engine.SupernetTrainer(model, opt, choices, reducer, amp_dtype=torch.float32)
     g = torch.Generator().manual_seed(100 + rank)              # different data per rank
     images = torch.randn(4, 3, 64, 64, generator=g)

@@ -128,3 +128,83 @@ def test_deit_tiny_irpe_k_single_image_forward():
     with torch.no_grad():
         logits = model(x)
     assert max_rel(logits, fix["logits"]) < 1e-4
+
+
+def _ext_cases():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "irpe_modules_ext.json")))
+
+
+def _zseed(tag):
+    import zlib
+    return zlib.crc32(tag.encode()) & 0x7fffffff
+
+
+def run_ext_case(I, case, device="cpu", tol=1e-5):
+    """One case of the reference-made irpe_modules_ext fixture (bias / euclidean / quant / cross,
+    skip = 0, non-square maps) through the module family `I` on `device`."""
+    fix = load_npz("irpe_modules_ext.npz")
+    tag, kw, heads, h, w, L = case["tag"], case["kw"], case["heads"], case["h"], case["w"], case["L"]
+    cfg = I.get_rpe_config(**kw)
+    mods = I.build_rpe(cfg, head_dim=64, num_heads=heads)
+    g = torch.Generator().manual_seed(_zseed(tag))
+    for which, mod in zip("qkv", mods):
+        if mod is None:
+            continue
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        if which == "v":
+            x = torch.randn(2, heads, L, L, generator=g).softmax(-1)
+        else:
+            x = torch.randn(2, heads, L, 64, generator=g)
+        mod = mod.to(device)
+        x = x.to(device).requires_grad_()
+        y = mod(x, height=h, width=w)
+        gy = torch.randn(y.shape, generator=g).to(device)
+        params = list(mod.parameters())
+        grads = torch.autograd.grad(y, [x] + params, gy, allow_unused=True)
+        sub = (lambda t: t[:, :, ::7, ::5] if (t.shape[-1] == L and L > 150) else t)
+        assert max_rel(sub(y).detach().cpu(), fix[f"{tag}|{which}|y"]) < tol, (tag, which)
+        ysum = float(fix[f"{tag}|{which}|ysum"][0])
+        assert abs(float(y.double().sum()) - ysum) < 1e-3 * max(1.0, abs(ysum))
+        if grads[0] is not None:
+            assert max_rel(sub(grads[0]).cpu(), fix[f"{tag}|{which}|dx"]) < tol, (tag, which)
+        for i, gp in enumerate(grads[1:]):
+            assert max_rel(gp.cpu(), fix[f"{tag}|{which}|dw{i}"]) < tol, (tag, which, i)
+        mod.to("cpu")
+
+
+@pytest.mark.parametrize("case", _ext_cases(), ids=lambda c: c["tag"])
+def test_extended_family_matches_reference(case):
+    run_ext_case(I, case)
+
+
+@pytest.mark.parametrize("rpe_on", ["k", "qkv"])
+def test_rpe_attention_L577_matches_reference(rpe_on):
+    run_attention_L577(rpe_on, "cpu", 1e-4)
+
+
+def run_attention_L577(rpe_on, device, tol, autocast=False):
+    from cream_amd.rpe_attention import RPEAttention
+    fix = load_npz("irpe_attention_L577.npz")
+    cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on=rpe_on)
+    att = RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg)
+    fill_params(att, seed=29)
+    with torch.no_grad():
+        for n, p in att.named_parameters():
+            if "lookup_table" in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n) + 5)))
+    att = att.to(device)
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(1, 577, 192, generator=g).to(device).requires_grad_()
+    gy = torch.randn(1, 577, 192, generator=g).to(device)
+    with torch.autocast(torch.device(device).type, dtype=torch.bfloat16, enabled=autocast):
+        y = att(x)
+    y.float().backward(gy)
+    worst = max(max_rel(y[:, ::3].detach().float().cpu(), fix[f"{rpe_on}|y"]), max_rel(x.grad[:, ::3].cpu(), fix[f"{rpe_on}|dx"]))
+    for k, v in fix.items():
+        if k.startswith(f"{rpe_on}|full|"):
+            worst = max(worst, max_rel(dict(att.named_parameters())[k[len(rpe_on) + 6:]].grad.cpu(), v))
+    assert worst < tol, worst
+    return worst

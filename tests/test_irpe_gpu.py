@@ -79,3 +79,64 @@ def test_deit_base_384_attention_bf16_runs_and_is_close():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = att(x)
     assert y.dtype == torch.bfloat16 and max_rel(y.detach().float().cpu(), ref.detach().cpu()) < 3e-2
+
+
+# ---- the boundary on the device: the import paths the reference's callers use ------------
+def _dropin():
+    """`import irpe` / `from rpe_ops.rpe_index import RPEIndexFunction` / `import rpe_index_cpp`
+    exactly as iRPE/DeiT-with-iRPE/irpe.py:8-15 and rpe_ops/rpe_index.py:2-8 write them, resolved
+    to the drop-in package."""
+    import importlib
+    import cream_amd.dropin as d
+    for k in [k for k in sys.modules if k in ("irpe", "rpe_index_cpp") or k.startswith("rpe_ops")]:
+        del sys.modules[k]
+    d.install()
+    return (importlib.import_module("irpe"), importlib.import_module("rpe_ops.rpe_index"),
+            importlib.import_module("rpe_index_cpp"))
+
+
+def test_reference_selftest_through_dropin_on_gpu():
+    """The reference's only known-answer test of the operator (rpe_ops/rpe_index.py:59-100): random
+    x (128, 32, 50, 50), random int32 index, op forward == flat-index gather, op backward under a random
+    mask == autograd of the gather — through the drop-in import path, on the device, bit-exact."""
+    _, rpe_index, cpp = _dropin()
+    assert cpp.version() == "1.2.0" and all(hasattr(cpp, n) for n in ("forward_cpu", "backward_cpu", "forward_gpu", "backward_gpu"))
+    import numpy as np
+    B, H, L_query, L_key, num_buckets = 128, 32, 50, 50, 50
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, L_query, num_buckets, generator=g).to(DEV).requires_grad_()
+    index = torch.randint(0, num_buckets, (L_query, L_key), generator=g).int().to(DEV)
+    offset = torch.arange(0, L_query * num_buckets, num_buckets, device=DEV).view(-1, 1)
+    mask = (torch.rand(B, H, L_query, L_key, generator=g) < 0.5).float().to(DEV)
+    y = rpe_index.RPEIndexFunction.apply(x, index)
+    gt = x.flatten(2)[:, :, (index + offset).flatten().long()].view(B, H, L_query, L_key)
+    np.testing.assert_array_equal(gt.detach().cpu().numpy(), y.detach().cpu().numpy())
+    (gt * mask).sum().backward()
+    g_ref = x.grad.clone()
+    x.grad = None
+    (y * mask).sum().backward()
+    np.testing.assert_almost_equal(g_ref.cpu().numpy(), x.grad.cpu().numpy(), decimal=5)
+
+
+def _ext_cases():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "irpe_modules_ext.json")))
+
+
+@pytest.mark.parametrize("case", _ext_cases(), ids=lambda c: c["tag"])
+def test_extended_family_on_gpu_through_dropin(case):
+    """bias mode (shared / per head), euclidean / quant / cross, skip = 0, H != W (the DETR and MiniViT
+    callers' use) on the device against the reference-made fixture."""
+    from test_irpe_cpu import run_ext_case
+    irpe, _, _ = _dropin()
+    run_ext_case(irpe, case, device=DEV, tol=1e-4)
+
+
+@pytest.mark.parametrize("rpe_on", ["k", "qkv"])
+def test_rpe_attention_L577_on_gpu(rpe_on):
+    """RPEAttention at the DeiT-base-384 sequence length against the reference-made L = 577 fixture:
+    fp32 <= 1e-3 (north_star), bf16 autocast at its documented tolerance."""
+    from test_irpe_cpu import run_attention_L577
+    w32 = run_attention_L577(rpe_on, DEV, 1e-3)
+    w16 = run_attention_L577(rpe_on, DEV, 3e-2, autocast=True)
+    print(f"[L577 {rpe_on}] worst rel err fp32 {w32:.2e}, bf16 {w16:.2e}")
