@@ -164,8 +164,9 @@ def linear_fwd(x, w, bias, N, K, out=None):
     M = x.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().cream_linear_fwd(_p(out), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
-               "cream_linear_fwd")
+    with timing.region("gemm_nt", flops=2 * M * N * K):
+        _lib.check(_lib.load().cream_linear_fwd(_p(out), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
+                   "cream_linear_fwd")
     return out
 
 
@@ -175,8 +176,9 @@ def linear_fwd_seg(x, w3, bias, N, K, nseg, out=None):
     M = x.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().cream_linear_fwd_seg(_p(out), _p(x), _p(w3), _p(bias), M, N, K, w3.stride(1), nseg,
-                                                w3.stride(0), _stream()), "cream_linear_fwd_seg")
+    with timing.region("gemm_nt", flops=2 * M * N * K):
+        _lib.check(_lib.load().cream_linear_fwd_seg(_p(out), _p(x), _p(w3), _p(bias), M, N, K, w3.stride(1), nseg,
+                                                    w3.stride(0), _stream()), "cream_linear_fwd_seg")
     return out
 
 
@@ -185,8 +187,9 @@ def linear_gelu_fwd(x, w, bias, N, K):
     M = x.shape[0]
     h = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     g = torch.empty_like(h)
-    _lib.check(_lib.load().cream_linear_gelu_fwd(_p(h), _p(g), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
-               "cream_linear_gelu_fwd")
+    with timing.region("gemm_nt_gelu", flops=2 * M * N * K):
+        _lib.check(_lib.load().cream_linear_gelu_fwd(_p(h), _p(g), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
+                   "cream_linear_gelu_fwd")
     return h, g
 
 
@@ -195,8 +198,9 @@ def linear_dgrad(dy, wt, N, K, out=None):
     M = dy.shape[0]
     if out is None:
         out = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
-    _lib.check(_lib.load().cream_linear_dgrad(_p(out), _p(dy), _p(wt), M, N, K, wt.stride(0), _stream()),
-               "cream_linear_dgrad")
+    with timing.region("gemm_nt", flops=2 * M * N * K):
+        _lib.check(_lib.load().cream_linear_dgrad(_p(out), _p(dy), _p(wt), M, N, K, wt.stride(0), _stream()),
+                   "cream_linear_dgrad")
     return out
 
 
@@ -205,8 +209,9 @@ def linear_dgrad_seg(dy, wt3, N, K, kseg, out=None):
     M = dy.shape[0]
     if out is None:
         out = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
-    _lib.check(_lib.load().cream_linear_dgrad_seg(_p(out), _p(dy), _p(wt3), M, N, K, wt3.stride(1), kseg, wt3.stride(0),
-                                                  _stream()), "cream_linear_dgrad_seg")
+    with timing.region("gemm_nt", flops=2 * M * N * K):
+        _lib.check(_lib.load().cream_linear_dgrad_seg(_p(out), _p(dy), _p(wt3), M, N, K, wt3.stride(1), kseg, wt3.stride(0),
+                                                      _stream()), "cream_linear_dgrad_seg")
     return out
 
 
@@ -216,8 +221,9 @@ def linear_dgrad_dgelu(dy, wt, h, N, K):
     lib = _lib.load()
     dh = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
     parts = torch.empty((lib.cream_colsum128_slabs(M), K), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.cream_linear_dgrad_dgelu(_p(dh), _p(parts), _p(dy), _p(wt), _p(h), M, N, K, wt.stride(0), _stream()),
-               "cream_linear_dgrad_dgelu")
+    with timing.region("gemm_nt_dgelu", flops=2 * M * N * K):
+        _lib.check(lib.cream_linear_dgrad_dgelu(_p(dh), _p(parts), _p(dy), _p(wt), _p(h), M, N, K, wt.stride(0), _stream()),
+                   "cream_linear_dgrad_dgelu")
     return dh, parts
 
 
@@ -232,8 +238,9 @@ def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None):
         out = torch.empty((S, N, K), dtype=torch.float32, device=dy.device)
     if want_bias and bias_out is None:
         bias_out = torch.empty((S, N), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.cream_linear_wgrad_parts(_p(out), _p(bias_out) if want_bias else ctypes.c_void_p(0), _p(dy), _p(x), M, N, K,
-                                            S, _stream()), "cream_linear_wgrad_parts")
+    with timing.region("gemm_tn_wgrad", flops=2 * M * N * K):
+        _lib.check(lib.cream_linear_wgrad_parts(_p(out), _p(bias_out) if want_bias else ctypes.c_void_p(0), _p(dy), _p(x), M, N,
+                                                K, S, _stream()), "cream_linear_wgrad_parts")
     return out, (bias_out if want_bias else None)
 
 

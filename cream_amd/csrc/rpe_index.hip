@@ -6,11 +6,14 @@
 // Both are zero-FLOP, HBM-bound passes over the (B,H,Lq,Lk) tensor.  The design is
 // not a translation of the reference's one-thread-per-element grid-stride loops:
 //
-//   fwd  one WAVE owns one query row i and walks a slice of the (b,h) planes.  The
-//        row's bucket ids idx[i,:] are fetched ONCE into registers; for every plane
-//        the nb-entry lookup row is staged in a wave-private LDS table and each lane
-//        gathers 16 bytes' worth of consecutive keys from LDS and issues one 16-byte
-//        store — no div/mod per element, no index re-reads, full-width HBM writes.
+//   fwd  one WORKGROUP owns a run of query rows of ONE (b,h) plane.  Its lookup rows (a
+//        contiguous rows x nb block of the input, <= 60 KB) are staged in LDS with one
+//        coalesced read; the block's output — one contiguous slab of the (B,H,Lq,Lk)
+//        tensor — is then streamed as a FLAT array: every lane owns 16-byte ALIGNED
+//        vectors of consecutive elements (a vector may straddle two query rows), reads
+//        their bucket ids straight from the equally flat (Lq,Lk) index matrix (L2
+//        resident), gathers from the LDS block and issues one aligned dwordx4 store.
+//        No per-row ragged tails, no scattered 200-byte lookup reads, full-line writes.
 //
 //   bwd  the reference's global atomics contend on <= nb addresses per 577 adds and
 //        give a run-to-run different fp sum.  Here the observation is that idx[i,j]
@@ -50,98 +53,89 @@ constexpr int WAVE = 64;
 // ------------------------------------------------------------------------------------
 // forward: gather
 // ------------------------------------------------------------------------------------
-// grid.x = ceil(Lq / waves per block), grid.y = number of plane slices.
-// NCHUNK = ceil(Lk / (64 * V)) register-resident index chunks (V = 16 / BYTES).
-// NBT    = ceil(nb / 64) register slots used to prefetch the next plane's lookup row.
-// 16-byte stores go through a per-row buffer descriptor (raw_buffer_store_b128): rows of
-// an odd Lk are only element-aligned and hipcc splits an under-aligned vector store into
-// four dword stores; the buffer form keeps one dwordx4 per lane.
-template <int BYTES, int NCHUNK, int NBT>
-__global__ __launch_bounds__(256) void rpe_gather_rows(
+// grid = (row blocks, planes) — consecutive workgroups write consecutive memory; 1024 threads.
+// Measured evolution on config 4 (B=64, H=12, L=577, nb=50; 1.11 GB fp32 / 0.56 GB bf16 algorithmic;
+// profiles/r02_rpe_index.md): the round-1 kernel (one wave per query row walking the planes, ids in
+// registers, element-aligned 2.3 KB rows) ran at 3.4 (fp32) / 2.9 (bf16) TB/s; rocprofv3 showed the
+// memory pipeline saturated (TA busy 98 %, 74 % of wave cycles stalled on instruction issue), and
+// ablations put 0.07 of its 0.31 ms on the scattered 200-byte lookup-row reads.  This kernel:
+// 3.8-4.2 / 3.7-3.8 TB/s.  What was tried and did NOT pay on top: shifting lanes to aligned stores
+// inside the row-per-wave kernel (DPP + alignbyte: slower), small row blocks in memory order (8-64
+// rows: slower than one large block per workgroup), 256/512-thread workgroups (slower).  A pure-store
+// ablation of this mapping tops out at ~4.4 TB/s against 6.9 TB/s of a framework fill of the same
+// buffer: the remaining gap is in how concurrent store streams land on DRAM pages, not in the gather.
+template <int BYTES>
+__global__ __launch_bounds__(1024) void rpe_gather_plane(
     typename raw_elem<BYTES>::type* __restrict__ y,
     const typename raw_elem<BYTES>::type* __restrict__ in,
     const int32_t* __restrict__ idx,
-    int BH, int H, int Lq, int Lk, int nb,
+    int H, int Lq, int Lk, int nb,
     int64_t s0, int64_t s1, int64_t s2, int64_t s3,
-    int planes_per_wave, int nb_pad)
+    int rows_per_block)
 {
     using E = typename raw_elem<BYTES>::type;
     constexpr int V = 16 / BYTES;
+    const int NT = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (i >= Lq) return;                       // whole wave leaves; no block barrier below
-    E* table = reinterpret_cast<E*>(smem) + (size_t)wave * nb_pad;
-
-    // bucket ids of this query row, resident in registers for the whole plane walk
-    int32_t myidx[NCHUNK][V];
-    const int32_t* irow = idx + (int64_t)i * Lk;
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const int j = (c * WAVE + lane) * V + v;
-            myidx[c][v] = (j < Lk) ? irow[j] : 0;
+    E* table = reinterpret_cast<E*>(smem);                     // [rows of the block][nb]
+    const int tid = threadIdx.x;
+    const int p = blockIdx.y;                                  // x = row block (fastest): consecutive workgroups write
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(Lq, r0 + rows_per_block);   // consecutive memory
+    if (r0 >= r1) return;
+    const int b = p / H, h = p - b * H;
+    const E* src = in + (int64_t)b * s0 + (int64_t)h * s1 + (int64_t)r0 * s2;
+    const int total = (r1 - r0) * nb;
+    if (s3 == 1 && s2 == nb) {                                  // the block is contiguous in memory
+        for (int t = tid; t < total; t += NT) table[t] = src[t];
+    } else {
+        for (int t = tid; t < total; t += NT) {
+            const int r = t / nb, u = t - r * nb;
+            table[t] = src[(int64_t)r * s2 + (int64_t)u * s3];
         }
     }
+    __syncthreads();
 
-    const int p0 = blockIdx.y * planes_per_wave;
-    const int p1 = min(BH, p0 + planes_per_wave);
-    if (p0 >= p1) return;
-
-    auto row_ptr = [&](int p) -> const E* {
-        const int b = p / H, h = p - b * H;
-        return in + (int64_t)b * s0 + (int64_t)h * s1 + (int64_t)i * s2;
+    // flat element range of this block inside the plane, and its 16-byte aligned interior
+    E* out = y + (int64_t)p * Lq * Lk;
+    const int32_t* fidx = idx;                                 // same flat layout as one output plane
+    const int f0 = r0 * Lk, f1 = r1 * Lk;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(out + f0) & 15) / BYTES);   // elements above alignment
+    const int fa = min(f1, f0 + ((V - mis) % V));              // first aligned element
+    const int nvec = (f1 - fa) / V;
+    const int ft = fa + nvec * V;                              // tail start
+    auto gather1 = [&](int f) -> E {
+        const int i = f / Lk;                                  // (only on the <= 2 (V - 1) edge elements)
+        return table[(i - r0) * nb + fidx[f]];
     };
-    auto fetch_row = [&](E (&dst)[NBT], const E* r) {
+    if (tid < fa - f0) out[f0 + tid] = gather1(f0 + tid);
+    if (tid < f1 - ft) out[ft + tid] = gather1(ft + tid);
+
+    // per-thread walk: vector q = tid, tid + NT, ...; (i, j) advanced without divisions
+    const int stepq = (NT * V) / Lk, stepr = (NT * V) % Lk;
+    int f = fa + tid * V;
+    int i = f / Lk, j = f - i * Lk;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(idx), 0, (int)((int64_t)Lq * Lk * 4), 0x00020000);
+    for (int q = tid; q < nvec; q += NT) {
+        int32_t ids[V];
 #pragma unroll
-        for (int t = 0; t < NBT; ++t) {
-            const int u = t * WAVE + lane;
-            dst[t] = (u < nb) ? r[(int64_t)u * s3] : E(0);
+        for (int w = 0; w < V / 4 + (V < 4); ++w) {
+            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (f + 4 * w) * 4, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * w + e < V) ids[4 * w + e] = (int32_t)t4[e];
         }
-    };
-
-    E pre[NBT];
-    fetch_row(pre, row_ptr(p0));                // prefetch the first lookup row
-
-    // lanes of the last chunk that still hold a full 16-byte vector / a partial one
-    const int jl = ((NCHUNK - 1) * WAVE + lane) * V;
-    const bool last_full = jl + V <= Lk;
-    const bool last_part = !last_full && jl < Lk;
-
-    for (int p = p0; p < p1; ++p) {
-        // stage this plane's lookup row in the wave-private LDS table
+        union { u32x4 vec; E e[V]; } pk;
 #pragma unroll
-        for (int t = 0; t < NBT; ++t) {
-            const int u = t * WAVE + lane;
-            table[u] = pre[t];                 // table holds NBT*64 entries per wave
+        for (int e = 0; e < V; ++e) {
+            const int over = (j + e >= Lk) ? 1 : 0;            // the vector may run into the next query row
+            pk.e[e] = table[(i + over - r0) * nb + ids[e]];
         }
-        // issue the next plane's loads before consuming this one (latency hiding)
-        if (p + 1 < p1) fetch_row(pre, row_ptr(p + 1));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        E* out = y + ((int64_t)p * Lq + i) * Lk;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            out, 0, Lk * BYTES, 0x00020000);
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            union { u32x4 vec; E e[V]; } pk;
-#pragma unroll
-            for (int v = 0; v < V; ++v) pk.e[v] = table[myidx[c][v]];
-            const int j0 = (c * WAVE + lane) * V;
-            if (c + 1 < NCHUNK || last_full) {
-                __builtin_amdgcn_raw_buffer_store_b128(pk.vec, rs, j0 * BYTES, 0, 0);
-            } else if (last_part) {
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    if (j0 + v < Lk) out[j0 + v] = pk.e[v];
-            }
-        }
-        // the table is rewritten next iteration: same-wave LDS ops retire in order
-        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4*>(out + f) = pk.vec;           // 16-byte aligned
+        f += NT * V;
+        i += stepq;
+        j += stepr;
+        if (j >= Lk) { j -= Lk; ++i; }
     }
 }
 
@@ -453,45 +447,21 @@ int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int
     constexpr int V = 16 / BYTES;
     clear_stale_error();
     const int BH = B * H;
-    const int nchunk = ceil_div(Lk, WAVE * V);
-    const int nbt = ceil_div(nb, WAVE);
-    const int nb_pad = nbt * WAVE;              // every lane stages unconditionally
-    if (nchunk > 4 || nbt > 2) {
+    // rows of one plane per workgroup: as many as fit 60 KB of LDS, fewer when there are few planes
+    int rpb = std::min<int64_t>(Lq, 61440 / ((int64_t)nb * BYTES));
+    if (rpb < 1 || Lk < V) {
         const int64_t rows = (int64_t)BH * Lq;
         const int grid = (int)std::min<int64_t>(rows, 256 * 16);
         hipLaunchKernelGGL((rpe_gather_generic<BYTES>), dim3(grid), dim3(256), 0, st,
                            (E*)y, (const E*)in, idx, rows, H, Lq, Lk, s0, s1, s2, s3);
         return launch_status();
     }
-    // ~8 waves per SIMD across 256 CUs, but at least 8 planes per wave so that the
-    // index registers are amortised.
-    const int waves_per_block = 4;
-    const int gx = ceil_div(Lq, waves_per_block);
-    int slices = std::max(1, (256 * 32 * 2) / std::max(1, Lq));
-    int ppw = std::max(8, ceil_div(BH, slices));
-    ppw = std::min(ppw, BH);
-    const int gy = ceil_div(BH, ppw);
-    const size_t lds = (size_t)waves_per_block * nb_pad * BYTES;
-    dim3 grid(gx, gy), block(waves_per_block * WAVE);
-#define CREAM_GATHER_CASE(NC, NT)                                                         \
-    hipLaunchKernelGGL((rpe_gather_rows<BYTES, NC, NT>), grid, block, lds, st, (E*)y,       \
-                       (const E*)in, idx, BH, H, Lq, Lk, nb, s0, s1, s2, s3, ppw, nb_pad)
-    if (nbt == 1) {
-        switch (nchunk) {
-            case 1: CREAM_GATHER_CASE(1, 1); break;
-            case 2: CREAM_GATHER_CASE(2, 1); break;
-            case 3: CREAM_GATHER_CASE(3, 1); break;
-            default: CREAM_GATHER_CASE(4, 1); break;
-        }
-    } else {
-        switch (nchunk) {
-            case 1: CREAM_GATHER_CASE(1, 2); break;
-            case 2: CREAM_GATHER_CASE(2, 2); break;
-            case 3: CREAM_GATHER_CASE(3, 2); break;
-            default: CREAM_GATHER_CASE(4, 2); break;
-        }
-    }
-#undef CREAM_GATHER_CASE
+    const int nthreads = 1024;
+    int nblk = ceil_div(Lq, rpb);
+    rpb = ceil_div(Lq, nblk);                                   // equal blocks
+    const size_t lds = (size_t)rpb * nb * BYTES;
+    hipLaunchKernelGGL((rpe_gather_plane<BYTES>), dim3(nblk, BH), dim3(nthreads), lds, st, (E*)y, (const E*)in, idx, H, Lq, Lk, nb,
+                       s0, s1, s2, s3, rpb);
     return launch_status();
 }
 

@@ -305,6 +305,52 @@ def autoformer_trace():
             sys.path.remove(d.PATH)
 
 
+def fake_accuracy(config, which):
+    """Deterministic stand-in for an evaluation pass: a function of the candidate only."""
+    import zlib
+    key = repr((config['layer_num'], [float(x) for x in config['mlp_ratio']], [int(x) for x in config['num_heads']],
+                int(config['embed_dim'][0]), which))
+    return (zlib.crc32(key.encode()) % 100000) / 1000.0
+
+
+def evolution():
+    """AutoFormer/evolution.py's own EvolutionSearcher (class source executed from the read-only file,
+    its timm / dataset imports left out) driven for two generations with a stubbed evaluator: the visited
+    candidates, populations and top lists are the fixture the host-side mirror must reproduce."""
+    import ast
+    import tempfile
+    import types
+    ref = refshim.load_autoformer_reference()
+    src = open(os.path.join(refshim.AUTOFORMER, 'evolution.py')).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name == 'decode_cand_tuple') or
+            (isinstance(n, ast.ClassDef) and n.name == 'EvolutionSearcher')]
+    visited = []
+
+    def evaluate(loader, model, device, amp=True, mode='retrain', retrain_config=None):
+        acc = fake_accuracy(retrain_config, loader)
+        if loader == 'val':
+            visited.append(retrain_config)
+        return {'acc1': acc}
+
+    ns = {'random': random, 'torch': torch, 'os': os, 'np': np, 'evaluate': evaluate,
+          'utils': types.SimpleNamespace(get_rank=lambda: 0), 'print': lambda *a, **k: None}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), 'evolution.py', 'exec'), ns)
+    model = ref.Vision_TransformerSuper(**model_kwargs('S'))
+    args = types.SimpleNamespace(max_epochs=2, select_num=4, population_num=10, m_prob=0.2, s_prob=0.4, crossover_num=4,
+                                 mutation_num=4, param_limits=23, min_param_limits=18, resume='', amp=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        es = ns['EvolutionSearcher'](args, 'cpu', model, model, SUPERNETS['S']['choices'], 'val', 'test', tmp)
+        random.seed(0)
+        es.search()
+    out = dict(args=vars(args), memory=es.memory, top50=es.keep_top_k[50], top_select=es.keep_top_k[4],
+               candidates=es.candidates, top_accuracies=es.top_accuracies,
+               visited=[[c['layer_num'], c['mlp_ratio'], c['num_heads'], c['embed_dim'][0]] for c in visited],
+               params={repr(k): v.get('params') for k, v in es.vis_dict.items() if 'params' in v})
+    json.dump(out, open(os.path.join(HERE, 'evolution_trace.json'), 'w'))
+    print(f"wrote evolution_trace.json: {len(visited)} evaluated candidates, {len(es.vis_dict)} seen")
+
+
 if __name__ == '__main__':
     assert refshim.have_reference(), "needs the reference checkout at /root/reference"
     which = sys.argv[1:] or ['autoformer', 'irpe']
@@ -316,3 +362,5 @@ if __name__ == '__main__':
         irpe_ext()
     if 'autoformer_trace' in which:
         autoformer_trace()
+    if 'evolution' in which:
+        evolution()

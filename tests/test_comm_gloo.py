@@ -58,6 +58,36 @@ def _worker(rank, world, port, q):
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     in_sync = torch.equal(both[0], both[1])
+    # ---- the native block path announces a block's gradients itself (block._notify, called from
+    # StackFunction.backward in REVERSE block order) instead of per-parameter autograd hooks: emulate that
+    # ordering on the CPU — gradients written straight into the arena views, blocks announced last to
+    # first, stem / tail through the ordinary hook — and the reduce-scatter + all-gather variant
+    from cream_amd.autoformer import block as _block
+    ok_notify = {}
+    for mode in ("allreduce", "rs_ag"):
+        reducer.close()
+        red2 = comm.GradReducer(model, mode=mode)
+        red2.zero_grad()
+        red2.prepare(cfg)
+        off = 0
+        for p in model.parameters():                           # this rank's local gradient
+            p.grad.copy_(local[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        for n, p in model.named_parameters():
+            if n.startswith(("norm.", "head.")):
+                red2._hook(p)
+        for i in reversed(range(cfg["layer_num"])):
+            _block._notify(model.blocks[i])                    # what StackFunction._backward_native does per block
+        for n, p in model.named_parameters():
+            if not n.startswith(("norm.", "head.", "blocks.")):
+                red2._hook(p)
+        assert all(v == 0 for v in red2.pending.values()), red2.pending
+        red2.finish()
+        got = torch.cat([p.grad.flatten() for p in model.parameters()])
+        ok_notify[mode] = torch.allclose(got, want, rtol=1e-5, atol=1e-7)
+        red2.close()
+        reducer = red2
+    assert all(ok_notify.values()), ok_notify
     inactive = [b for b in reducer.bucket_names if b.startswith("block") and int(b[5:]) >= cfg["layer_num"]]
     full_bytes = sum(buf.numel() * 4 for buf in reducer.flat.values())
     q.put((rank, ok_avg, in_sync, cfg["layer_num"], len(inactive), sent, full_bytes, float(loss)))
