@@ -290,7 +290,7 @@ def main():
         _blk.NATIVE_BLOCK = _blk.WGRAD_SIDE_STREAM = False     # one stream: nothing overlaps the timed kernels
         timing.reset()
         timing.enable(True, only=("attn_rpe2d_fwd", "attn_rpe2d_bwd", "rpe_index_fwd", "rpe_index_bwd", "gemm_nt",
-                                  "gemm_nt_gelu", "gemm_nt_dgelu", "gemm_tn_wgrad"))
+                                  "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad"))
         trainer.start_epoch(0)
         for _ in range(max(4, min(a.steps, 12))):
             trainer.step(images, target)

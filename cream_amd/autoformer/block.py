@@ -183,7 +183,8 @@ def linear_fwd_seg(x, w3, bias, N, K, nseg, out=None):
 
 
 def linear_gelu_fwd(x, w, bias, N, K):
-    """-> (h, g): h = x . W^T + bias (bf16), g = gelu(float(h)) (bf16) in one pass (fc1 + activation)."""
+    """-> (gp, g) with h = bf16(x . W^T + bias): gp = gelu'(float(h)), g = gelu(float(h)), both bf16, in
+    one pass (fc1 + activation; gp is everything the backward needs of h)."""
     M = x.shape[0]
     h = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     g = torch.empty_like(h)
@@ -215,15 +216,16 @@ def linear_dgrad_seg(dy, wt3, N, K, kseg, out=None):
     return out
 
 
-def linear_dgrad_dgelu(dy, wt, h, N, K):
-    """-> (dh, parts): dh (M, K) = (dy . W) * gelu'(h), parts (slabs, K) its per-slab column sums."""
+def linear_dgrad_mul(dy, wt, factor, N, K):
+    """-> (dh, parts): dh (M, K) = (dy . W) * factor (the saved gelu'(h)), parts (slabs, K) its per-slab
+    column sums."""
     M = dy.shape[0]
     lib = _lib.load()
     dh = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
     parts = torch.empty((lib.cream_colsum128_slabs(M), K), dtype=torch.float32, device=dy.device)
-    with timing.region("gemm_nt_dgelu", flops=2 * M * N * K):
-        _lib.check(lib.cream_linear_dgrad_dgelu(_p(dh), _p(parts), _p(dy), _p(wt), _p(h), M, N, K, wt.stride(0), _stream()),
-                   "cream_linear_dgrad_dgelu")
+    with timing.region("gemm_nt_mul", flops=2 * M * N * K):
+        _lib.check(lib.cream_linear_dgrad_mul(_p(dh), _p(parts), _p(dy), _p(wt), _p(factor), M, N, K, wt.stride(0), _stream()),
+                   "cream_linear_dgrad_mul")
     return dh, parts
 
 
@@ -565,7 +567,7 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     pw2, _ = wgrad_parts_async(df, g)
     jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
     jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
-    dh, pb1 = linear_dgrad_dgelu(df, w2_t, h, E, F_)         # (df . W2) * gelu'(h) + fc1 bias partials
+    dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)           # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
     pw1, _ = wgrad_parts_async(dh, c)
     jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
     jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)

@@ -182,7 +182,7 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     // x1 = x + s1 * p ; c = LN2(x1)
     TRY(cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
                          at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
-    // fc1 + gelu in one pass (h kept for the backward)
+    // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
     TRY(cream_linear_gelu_fwd(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F, E, d->ld_w1, stream));
     TRY(cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
@@ -213,8 +213,8 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     // ---- MLP branch ----------------------------------------------------------------------------
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // df, g complete on main
     TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
-    // dh = (df . W2) * gelu'(h) and the fc1 bias partials in the dgrad's epilogue
-    TRY(cream_linear_dgrad_dgelu(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+    // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
+    TRY(cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
                                  main));
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
     TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));

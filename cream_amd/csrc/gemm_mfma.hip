@@ -90,13 +90,13 @@ int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bi
     return launch_nt<EPI_BIAS>(p, (hipStream_t)stream);
 }
 
-int cream_linear_gelu_fwd(void* h, void* g, const void* x, const void* w, const void* bias, int M, int N, int K,
+int cream_linear_gelu_fwd(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int K,
                           int64_t ldw, void* stream)
 {
-    const int rc = check_nt(h, x, w, M, N, K, ldw, K);
+    const int rc = check_nt(gp, x, w, M, N, K, ldw, K);
     if (rc) return rc < 0 ? rc : CREAM_OK;
     if (!g || !bias || !aligned16(g)) return CREAM_ERR_BAD_ARG;
-    NtParams p = plain(h, x, w, M, N, K, ldw);
+    NtParams p = plain(gp, x, w, M, N, K, ldw);
     p.bias = (const uint16_t*)bias;
     p.out2 = (uint16_t*)g;
     return launch_nt<EPI_BIAS_GELU>(p, (hipStream_t)stream);
@@ -122,25 +122,27 @@ int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int 
     return launch_nt<EPI_STORE>(p, (hipStream_t)stream);
 }
 
-int cream_linear_dgrad_dgelu(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* h, int M, int N,
+int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* factor, int M, int N,
                              int K, int64_t ldwt, void* stream)
 {
     const int rc = check_nt(dh, dy, wt, M, K, N, ldwt, N);
     if (rc) return rc < 0 ? rc : CREAM_OK;
-    if (!colsum_parts || !h || !aligned16(h)) return CREAM_ERR_BAD_ARG;
+    if (!colsum_parts || !factor || !aligned16(factor)) return CREAM_ERR_BAD_ARG;
     NtParams p = plain(dh, dy, wt, M, K, N, ldwt);
-    p.aux = (const uint16_t*)h; p.ldaux = K;
+    p.aux = (const uint16_t*)factor; p.ldaux = K;
     p.colsum = colsum_parts;
-    return launch_nt<EPI_DGELU_COLSUM>(p, (hipStream_t)stream);
+    return launch_nt<EPI_MUL_COLSUM>(p, (hipStream_t)stream);
 }
 
 int cream_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128), steps = (M + 63) / 64;
-    // ~1 workgroup per CU: the weight gradients run beside the main chain on the side stream, and every
-    // extra split is another fp32 partial tile through HBM (written here, read by cream_grad_finalize)
-    int s = (256 + tiles - 1) / tiles;
+    // all workgroups resident at once (2 per CU: 512 slots — one more workgroup than slots costs a whole
+    // extra round), at most 16 splits: every split is another fp32 partial tile through HBM (written
+    // here, read by cream_grad_finalize)
+    constexpr int slots = 512;
+    int s = slots / tiles;
     if (s > 16) s = 16;
     if (s > steps) s = steps;
     return s < 1 ? 1 : s;

@@ -30,8 +30,10 @@
 //     row segments (the q / k / v thirds of the de-interleaved qkv weight) and the contraction in
 //     `kseg` segments (the same thirds on the transposed copy used by dgrad); leading dimension =
 //     super width (the active block W[:N, :K] is read in place).
-// Epilogues (EPI_*): plain store; + bias; + bias, erf-GELU with both h and gelu(h) written (fc1);
-// x gelu'(h) with column sums of the result (fc2 dgrad -> fc1 bias gradient).
+// Epilogues (EPI_*): plain store; + bias; + bias and erf-GELU, writing gelu(h) AND gelu'(h) (fc1: the
+// derivative shares the expensive terms with the forward value, so the backward never evaluates erf);
+// x an element-wise factor (the saved gelu'(h)) with column sums of the result (fc2 dgrad + GELU
+// backward + fc1 bias gradient).
 //
 // M, N arbitrary (N % 8 == 0), K % 8 == 0.
 #pragma once
@@ -45,7 +47,7 @@
 namespace cream {
 namespace gemm {
 
-enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_DGELU_COLSUM = 3 };
+enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3 };
 
 struct NtParams {
     const uint16_t* A;      // (M x K) bf16, row stride lda
@@ -53,13 +55,13 @@ struct NtParams {
     int64_t lda, ldb, nseg_stride, kseg_stride;
     int nseg, kseg;         // nseg >= N and kseg >= K for a plain matrix; kseg % 64 == 0 when kseg < K; N <= 3 nseg
     int M, N, K;
-    uint16_t* out;          // (M x N) bf16, row stride ldo
-    uint16_t* out2;         // EPI_BIAS_GELU: gelu(out), same layout
+    uint16_t* out;          // (M x N) bf16, row stride ldo  (EPI_BIAS_GELU: gelu'(h), h = bf16(x . W^T + bias))
+    uint16_t* out2;         // EPI_BIAS_GELU: gelu(h), same layout
     int64_t ldo;
     const uint16_t* bias;   // (N) bf16 or nullptr                      (EPI_BIAS, EPI_BIAS_GELU)
-    const uint16_t* aux;    // EPI_DGELU_COLSUM: h (M x N) bf16, row stride ldaux
+    const uint16_t* aux;    // EPI_MUL_COLSUM: element-wise factor (M x N) bf16, row stride ldaux
     int64_t ldaux;
-    float* colsum;          // EPI_DGELU_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
+    float* colsum;          // EPI_MUL_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
 };
 
 // erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
@@ -244,6 +246,25 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     }
 
     // ---- epilogue: accumulators -> LDS (fp32, [BM][BN + 4]) -> (row, 8 columns) chunks -------------
+    constexpr int CPR = BN / 8;                                 // chunks per tile row
+    constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+    const bool ncol_ok = n < p.N;                               // N % 8 == 0: a chunk is all in or all out
+    // side inputs of this thread's chunks are requested NOW: their latency hides behind the LDS round trip
+    // of the accumulators instead of being paid once per row inside the store loop
+    u32x4v auxv[EPI == EPI_MUL_COLSUM ? BM / RPP : 1];
+    if constexpr (EPI == EPI_MUL_COLSUM) {
+#pragma unroll
+        for (int j = 0; j < BM / RPP; ++j) {
+            const int m = m0 + r0 + j * RPP;
+            auxv[j] = (m < p.M && ncol_ok) ? *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n) : u32x4v{0, 0, 0, 0};
+        }
+    }
+    u32x4v braw = u32x4v{0, 0, 0, 0};
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        if (p.bias && ncol_ok) braw = *reinterpret_cast<const u32x4v*>(p.bias + n);
+    }
     __syncthreads();                                            // every wave is done with the stages
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -258,24 +279,14 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             }
         }
     __syncthreads();
-    constexpr int CPR = BN / 8;                                 // chunks per tile row
-    constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
-    const int cc = tid % CPR, r0 = tid / CPR;
-    const int n = n0 + cc * 8;
-    const bool ncol_ok = n < p.N;                               // N % 8 == 0: a chunk is all in or all out
-    float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        if (p.bias && ncol_ok) {
-            const u32x4v b = *reinterpret_cast<const u32x4v*>(p.bias + n);
+    float bv[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bv[2 * e] = __uint_as_float(b[e] << 16);
-                bv[2 * e + 1] = __uint_as_float(b[e] & 0xFFFF0000u);
-            }
-        }
+    for (int e = 0; e < 4; ++e) {
+        bv[2 * e] = __uint_as_float(braw[e] << 16);
+        bv[2 * e + 1] = __uint_as_float(braw[e] & 0xFFFF0000u);
     }
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 2
+#pragma unroll
     for (int j = 0; j < BM / RPP; ++j) {
         const int row = r0 + j * RPP, m = m0 + row;
         if (m >= p.M || !ncol_ok) continue;
@@ -290,29 +301,34 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                 u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])};
         } else if constexpr (EPI == EPI_BIAS_GELU) {
             // fc1 under autocast yields bf16 h; gelu runs in fp32 ON that bf16 value and casts back
-            // (supernet_transformer.py:14-16, :276-277)
-            u32x4v hb, gb;
+            // (supernet_transformer.py:14-16, :276-277).  gelu'(h) = Phi(h) + h phi(h) reuses Phi and the
+            // exponential: it is written INSTEAD of h (the backward needs nothing else of h).
+            u32x4v pb, gb;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hb[e] = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
-                gb[e] = f2bf_pair(gelu_f(__uint_as_float(hb[e] << 16)), gelu_f(__uint_as_float(hb[e] & 0xFFFF0000u)));
+                const uint32_t hb = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
+                const float h0 = __uint_as_float(hb << 16), h1 = __uint_as_float(hb & 0xFFFF0000u);
+                float c0, e0, c1, e1;
+                phi_parts(h0, c0, e0);
+                phi_parts(h1, c1, e1);
+                gb[e] = f2bf_pair(h0 * c0, h1 * c1);
+                pb[e] = f2bf_pair(fmaf(h0 * 0.3989422804014327f, e0, c0), fmaf(h1 * 0.3989422804014327f, e1, c1));
             }
-            *reinterpret_cast<u32x4v*>(o) = hb;
+            *reinterpret_cast<u32x4v*>(o) = pb;
             *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
-        } else {   // EPI_DGELU_COLSUM
-            const u32x4v hb = *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n);
+        } else {   // EPI_MUL_COLSUM
+            const u32x4v fb = auxv[j];
             u32x4v db;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                db[e] = f2bf_pair(v[2 * e] * gelu_grad_f(__uint_as_float(hb[e] << 16)),
-                                  v[2 * e + 1] * gelu_grad_f(__uint_as_float(hb[e] & 0xFFFF0000u)));
+                db[e] = f2bf_pair(v[2 * e] * __uint_as_float(fb[e] << 16), v[2 * e + 1] * __uint_as_float(fb[e] & 0xFFFF0000u));
                 cs[2 * e] += __uint_as_float(db[e] << 16);              // sums of the ROUNDED values written
                 cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
             }
             *reinterpret_cast<u32x4v*>(o) = db;
         }
     }
-    if constexpr (EPI == EPI_DGELU_COLSUM) {
+    if constexpr (EPI == EPI_MUL_COLSUM) {
         __syncthreads();                                        // the fp32 tile has been consumed
         float* red = ctile;                                     // [RPP][BN]
 #pragma unroll
@@ -369,7 +385,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int ntk = (p.K + BT - 1) / BT, ntn = (p.N + BT - 1) / BT;
-    const int tile = blockIdx.x % (ntk * ntn), split = blockIdx.x / (ntk * ntn);
+    // XCD-aware order: all tiles of one split run on ONE XCD (they re-read the same 64-token rows of dY
+    // and X every step: one HBM fetch, the rest from that XCD's L2 — without the remap neighbouring
+    // tiles sit on different XCDs and every operand row is fetched ntn / ntk times)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % (ntk * ntn), split = bid / (ntk * ntn);
     const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
     const int tsteps = (p.M + BM - 1) / BM;
     const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
@@ -419,41 +439,72 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     }
     const bf16x8 ones = bf16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
-    if (s_lo < s_hi) issue(s_lo, 0);
-    for (int st = s_lo; st < s_hi; ++st) {
-        const int buf = (st - s_lo) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 1 < s_hi) issue(st + 1, buf ^ 1);
-        uint16_t* Yt = lds + buf * STAGE;
-        uint16_t* Xt = Yt + BM * BT;
-        if ((st + 1) * BM > p.M) {                              // token tail: zero the rows beyond M
-            const int valid = p.M - st * BM;
+    // one 64-token step from stage `buf`: fragments double buffered in registers (the transpose reads of
+    // sub-step ms+1 are issued before the MFMAs of sub-step ms)
+    auto step = [&](int buf, auto with_bias) {
+        constexpr bool BIAS = decltype(with_bias)::value;
+        const uint16_t* Yt = lds + buf * STAGE;
+        const uint16_t* Xt = Yt + BM * BT;
+        bf16x8 fy[2][2], fx[2][2];
+        auto load = [&](int ms, int slot) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fy[slot][i] = frag(Yt, wn * 64 + i * 32, ms * 16);
+                fx[slot][i] = frag(Xt, wk * 64 + i * 32, ms * 16);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int ms = 0; ms < BM / 16; ++ms) {
+            if (ms + 1 < BM / 16) load(ms + 1, (ms + 1) & 1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ms & 1][a], fx[ms & 1][b], acc[a][b], 0, 0, 0);
+            if constexpr (BIAS) {
+                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ms & 1][0], ones, bacc[0], 0, 0, 0);
+                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ms & 1][1], ones, bacc[1], 0, 0, 0);
+            }
+        }
+        constexpr int NM = BIAS ? 6 : 4;
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                     // transpose reads of sub-steps 0 and 1
+#pragma unroll
+        for (int ms = 0; ms < BM / 16; ++ms) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            if (ms + 2 < BM / 16) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        }
+    };
+    using No = std::integral_constant<bool, false>;
+    using Yes = std::integral_constant<bool, true>;
+    // the loop exists twice (with / without the bias MFMAs) so that no branch sits between the MFMAs;
+    // the token tail (rows beyond M: only the very last step of the last split) is handled after it
+    const bool tail = s_hi > s_lo && s_hi * BM > p.M;
+    const int s_full = tail ? s_hi - 1 : s_hi;
+    auto run = [&](auto with_bias) {
+        if (s_lo < s_hi) issue(s_lo, 0);
+        for (int st = s_lo; st < s_full; ++st) {
+            const int buf = (st - s_lo) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (st + 1 < s_hi) issue(st + 1, buf ^ 1);
+            step(buf, with_bias);
+        }
+        if (tail) {
+            const int buf = (s_full - s_lo) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            uint16_t* Yt = lds + buf * STAGE;                   // zero the token rows beyond M in both tiles
+            const int valid = p.M - s_full * BM;
             for (int i = tid; i < 2 * BM * BT / 8; i += 256) {
                 const int r = (i / 16) & (BM - 1);
                 if (r >= valid) *reinterpret_cast<u32x4v*>(Yt + i * 8) = u32x4v{0, 0, 0, 0};
             }
             __syncthreads();
+            step(buf, with_bias);
         }
-#pragma unroll
-        for (int ms = 0; ms < BM / 16; ++ms) {
-            bf16x8 fy[2], fx[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fy[i] = frag(Yt, wn * 64 + i * 32, ms * 16);
-                fx[i] = frag(Xt, wk * 64 + i * 32, ms * 16);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
-            if (want_bias && wk == 0) {
-                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[0], ones, bacc[0], 0, 0, 0);
-                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[1], ones, bacc[1], 0, 0, 0);
-            }
-        }
-    }
+    };
+    if (want_bias && wk == 0) run(Yes{}); else run(No{});
     // ---- partial tile: D[n][k], lane = column k (l & 31), registers = rows n -------------------------
     const int g = lane >> 5, c32 = lane & 31;
     float* out = p.parts + (int64_t)split * p.N * p.K;

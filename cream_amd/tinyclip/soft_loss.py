@@ -1,0 +1,92 @@
+"""Affinity-mimicking distillation loss of TinyCLIP — host-side mirror of
+TinyCLIP/src/open_clip/clip_soft_loss.py:10-88 (`ClipSoftLoss`) and of the feature gathering it
+calls (TinyCLIP/src/open_clip/loss.py:71-106, `gather_feature`).
+
+Per step and rank (local_loss=True, the only mode the reference's class accepts, :29):
+    logits_i2t = s * I_local @ T_all^T        logits_t2i = s * T_local @ I_all^T        (student)
+    the same with the frozen teacher's features and logit scale
+    loss = ( CE(logits_i2t, softmax(teacher_i2t)) + CE(logits_t2i, softmax(teacher_t2i)) ) / 2
+where *_all are the features of ALL ranks (global batch) — the one exchange step of this path.
+
+MI355X / RCCL shape of the exchange (not a translation of the reference's four list-based
+all_gathers, loss.py:94-104): image and text features of a tower pair travel TOGETHER — one
+`all_gather_into_tensor` of a (B_local, 2 D) buffer for the student (differentiable: its backward is
+one reduce-scatter of the gathered gradient, i.e. what `torch.distributed.nn.all_gather` does in
+world many sends) and one for the teacher (no gradient) — 2 collectives per step instead of 4, each
+a single contiguous message over the xGMI mesh.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _AllGatherCat(torch.autograd.Function):
+    """(B, D) on every rank -> (world * B, D), rank-major.  Backward: the gradient of the gathered
+    tensor is summed over ranks and each rank keeps its own rows (reduce-scatter)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        out = x.new_empty((world * x.shape[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        group = ctx.group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        g = g.contiguous()
+        b = g.shape[0] // world
+        if dist.get_backend(group) == "nccl":
+            mine = g.new_empty((b,) + tuple(g.shape[1:]))
+            dist.reduce_scatter_tensor(mine, g, op=dist.ReduceOp.SUM, group=group)
+            return mine, None
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)        # backends without reduce_scatter (gloo)
+        return g[rank * b:(rank + 1) * b].clone(), None
+
+
+def gather_features_with_grad(image_features, text_features, with_grad=True, group=None):
+    """-> (all_image, all_text): both towers' features of every rank with ONE collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return image_features, text_features
+    d = image_features.shape[1]
+    both = torch.cat([image_features, text_features], dim=1)
+    if with_grad:
+        allf = _AllGatherCat.apply(both, group)
+    else:
+        with torch.no_grad():
+            allf = _AllGatherCat.apply(both.detach(), group)
+    return allf[:, :d], allf[:, d:]
+
+
+class ClipSoftLoss(nn.Module):
+    """Same constructor flags and forward signature as the reference's ClipSoftLoss
+    (clip_soft_loss.py:11-32, :54-88); `use_horovod` is accepted and must be False (RCCL only)."""
+
+    def __init__(self, local_loss=True, gather_with_grad=False, cache_labels=False, rank=None, world_size=None,
+                 use_horovod=False, group=None):
+        super().__init__()
+        assert local_loss, "the reference's ClipSoftLoss only supports local_loss (clip_soft_loss.py:29)"
+        assert not use_horovod, "RCCL through torch.distributed only"
+        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
+        self.group = group
+
+    def compute_sim(self, image_features, text_features, with_grad):
+        all_image, all_text = gather_features_with_grad(image_features, text_features, with_grad, self.group)
+        return image_features @ all_text.T, text_features @ all_image.T
+
+    def forward(self, image_features, text_features, logit_scale, teacher_image_features, teacher_text_features,
+                teacher_logit_scale, average_two_losses=True, labels=None):
+        li, lt = self.compute_sim(image_features, text_features, self.gather_with_grad)
+        ti, tt = self.compute_sim(teacher_image_features, teacher_text_features, False)
+        li, lt = logit_scale * li, logit_scale * lt
+        ti, tt = teacher_logit_scale * ti, teacher_logit_scale * tt
+
+        def single(logits, teacher_logits):
+            return F.cross_entropy(logits, F.softmax(teacher_logits, -1))
+
+        if average_two_losses:
+            return (single(li, ti) + single(lt, tt)) / 2
+        return single(li, ti), single(lt, tt)

@@ -211,16 +211,17 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
  *                             `nseg_stride` elements apart: the de-interleaved [q | k | v] copy of
  *                             the qkv super weight (row n of the product = row n % nseg of segment
  *                             n / nseg) — replaces the torch.cat row gather of qkv_super.py:75
- *   cream_linear_gelu_fwd     h = x . W^T + bias (bf16) and g = gelu(float(h)) in one pass (fc1 + the
- *                             fp32 gelu of supernet_transformer.py:14-16; gelu on the bf16-rounded h,
- *                             exactly as under the reference's autocast)
+ *   cream_linear_gelu_fwd     with h = bf16(x . W^T + bias): g = gelu(float(h)) and gp = gelu'(float(h)), both
+ *                             bf16, in one pass (fc1 + the fp32 gelu of supernet_transformer.py:14-16, on the
+ *                             bf16-rounded h exactly as under the reference's autocast; the derivative shares
+ *                             Phi and the exponential with the value and is what the backward needs of h)
  *   cream_linear_dgrad        dx(M x K) = dy(M x N) . W(N x K); `wt` is the TRANSPOSED copy W^T
  *                             (K rows, N contiguous, row stride ldwt)
  *   cream_linear_dgrad_seg    the same with the contraction index in segments of `kseg` (the
  *                             transposed [q | k | v] copies, `kseg_stride` elements apart; kseg % 64 == 0)
- *   cream_linear_dgrad_dgelu  dh(M x K) = (dy . W) * gelu'(h) and the column sums of dh per 128-row
- *                             slab: colsum_parts[slab][K] (fc2 dgrad + GELU backward + fc1 bias
- *                             gradient partials, cream_gemm_rows_per_colsum_slab() rows per slab)
+ *   cream_linear_dgrad_mul    dh(M x K) = (dy . W) * factor (bf16, M x K: the saved gelu'(h)) and the column
+ *                             sums of dh per 128-row slab: colsum_parts[slab][K] (fc2 dgrad + GELU backward +
+ *                             fc1 bias gradient partials, cream_gemm_rows_per_colsum_slab() rows per slab)
  *   cream_linear_wgrad_parts  parts[s](N x K) fp32 = dy_s^T x_s over S slices of the M rows (slices of
  *                             whole 64-row steps, as even as possible; added by cream_grad_finalize);
  *                             bias_parts[s](N) = column sums of dy_s — the bias gradient rides on the
@@ -231,13 +232,13 @@ int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, 
                      int64_t ldw, void* stream);
 int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                          int64_t ldw, int nseg, int64_t nseg_stride, void* stream);
-int cream_linear_gelu_fwd(void* h, void* g, const void* x, const void* w, const void* bias, int M, int N,
+int cream_linear_gelu_fwd(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N,
                           int K, int64_t ldw, void* stream);
 int cream_linear_dgrad(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
                        void* stream);
 int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
                            int kseg, int64_t kseg_stride, void* stream);
-int cream_linear_dgrad_dgelu(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* h,
+int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* factor,
                              int M, int N, int K, int64_t ldwt, void* stream);
 int cream_linear_wgrad_splits(int M, int N, int K);
 int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N,

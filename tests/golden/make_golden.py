@@ -351,6 +351,37 @@ def evolution():
     print(f"wrote evolution_trace.json: {len(visited)} evaluated candidates, {len(es.vis_dict)} seen")
 
 
+def tinyclip_loss():
+    """TinyCLIP/src/open_clip/clip_soft_loss.py's ClipSoftLoss (class source executed from the read-only
+    file together with loss.py's gather_feature; their open_clip / horovod imports left out) at world size 1
+    on seeded features: loss and feature gradients."""
+    import ast
+    tc = os.path.join(refshim.REFERENCE, 'TinyCLIP', 'src', 'open_clip')
+    ns = {'torch': torch, 'nn': torch.nn, 'F': torch.nn.functional, 'dist': torch.distributed, 'hvd': None,
+          'nullcontext': __import__('contextlib').nullcontext, 'np': np}
+    for fname, names in (('loss.py', ('gather_feature',)), ('clip_soft_loss.py', ('ClipSoftLoss',))):
+        tree = ast.parse(open(os.path.join(tc, fname)).read())
+        keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+        exec(compile(ast.Module(body=keep, type_ignores=[]), fname, 'exec'), ns)
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.nn.functional.normalize(torch.randn(24, 64, generator=g), dim=-1).requires_grad_(i < 2) for i in range(4)]
+    loss_fn = ns['ClipSoftLoss'](local_loss=True, gather_with_grad=False, rank=0, world_size=1)
+    # world size 1: gather_feature's all_gather of one tensor is the identity; run it without a process group
+    ns['dist'] = type('D', (), {'all_gather': staticmethod(lambda outs, x: outs[0].copy_(x))})
+    ns['gather_feature'].__globals__['dist'] = ns['dist']
+    out = {}
+    for avg in (True, False):
+        for f in feats[:2]:
+            f.grad = None
+        res = loss_fn(feats[0], feats[1], torch.tensor(50.0), feats[2], feats[3], torch.tensor(100.0), average_two_losses=avg)
+        tot = res if avg else res[0] + 2 * res[1]
+        tot.backward()
+        out[f'avg{int(avg)}|loss'] = torch.stack(list(res)) if not avg else res.reshape(1)
+        out[f'avg{int(avg)}|dimage'] = feats[0].grad.clone()
+        out[f'avg{int(avg)}|dtext'] = feats[1].grad.clone()
+    save('tinyclip_soft_loss.npz', **out)
+
+
 if __name__ == '__main__':
     assert refshim.have_reference(), "needs the reference checkout at /root/reference"
     which = sys.argv[1:] or ['autoformer', 'irpe']
@@ -364,3 +395,5 @@ if __name__ == '__main__':
         autoformer_trace()
     if 'evolution' in which:
         evolution()
+    if 'tinyclip_loss' in which:
+        tinyclip_loss()

@@ -165,27 +165,30 @@ def test_qkv_segment_addressing_matches_row_gather(M, E, H):
 
 @pytest.mark.parametrize("M,E,F_", [(197 * 8, 384, 1344), (25216, 448, 1792), (1000, 320, 1120), (197 * 4, 320, 960)])
 def test_fused_gelu_epilogues_match_unfused_passes(M, E, F_):
-    """fc1 with the erf-GELU in its epilogue == linear + cream_gelu_fwd on the bf16-rounded h (bits of
-    h identical; gelu(h) within one bf16 ulp: the epilogue evaluates erf by A&S 7.1.26, |err| <= 5e-7);
-    fc2's dgrad with GELU' == dgrad (fp32 accumulator, not bf16-rounded first) * gelu'(h), and the
-    column-sum partials add up to the column sums of what was written."""
+    """fc1 with the erf-GELU in its epilogue: g == gelu(float(h)) and gp == gelu'(float(h)) for the
+    bf16-rounded h = fc1(c) (what the reference computes under autocast) within one bf16 ulp (the epilogue
+    evaluates erf by A&S 7.1.26, |err| <= 5e-7); fc2's dgrad with the saved derivative in its epilogue ==
+    (fp32 accumulator, not bf16-rounded first) * gelu'(h), and the column-sum partials add up to the
+    column sums of what was written."""
     from cream_amd.autoformer import block as K_
     g = torch.Generator(device=DEV).manual_seed(5)
     c = torch.randn(M, E, device=DEV, generator=g).bfloat16()
     w1 = (torch.randn(F_, E, device=DEV, generator=g) * 0.08).bfloat16()
     b1 = torch.randn(F_, device=DEV, generator=g).bfloat16()
-    h, gg = K_.linear_gelu_fwd(c, w1, b1, F_, E)
-    assert torch.equal(h, K_.linear_fwd(c, w1, b1, F_, E))
-    ref_g = F.gelu(h.float())
+    gp, gg = K_.linear_gelu_fwd(c, w1, b1, F_, E)
+    h = K_.linear_fwd(c, w1, b1, F_, E)                      # the bf16 h the epilogue worked on
+    hr = h.float().requires_grad_()
+    ref_g = F.gelu(hr)
+    ref_g.sum().backward()
+    ref_gp = hr.grad
     assert _rel(gg.float(), ref_g) < 4e-3 and float((gg.float() - ref_g).abs().max()) <= 2 ** -7 * float(ref_g.abs().max())
     assert _rel(gg.float(), K_.gelu_fwd(h).float()) < 4e-3
+    assert _rel(gp.float(), ref_gp) < 4e-3
     df = torch.randn(M, E, device=DEV, generator=g).bfloat16()
     w2 = (torch.randn(E, F_, device=DEV, generator=g) * 0.05).bfloat16()
     w2t = w2.t().contiguous()
-    dh, parts = K_.linear_dgrad_dgelu(df, w2t, h, E, F_)
-    hr = h.float().requires_grad_()
-    F.gelu(hr).backward(df.float() @ w2.float())
-    assert _rel(dh.float(), hr.grad) < 1e-2
+    dh, parts = K_.linear_dgrad_mul(df, w2t, gp, E, F_)
+    assert _rel(dh.float(), (df.float() @ w2.float()) * ref_gp) < 1e-2
     assert parts.shape == (K_._lib.load().cream_colsum128_slabs(M), F_)
     assert _rel(parts.sum(0), dh.float().sum(0)) < 1e-5
 

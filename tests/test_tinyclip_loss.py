@@ -1,0 +1,111 @@
+"""TinyCLIP affinity-mimicking loss: (a) world size 1 against values produced by the
+reference's own ClipSoftLoss (tests/golden/make_golden.py tinyclip_loss), (b) world size 2 over gloo:
+each rank's loss and feature gradients equal the single-process computation on the concatenated batch
+(what the reference's gather_feature + local_loss computes), through ONE gather per tower pair."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _features(n=24, d=64, seed=77):
+    g = torch.Generator().manual_seed(seed)
+    return [F.normalize(torch.randn(n, d, generator=g), dim=-1) for _ in range(4)]
+
+
+def test_soft_loss_matches_reference_values():
+    from cream_amd.tinyclip import ClipSoftLoss
+    z = np.load(os.path.join(GOLDEN, "tinyclip_soft_loss.npz"))
+    feats = _features()
+    for avg in (True, False):
+        img, txt = feats[0].clone().requires_grad_(), feats[1].clone().requires_grad_()
+        res = ClipSoftLoss()(img, txt, torch.tensor(50.0), feats[2], feats[3], torch.tensor(100.0), average_two_losses=avg)
+        tot = res if avg else res[0] + 2 * res[1]
+        tot.backward()
+        got = res.reshape(1) if avg else torch.stack(list(res))
+        np.testing.assert_allclose(got.detach().numpy(), z[f"avg{int(avg)}|loss"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(img.grad.numpy(), z[f"avg{int(avg)}|dimage"], rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(txt.grad.numpy(), z[f"avg{int(avg)}|dtext"], rtol=1e-4, atol=5e-6)
+
+
+def _single_process(feats, world, rank, s, ts):
+    """What rank `rank` must get: local rows against ALL rows (loss.py:71-106 + clip_soft_loss.py:34-52)."""
+    img, txt = feats[0].clone().requires_grad_(), feats[1].clone().requires_grad_()
+    b = img.shape[0] // world
+    sl = slice(rank * b, (rank + 1) * b)
+    li, lt = s * img[sl] @ txt.T, s * txt[sl] @ img.T
+    ti, tt = ts * feats[2][sl] @ feats[3].T, ts * feats[3][sl] @ feats[2].T
+    loss = (F.cross_entropy(li, F.softmax(ti, -1)) + F.cross_entropy(lt, F.softmax(tt, -1))) / 2
+    return loss, img, txt
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    from cream_amd.tinyclip import ClipSoftLoss
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats = _features()
+    b = feats[0].shape[0] // world
+    sl = slice(rank * b, (rank + 1) * b)
+    img, txt = feats[0][sl].clone().requires_grad_(), feats[1][sl].clone().requires_grad_()
+    s, ts = torch.tensor(50.0), torch.tensor(100.0)
+    loss = ClipSoftLoss(gather_with_grad=True)(img, txt, s, feats[2][sl], feats[3][sl], ts)
+    loss.backward()
+    # the gradient of the SUM of all ranks' losses w.r.t. this rank's rows (gather_with_grad: other ranks' losses
+    # see our features too)
+    tot, gi, gt = 0, None, None
+    full_i, full_t = feats[0].clone().requires_grad_(), feats[1].clone().requires_grad_()
+    losses = []
+    for r in range(world):
+        rs = slice(r * b, (r + 1) * b)
+        li, lt = s * full_i[rs] @ full_t.T, s * full_t[rs] @ full_i.T
+        ti, tt = ts * feats[2][rs] @ feats[3].T, ts * feats[3][rs] @ feats[2].T
+        losses.append((F.cross_entropy(li, F.softmax(ti, -1)) + F.cross_entropy(lt, F.softmax(tt, -1))) / 2)
+    sum(losses).backward()
+    ok = (torch.allclose(loss.detach(), losses[rank].detach(), rtol=1e-6, atol=1e-7)
+          and torch.allclose(img.grad, full_i.grad[sl], rtol=1e-4, atol=5e-6)
+          and torch.allclose(txt.grad, full_t.grad[sl], rtol=1e-4, atol=5e-6))
+    # without gather_with_grad only the local rows carry gradient (loss.py:96-103 puts the local tensor back
+    # into the gathered list; here the local rows are used directly)
+    img2, txt2 = feats[0][sl].clone().requires_grad_(), feats[1][sl].clone().requires_grad_()
+    loss2 = ClipSoftLoss(gather_with_grad=False)(img2, txt2, s, feats[2][sl], feats[3][sl], ts)
+    loss2.backward()
+    ref, ri, rt = _single_process(feats, world, rank, s, ts)
+    # local-only gradient: differentiate w.r.t. the local rows with the gathered copies detached
+    li = s * ri[sl] @ feats[1].T
+    lt = s * rt[sl] @ feats[0].T
+    ti, tt = ts * feats[2][sl] @ feats[3].T, ts * feats[3][sl] @ feats[2].T
+    l3 = (F.cross_entropy(li, F.softmax(ti, -1)) + F.cross_entropy(lt, F.softmax(tt, -1))) / 2
+    l3.backward()
+    ok2 = (torch.allclose(loss2.detach(), ref.detach(), rtol=1e-6, atol=1e-7)
+           and torch.allclose(img2.grad, ri.grad[sl], rtol=1e-4, atol=5e-6)
+           and torch.allclose(txt2.grad, rt.grad[sl], rtol=1e-4, atol=5e-6))
+    q.put((rank, bool(ok), bool(ok2), float((loss - losses[rank]).abs()), float((img.grad - full_i.grad[sl]).abs().max()), float((txt.grad - full_t.grad[sl]).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_soft_loss_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ok2, *dbg in res:
+        print(rank, dbg)
+        assert ok, f"rank {rank}: gather_with_grad loss / gradients differ from the global-batch computation"
+        assert ok2, f"rank {rank}: local-gradient mode differs"

@@ -46,11 +46,14 @@ __global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, 
     if (epi == EPI_STORE) want = v;
     else if (epi == EPI_BIAS) want = v + (p.bias ? bfv(p.bias[n]) : 0.f);
     else if (epi == EPI_BIAS_GELU) {
-        want = v + bfv(p.bias[n]);
-        const float g = gelu_f(got), got2 = bfv(p.out2[(int64_t)m * p.ldo + n]);
+        // out = gelu'(h), out2 = gelu(h) for h = bf16(v + bias)
+        const float hb = bfv((uint16_t)(__float_as_uint(v + bfv(p.bias[n])) >> 16));          // (truncation: 1 ulp slack below)
+        want = gelu_grad_f(v + bfv(p.bias[n]));
+        const float g = gelu_f(v + bfv(p.bias[n])), got2 = bfv(p.out2[(int64_t)m * p.ldo + n]);
+        (void)hb;
         err = fabsf(g - got2) / (1.f + fabsf(g));
         atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
-    } else want = v * gelu_grad_f(bfv(p.aux[(int64_t)m * p.ldaux + n]));
+    } else want = v * bfv(p.aux[(int64_t)m * p.ldaux + n]);
     err = fabsf(want - got) / (1.f + fabsf(want));
     atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(err == err ? err : 1e30f));
 }
@@ -69,7 +72,7 @@ struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtPar
 #define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
 static const Variant VARIANTS[] = {
     V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3), V(256, 128, 4, 2, 2, EPI_BIAS, 1),
-    V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_DGELU_COLSUM, 2),
+    V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_MUL_COLSUM, 2),
 };
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
     const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm;
@@ -302,7 +305,7 @@ int main(int argc, char** argv)
             CK(hipMemset(dmax, 0, 16));
             launch(v, p);
             check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
-            if (v.epi == EPI_DGELU_COLSUM) check_colsum<<<(((s.M + v.bm - 1) / v.bm) * s.N + 255) / 256, 256>>>(dmax, p, v.bm);
+            if (v.epi == EPI_MUL_COLSUM) check_colsum<<<(((s.M + v.bm - 1) / v.bm) * s.N + 255) / 256, 256>>>(dmax, p, v.bm);
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
             for (int i = 0; i < 3; ++i) launch(v, p);
