@@ -38,6 +38,11 @@ SIGNATURES = {
     "cream_rpe_index_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cream_rpe_index_fwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "cream_rpe_index_bwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "cream_irpe_padded_len": (_i, [_i]),
+    "cream_irpe_bucket_bytes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "cream_irpe_attn_fwd": (_i, [_vp, _vp]),
+    "cream_irpe_attn_bwd": (_i, [_vp, _vp]),
+    "cream_irpe_table_grad": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i, _i, _i, _f, _vp]),
     "cream_attn_rpe2d_padded_len": (_i, [_i]),
     "cream_attn_rpe2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i,
                                   _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -95,6 +100,17 @@ class BlockDesc(ctypes.Structure):
                                      "ld_w1_t", "ld_w2", "ld_w2_t")] +
                 [(n, _vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
                 [("ldt", _i64)])
+
+
+class IrpeAttnDesc(ctypes.Structure):
+    """struct cream_irpe_attn_desc of include/cream_amd.h."""
+    _fields_ = ([(n, _vp) for n in ("q", "k", "v")] + [(n, _i64) for n in ("sb", "sn", "sh")] +
+                [(n, _vp) for n in ("out", "lse", "sv", "wq", "wk", "wv")] +
+                [(n, _i64) for n in ("wq_hs", "wk_hs", "wv_hs")] +
+                [(n, _vp) for n in ("idq", "idk", "idv", "idq_t", "idk_t", "idv_t")] +
+                [(n, _c.c_int32) for n in ("B", "H", "L", "NP", "nb")] + [("scale", _f)] +
+                [(n, _vp) for n in ("dout", "dq", "dk", "dv")] + [(n, _i64) for n in ("dsb", "dsn", "dsh")] +
+                [(n, _vp) for n in ("delta", "lkg", "gg", "dlk", "dlq")])
 
 
 class ParamJob(ctypes.Structure):

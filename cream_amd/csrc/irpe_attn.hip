@@ -1,0 +1,967 @@
+// irpe_attn.hip — fused attention with image relative position encoding (iRPE, contextual mode) on
+// queries, keys and values, forward and backward, for gfx950 (MI355X).
+//
+// Reference semantics (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:68-97 `RPEAttention.forward`
+// with irpe.py:585-687), per (batch b, head h), head_dim 64, L tokens, nb <= 64 buckets, s = scale:
+//     LK = (s q) Wk                 (L x nb)   rpe_k lookups   (irpe.py:639-642)
+//     LQ = (s k) Wq                 (L x nb)   rpe_q lookups
+//     A[i,j] = (s q_i).k_j + LK[i, idk[i,j]] + LQ[j, idq[j,i]]            (:74-83)
+//     P = softmax_j(A)
+//     SV[i,u] = sum_{j: idv[i,j]=u} P[i,j]                                 (irpe.py:649-687)
+//     O_i = sum_j P[i,j] v_j + SV[i,:] Wv                                  (:88-92)
+// The reference materialises four to eight (B,H,L,L) tensors per layer (1 GB each in fp32 at
+// B=64, H=12, L=577) around the rpe_index gather; here nothing of size L^2 touches HBM — the only
+// side buffers are (B,H,L,64) bf16 rows (lookups, bucket sums and their gradients).
+//
+// Shape of the kernels.  One workgroup = 4 waves = 128 tokens of one (b,h); a wave owns 32 of them and
+// computes 32 x 32 score tiles against the streamed other side with the swapped product of
+// attn_common.hpp, so a lane holds 16 partners of ONE own token: the bias gather is 16 LDS reads from
+// lookup rows lk[token][bucket] (bf16 like the reference's autocast matmul result; pitch 33 words: the
+// bucket of a pair is data, so the reads are a random bank pattern whatever the pitch — an odd one
+// keeps rows from aliasing), the bucket ids come as bytes, four consecutive partners per 32-bit LDS
+// read, from a (128 x 32) id tile that the workgroup stages with coalesced 16-byte loads next to the
+// operand tiles.  The bucket tables are converted once per (table, device) to padded uint8 matrices
+// in BOTH orientations (query-major for the kernels whose lanes own queries, key-major for the dK/dV
+// kernel), 370 KB at L=577: L2 resident.  Scatter-adds (value-side bucket sums, bucket gradients) are
+// LDS float atomics into rows owned by the wave.
+//
+// Forward softmax is two-pass (max first, then exp / sums / P.V): the bucket sums cannot be rescaled
+// cheaply when a running maximum moves, and the second pass is exactly what backward needs anyway
+// (P from the saved log-sum-exp).  K is streamed twice through LDS (L2 hits), V once.
+//
+// Backward, with G = dO Wv^T (the value-side lookups of dO) and delta_i = dO_i . O_i:
+//     dP[i,j] = dO_i . v_j + G[i, idv[i,j]]        dS = P o (dP - delta)
+//     dLK[i,u] = sum_{j: idk[i,j]=u} dS[i,j]       dLQ[j,u] = sum_{i: idq[j,i]=u} dS[i,j]
+//     dq = s (dS k + dLK Wk^T)     dk = dS^T (s q) + s dLQ Wq^T     dv = P^T dO
+//     dWk = (s q)^T dLK            dWq = (s k)^T dLQ                dWv = SV^T dO     (summed over b, (h), tokens)
+// Launch A (lanes own queries): delta, dq, dLK rows; hands LK and G rows to launch B.  Launch B (lanes
+// own keys): dk, dv, dLQ rows.  The three table gradients are per-(b,h) 64 x 64 products over tokens
+// (`irpe_table_grad_kernel`), reduced over b (and h for shared tables) by the caller.  No global atomics.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bfloat16.h>
+#include <stdint.h>
+
+#include "attn_common.hpp"
+#include "cream_amd.h"
+
+namespace {
+using namespace cream;
+using TT = Tr<hip_bfloat16>;
+using F = TT::frag;
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KP = 72;      // pitch (bf16) of row-major [32][64] tiles and of the [64][64] tables
+constexpr int VTP = 36;     // pitch (bf16) of transposed [64][32] tiles read with load_perm
+constexpr int LKP = 65;     // pitch (fp32) of scatter-add rows (LDS float atomics)
+constexpr int LBP = 66;     // pitch (bf16) of lookup rows: 33 words
+constexpr int IDP = 36;     // pitch (bytes) of an id tile row: 32 partners + 4
+constexpr int QW = 4;       // waves (32-token tiles) per workgroup
+
+struct Args {
+    const short *q, *k, *v;
+    int64_t sb, sn, sh;
+    short* out;                       // (B, L, H, 64)
+    float* lse;                       // (B, H, L)
+    short* sv;                        // (B, H, NP, 64) bucket sums of P (value side), bf16
+    const float *wq, *wk, *wv;        // (H', 64, nb), (H', 64, nb), (H', nb, 64) fp32
+    int64_t wq_hs, wk_hs, wv_hs;      // head strides (0: shared)
+    const uint8_t *idq, *idk, *idv;         // (NP, NP) query-major:  [i][j] = bucket_q[j][i], bucket_k[i][j], bucket_v[i][j]
+    const uint8_t *idq_t, *idk_t, *idv_t;   // (NP, NP) key-major:    [j][i] of the same
+    int B, H, L, NP, nb;
+    float scale;
+    // backward
+    const short* dout;                // (B, L, H, 64)
+    short *dq, *dk, *dv;
+    int64_t dsb, dsn, dsh;
+    float* delta;                     // (B, H, NP)
+    short *lkg, *gg;                  // (B, H, NP, 64) rpe_k lookups / value-side lookups of dO   (A -> B)
+    short *dlk, *dlq;                 // (B, H, NP, 64) bucket gradients (-> table gradients)
+};
+
+// consecutive logical workgroups (the blocks of one (b,h), which share the streamed side) on one XCD
+__device__ __forceinline__ int xcd_order(int bid, int n) {
+    if (n & 7) return bid;
+    return (bid & 7) * (n >> 3) + (bid >> 3);
+}
+
+__device__ __forceinline__ F scaled(const F x, float s) {
+    f32x8v y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = bf2f(x[e]) * s;
+    return __builtin_bit_cast(F, __builtin_convertvector(y, hwbf16x8));
+}
+__device__ __forceinline__ u32x4v scaled_raw(const u32x4v x, float s) {
+    return __builtin_bit_cast(u32x4v, scaled(__builtin_bit_cast(F, x), s));
+}
+
+// dst[c][r] = src[r][c] (src: nrow x ncol fp32, zero outside) as bf16 operand rows of pitch KP
+__device__ __forceinline__ void stage_table_T(short* dst, const float* src, int nrow, int ncol) {
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i & 63, r = i >> 6;
+        dst[c * KP + r] = f2bf((r < nrow && c < ncol) ? src[(int64_t)r * ncol + c] : 0.f);
+    }
+}
+// dst[r][c] = src[r][c]
+__device__ __forceinline__ void stage_table_R(short* dst, const float* src, int nrow, int ncol) {
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i & 63, r = i >> 6;
+        dst[r * KP + c] = f2bf((r < nrow && c < ncol) ? src[(int64_t)r * ncol + c] : 0.f);
+    }
+}
+
+// ---- staged tiles ------------------------------------------------------------------------------------
+// row-major [32][64] tile: thread -> (row tid >> 3, 16-byte chunk tid & 7)
+__device__ __forceinline__ u32x4v rows_load(const short* base, int64_t rs, int row0, int nrows, bool zero_pad) {
+    const int row = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const int j = min(row0 + row, nrows - 1);
+    const u32x4v x = *reinterpret_cast<const u32x4v*>(base + (int64_t)j * rs + cc * 8);
+    return (!zero_pad || row0 + row < nrows) ? x : u32x4v{0, 0, 0, 0};
+}
+__device__ __forceinline__ void rows_store(short* dst, const u32x4v& x) {
+    const int row = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    *reinterpret_cast<u32x4v*>(dst + row * KP + cc * 8) = x;
+}
+__device__ __forceinline__ void rows_store_T(short* dst, const u32x4v& x, int pitch = VTP) {
+    const int row = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    union { u32x4v v; short e[8]; } u;
+    u.v = x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(cc * 8 + e) * pitch + row] = u.e[e];
+}
+// lookup rows (bf16 [32][64] contiguous in global) -> [32][LBP]
+__device__ __forceinline__ void lrows_store(short* dst, const u32x4v& x) {
+    const int row = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + row * LBP + cc * 8);
+    d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
+}
+// id tile: 128 own rows x 32 partners; thread -> (row tid >> 1, half tid & 1)
+__device__ __forceinline__ u32x4v ids_load(const uint8_t* tab, int NP, int row0, int t) {
+    const int row = min(row0 + (int)(threadIdx.x >> 1), NP - 1);
+    return *reinterpret_cast<const u32x4v*>(tab + (int64_t)row * NP + t * 32 + (threadIdx.x & 1) * 16);
+}
+__device__ __forceinline__ void ids_store(unsigned char* tile, const u32x4v& x) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(tile + (threadIdx.x >> 1) * IDP + (threadIdx.x & 1) * 16);
+    d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
+}
+// the 16 bucket ids of this lane's (own row, partners acc_row(r, g)) in a staged id tile
+__device__ __forceinline__ void lane_ids(uint32_t (&w)[4], const unsigned char* tile, int row, int g) {
+    const unsigned char* p = tile + row * IDP + 4 * g;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) w[rr] = *reinterpret_cast<const uint32_t*>(p + 8 * rr);
+}
+__device__ __forceinline__ int id_of(const uint32_t (&w)[4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+
+// lookups^T (64 buckets x 32 own rows) = tab(64 buckets x 64 d) . X^T  ->  scr[row][bucket] (bf16) * mul
+__device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, const F (&xb)[4], float mul, int lane) {
+    const int c32 = lane & 31, g = lane >> 5;
+    f32x16 a0 = {}, a1 = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a0 = TT::mma(TT::load(tab + c32 * KP + ks * 16 + g * 8), xb[ks], a0);
+        a1 = TT::mma(TT::load(tab + (c32 + 32) * KP + ks * 16 + g * 8), xb[ks], a1);
+    }
+    short* row = scr + c32 * LBP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        row[acc_row(r, g)] = f2bf(a0[r] * mul);
+        row[32 + acc_row(r, g)] = f2bf(a1[r] * mul);
+    }
+}
+// this lane's half of a bf16 lookup row (buckets ks*16 + g*8 .. +7, ks = 0..3) -> global row of 64
+__device__ __forceinline__ void lrow_to_global(short* dst, const short* row, int g) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(row + ks * 16 + g * 8);
+        *reinterpret_cast<u32x4v*>(dst + ks * 16 + g * 8) = u32x4v{s[0], s[1], s[2], s[3]};
+    }
+}
+// fragment of 8 consecutive values (buckets ks*16 + g*8 ..) of an fp32 scatter-add row, times mul
+__device__ __forceinline__ F srow_frag(const float* row, int ks, int g, float mul) {
+    f32x8v x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = row[ks * 16 + g * 8 + e] * mul;
+    return __builtin_bit_cast(F, __builtin_convertvector(x, hwbf16x8));
+}
+__device__ __forceinline__ void store_row64(short* op, const f32x16 (&o)[2], int g, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = dt * 32 + 8 * r4 + 4 * g;
+            *reinterpret_cast<u32x2v*>(op + d) = u32x2v{f2bf_pair(o[dt][4 * r4] * mul, o[dt][4 * r4 + 1] * mul),
+                                                        f2bf_pair(o[dt][4 * r4 + 2] * mul, o[dt][4 * r4 + 3] * mul)};
+        }
+}
+__device__ __forceinline__ void load_frags(F (&f)[4], const short* row, int g) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = TT::load(row + ks * 16 + g * 8);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <bool HQ, bool HK, bool HV> struct LdsF {
+    static constexpr int kbuf = 0;                                   // 2 x [32][KP] bf16
+    static constexpr int vtbuf = kbuf + 2 * 32 * KP * 2;             // 2 x [64][VTP] bf16
+    static constexpr int idk = vtbuf + 2 * 64 * VTP * 2;             // 2 x [128][IDP] bytes
+    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
+    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
+    static constexpr int wkT = idq + (HQ ? 2 * 128 * IDP : 0);       // [64 buckets][KP] bf16
+    static constexpr int wqT = wkT + (HK ? 64 * KP * 2 : 0);
+    static constexpr int wvT = wqT + (HQ ? 64 * KP * 2 : 0);         // [64 d][KP] bf16 (columns = buckets)
+    static constexpr int lk = wvT + (HV ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
+    static constexpr int sv = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LKP] fp32
+    static constexpr int lq = sv + (HV ? QW * 32 * LKP * 4 : 0);     // 2 x [32 keys][LBP] bf16
+    static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
+};
+
+// S^T tile (rows = streamed tokens, column = own token) with the relative position terms:
+//   own_row[id_own]             lookups indexed by the lane's own token        (ids in own_ids)
+//   side[partner][id_side]      lookups indexed by the streamed token          (ids in side_ids)
+template <bool OWN, bool SIDE>
+__device__ __forceinline__ f32x16 score_tile(const short* rows, const F (&own)[4], const unsigned char* own_ids,
+                                             const unsigned char* side_ids, const short* own_row, const short* side,
+                                             int trow, int lane) {
+    const int c32 = lane & 31, g = lane >> 5;
+    f32x16 s = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = TT::mma(TT::load(rows + c32 * KP + ks * 16 + g * 8), own[ks], s);
+    if constexpr (OWN) {
+        uint32_t w[4];
+        lane_ids(w, own_ids, trow, g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += bf2f(own_row[id_of(w, r)]);
+    }
+    if constexpr (SIDE) {
+        uint32_t w[4];
+        lane_ids(w, side_ids, trow, g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += bf2f(side[acc_row(r, g) * LBP + id_of(w, r)]);
+    }
+    return s;
+}
+
+// rpe_q lookups of a staged key tile, shared by the four waves: waves 0 and 1 each compute one half of
+// the buckets.  Ends with a workgroup barrier.
+__device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const short* kb, float scale, int wave, int lane) {
+    if (wave < 2) {
+        const int c32 = lane & 31, g = lane >> 5;
+        f32x16 acc = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = TT::mma(TT::load(wqT + (c32 + 32 * wave) * KP + ks * 16 + g * 8), TT::load(kb + c32 * KP + ks * 16 + g * 8),
+                          acc);
+        short* row = dst + c32 * LBP + 32 * wave;                     // lane = key, rows = buckets
+#pragma unroll
+        for (int r = 0; r < 16; ++r) row[acc_row(r, g)] = f2bf(acc[r] * scale);   // (k * scale) Wq (:82)
+    }
+    __syncthreads();
+}
+
+template <bool HQ, bool HK, bool HV>
+__global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
+    using L = LdsF<HQ, HK, HV>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
+    const int lb = xcd_order(blockIdx.x, gridDim.x);
+    const int bh = lb / QB, qblk = lb - bh * QB;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int q0 = qblk * 32 * QW;
+    const bool active = qblk * QW + wave < NT;
+    const int qrow = wave * 32 + c32;                 // row of this lane's query inside the workgroup's block
+    const int qi = q0 + qrow;
+    const bool qok = active && qi < a.L;
+
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const short* qp = a.q + base;
+    const short* kp = a.k + base;
+    const short* vp = a.v + base;
+
+    short* kbuf = reinterpret_cast<short*>(smem + L::kbuf);
+    short* vtbuf = reinterpret_cast<short*>(smem + L::vtbuf);
+    short* wkT = reinterpret_cast<short*>(smem + L::wkT);
+    short* wqT = reinterpret_cast<short*>(smem + L::wqT);
+    short* wvT = reinterpret_cast<short*>(smem + L::wvT);
+    short* lkw = reinterpret_cast<short*>(smem + L::lk) + wave * 32 * LBP;
+    float* svw = reinterpret_cast<float*>(smem + L::sv) + wave * 32 * LKP;
+    short* lqs = reinterpret_cast<short*>(smem + L::lq);
+
+    // ---- prologue: this lane's query row (scaled), tables, first key tile -----------------------
+    F qs[4];
+    load_frags(qs, qp + (int64_t)min(qi, a.L - 1) * a.sn, g);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qs[ks] = scaled(qs[ks], a.scale);          // q * scale in q's dtype (:73)
+    u32x4v sk, sv4 = {}, sik = {}, siv = {}, siq = {};
+    sk = rows_load(kp, a.sn, 0, a.L, false);
+    if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
+    if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
+    if constexpr (HK) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);
+    if constexpr (HQ) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+    if constexpr (HV) {
+        stage_table_T(wvT, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);            // Wv (nb x 64): dst[d][u]
+        for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f;
+    }
+    rows_store(kbuf, sk);
+    if constexpr (HK) ids_store(smem + L::idk, sik);
+    if constexpr (HQ) ids_store(smem + L::idq, siq);
+    __syncthreads();
+    if constexpr (HK) {
+        if (active) lookups_to_lds(lkw, wkT, qs, 1.f, lane);
+        wave_lds_fence();
+    }
+    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
+
+    // ---- pass 1: row maxima ----------------------------------------------------------------------
+    // tiles 0..NT-1 (pass 1) and again 0..NT-1 (pass 2) form one stream of staged tiles
+    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const int tn = t + 1 < NT ? t + 1 : 0;
+        const bool with_v = t + 1 >= NT;
+        sk = rows_load(kp, a.sn, tn * 32, a.L, false);
+        if (with_v) sv4 = rows_load(vp, a.sn, tn * 32, a.L, true);
+        if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, tn);
+        if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, tn);
+        if constexpr (HV) { if (with_v) siv = ids_load(a.idv, a.NP, q0, tn); }
+        if (active) {
+            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
+                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+            if (t == NT - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 32 + acc_row(r, g) >= a.L) s[r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], s[r]);
+        }
+        rows_store(kbuf + nxt * 32 * KP, sk);
+        if (with_v) rows_store_T(vtbuf + nxt * 64 * VTP, sv4);
+        if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
+        if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
+        if constexpr (HV) { if (with_v) ids_store(smem + L::idv + nxt * 128 * IDP, siv); }
+        __syncthreads();
+        if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+    }
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float mL = m * LOG2E;
+
+    // ---- pass 2: probabilities, P.V, bucket sums -------------------------------------------------
+    f32x16 o[2] = {f32x16{}, f32x16{}};
+    float l4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+        const int cur = (NT + t) & 1, nxt = cur ^ 1;
+        const bool more = t + 1 < NT;
+        if (more) {
+            sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
+            sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
+            if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
+            if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
+            if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
+        }
+        if (active) {
+            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
+                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t < NT - 1 || t * 32 + acc_row(r, g) < a.L;
+                const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -mL)) : 0.f;
+                s[r] = p;
+                l4[r & 3] += p;
+            }
+            const short* vt = vtbuf + cur * 64 * VTP;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const F pb = TT::from_acc(s, s2);
+                o[0] = TT::mma(TT::load_perm(vt + c32 * VTP, s2, g), pb, o[0]);
+                o[1] = TT::mma(TT::load_perm(vt + (c32 + 32) * VTP, s2, g), pb, o[1]);
+            }
+            if constexpr (HV) {
+                uint32_t w[4];
+                lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
+                float* row = svw + c32 * LKP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), s[r]);
+            }
+        }
+        if (more) {
+            rows_store(kbuf + nxt * 32 * KP, sk);
+            rows_store_T(vtbuf + nxt * 64 * VTP, sv4);
+            if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
+            if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
+            if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
+            __syncthreads();
+            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+        }
+    }
+    if (!active) return;
+    float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.f / l;
+    if (qok && g == 0) a.lse[(int64_t)bh * a.L + qi] = m + __logf(l);
+
+    // ---- value-side term: (normalised bucket sums) . Wv;  the bucket sums are kept for backward ------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; }
+    if constexpr (HV) {
+        wave_lds_fence();
+        const float* row = svw + c32 * LKP;
+        short* svg = a.sv + ((int64_t)bh * a.NP + qi) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const F sb = srow_frag(row, ks, g, inv_l);
+            *reinterpret_cast<F*>(svg + ks * 16 + g * 8) = sb;
+            o[0] = TT::mma(TT::load(wvT + c32 * KP + ks * 16 + g * 8), sb, o[0]);
+            o[1] = TT::mma(TT::load(wvT + (c32 + 32) * KP + ks * 16 + g * 8), sb, o[1]);
+        }
+    }
+    if (qok) store_row64(a.out + (((int64_t)b * a.L + qi) * a.H + h) * 64, o, g, 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward A: lanes own queries — delta, dq, dLK; LK / G rows for launch B
+// ---------------------------------------------------------------------------------------------------
+template <bool HQ, bool HK, bool HV> struct LdsA {
+    static constexpr int kbuf = 0;                                   // 2 x [32][KP]   K rows
+    static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP]   V rows
+    static constexpr int ktbuf = vbuf + 2 * 32 * KP * 2;             // 2 x [64][VTP]  K^T
+    static constexpr int stage_end = ktbuf + 2 * 64 * VTP * 2;       // (tables are staged over this area outside the loop)
+    static constexpr int idk = stage_end;
+    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
+    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
+    static constexpr int wqT = idq + (HQ ? 2 * 128 * IDP : 0);
+    static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
+    static constexpr int gl = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LBP] bf16
+    static constexpr int dlk = gl + (HV ? QW * 32 * LBP * 2 : 0);    // QW x [32][LKP] fp32
+    static constexpr int lq = dlk + (HK ? QW * 32 * LKP * 4 : 0);    // 2 x [32][LBP] bf16
+    static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
+};
+
+template <bool HQ, bool HK, bool HV>
+__global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
+    using L = LdsA<HQ, HK, HV>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
+    const int lb = xcd_order(blockIdx.x, gridDim.x);
+    const int bh = lb / QB, qblk = lb - bh * QB;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int q0 = qblk * 32 * QW;
+    const bool active = qblk * QW + wave < NT;
+    const int qrow = wave * 32 + c32;
+    const int qi = q0 + qrow;
+    const bool qok = active && qi < a.L;
+    const int qcl = min(qi, a.L - 1);
+
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const short* kp = a.k + base;
+    const short* vp = a.v + base;
+    const int64_t orow = (int64_t)a.H * 64;
+    const short* dop = a.dout + ((int64_t)b * a.L * a.H + h) * 64;
+    const short* outp = a.out + ((int64_t)b * a.L * a.H + h) * 64;
+
+    short* kbuf = reinterpret_cast<short*>(smem + L::kbuf);
+    short* vbuf = reinterpret_cast<short*>(smem + L::vbuf);
+    short* ktbuf = reinterpret_cast<short*>(smem + L::ktbuf);
+    short* tab0 = reinterpret_cast<short*>(smem);                    // tables staged over the tile area
+    short* tab1 = tab0 + 64 * KP;
+    short* wqT = reinterpret_cast<short*>(smem + L::wqT);
+    short* lkw = reinterpret_cast<short*>(smem + L::lk) + wave * 32 * LBP;
+    short* glw = reinterpret_cast<short*>(smem + L::gl) + wave * 32 * LBP;
+    float* dlkw = reinterpret_cast<float*>(smem + L::dlk) + wave * 32 * LKP;
+    short* lqs = reinterpret_cast<short*>(smem + L::lq);
+
+    // ---- prologue ---------------------------------------------------------------------------------
+    F qs[4], dob[4];
+    float delta = 0.f;
+    {
+        F ob[4];
+        load_frags(qs, a.q + base + (int64_t)qcl * a.sn, g);
+        load_frags(dob, dop + (int64_t)qcl * orow, g);
+        load_frags(ob, outp + (int64_t)qcl * orow, g);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qs[ks] = scaled(qs[ks], a.scale);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += bf2f(dob[ks][e]) * bf2f(ob[ks][e]);
+        }
+        delta += __shfl_xor(delta, 32);
+        if (!qok) {
+            delta = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dob[ks] = TT::zero();
+        }
+    }
+    if (active && g == 0) a.delta[(int64_t)bh * a.NP + qi] = delta;
+    const float lseL = qok ? a.lse[(int64_t)bh * a.L + qi] * LOG2E : INFINITY;
+
+    if constexpr (HK) stage_table_T(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);       // [bucket][d]
+    if constexpr (HV) stage_table_R(tab1, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);       // [bucket][d]
+    if constexpr (HQ) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+    if constexpr (HK) { for (int i = lane; i < 32 * LKP; i += 64) dlkw[i] = 0.f; }
+    __syncthreads();
+    if (active) {
+        if constexpr (HK) {
+            lookups_to_lds(lkw, tab0, qs, 1.f, lane);
+            wave_lds_fence();
+            lrow_to_global(a.lkg + ((int64_t)bh * a.NP + qi) * 64, lkw + c32 * LBP, g);
+        }
+        if constexpr (HV) {
+            lookups_to_lds(glw, tab1, dob, 1.f, lane);
+            wave_lds_fence();
+            lrow_to_global(a.gg + ((int64_t)bh * a.NP + qi) * 64, glw + c32 * LBP, g);
+        }
+    }
+    __syncthreads();                                   // tables consumed: the tile area is free
+    u32x4v sk, sv4, sik = {}, siv = {}, siq = {};
+    sk = rows_load(kp, a.sn, 0, a.L, false);
+    sv4 = rows_load(vp, a.sn, 0, a.L, true);
+    if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
+    if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
+    if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, 0);
+    rows_store(kbuf, sk);
+    rows_store_T(ktbuf, sk);
+    rows_store(vbuf, sv4);
+    if constexpr (HK) ids_store(smem + L::idk, sik);
+    if constexpr (HQ) ids_store(smem + L::idq, siq);
+    if constexpr (HV) ids_store(smem + L::idv, siv);
+    __syncthreads();
+    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
+
+    // ---- key tiles ----------------------------------------------------------------------------------
+    f32x16 dq[2] = {f32x16{}, f32x16{}};
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool more = t + 1 < NT;
+        if (more) {
+            sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
+            sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
+            if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
+            if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
+            if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
+        }
+        if (active) {
+            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
+                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+            f32x16 dp = {};
+            const short* vb = vbuf + cur * 32 * KP;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = TT::mma(TT::load(vb + c32 * KP + ks * 16 + g * 8), dob[ks], dp);
+            if constexpr (HV) {
+                uint32_t w[4];
+                lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
+                const short* row = glw + c32 * LBP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] += bf2f(row[id_of(w, r)]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t < NT - 1 || t * 32 + acc_row(r, g) < a.L;
+                const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -lseL)) : 0.f;
+                s[r] = p * (dp[r] - delta);
+            }
+            if constexpr (HK) {
+                uint32_t w[4];
+                lane_ids(w, smem + L::idk + cur * 128 * IDP, qrow, g);
+                float* row = dlkw + c32 * LKP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), s[r]);
+            }
+            const short* ktb = ktbuf + cur * 64 * VTP;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const F db = TT::from_acc(s, s2);
+                dq[0] = TT::mma(TT::load_perm(ktb + c32 * VTP, s2, g), db, dq[0]);
+                dq[1] = TT::mma(TT::load_perm(ktb + (c32 + 32) * VTP, s2, g), db, dq[1]);
+            }
+        }
+        if (more) {
+            rows_store(kbuf + nxt * 32 * KP, sk);
+            rows_store_T(ktbuf + nxt * 64 * VTP, sk);
+            rows_store(vbuf + nxt * 32 * KP, sv4);
+            if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
+            if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
+            if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
+            __syncthreads();
+            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+        }
+    }
+
+    // ---- dq += dLK Wk^T; bucket gradient rows out -------------------------------------------------
+    if constexpr (HK) {
+        __syncthreads();                               // every wave is done with the tile area
+        stage_table_R(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);      // [d][bucket]
+        __syncthreads();
+        if (active) {
+            const float* row = dlkw + c32 * LKP;
+            short* dst = a.dlk + ((int64_t)bh * a.NP + qi) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const F db = srow_frag(row, ks, g, 1.f);
+                *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = db;
+                dq[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dq[0]);
+                dq[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dq[1]);
+            }
+        }
+    }
+    if (qok) store_row64(a.dq + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh, dq, g, a.scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward B: lanes own keys — dk, dv, dLQ
+// ---------------------------------------------------------------------------------------------------
+template <bool HQ, bool HK, bool HV> struct LdsB {
+    static constexpr int qbuf = 0;                                   // 2 x [32][KP]   (s q) rows
+    static constexpr int dobuf = qbuf + 2 * 32 * KP * 2;             // 2 x [32][KP]   dO rows
+    static constexpr int qtbuf = dobuf + 2 * 32 * KP * 2;            // 2 x [64][VTP]  (s q)^T
+    static constexpr int dotbuf = qtbuf + 2 * 64 * VTP * 2;          // 2 x [64][VTP]  dO^T
+    static constexpr int stage_end = dotbuf + 2 * 64 * VTP * 2;
+    static constexpr int idk = stage_end;                            // key-major id tiles
+    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
+    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
+    static constexpr int lkt = idq + (HQ ? 2 * 128 * IDP : 0);       // 2 x [32 queries][LBP]  rpe_k lookups of the query tile
+    static constexpr int gt = lkt + (HK ? 2 * 32 * LBP * 2 : 0);     // 2 x [32 queries][LBP]  value-side lookups of dO
+    static constexpr int lqk = gt + (HV ? 2 * 32 * LBP * 2 : 0);     // QW x [32 keys][LBP]    rpe_q lookups (own keys)
+    static constexpr int dlq = lqk + (HQ ? QW * 32 * LBP * 2 : 0);   // QW x [32 keys][LKP] fp32
+    static constexpr int stats = dlq + (HQ ? QW * 32 * LKP * 4 : 0); // lse*log2e [NP], delta [NP]
+    static constexpr int fixed = stats;
+};
+
+template <bool HQ, bool HK, bool HV>
+__global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
+    using L = LdsB<HQ, HK, HV>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NT = a.NP >> 5, KB = (NT + QW - 1) / QW;
+    const int lb = xcd_order(blockIdx.x, gridDim.x);
+    const int bh = lb / KB, kblk = lb - bh * KB;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int k0 = kblk * 32 * QW;
+    const bool active = kblk * QW + wave < NT;
+    const int krow = wave * 32 + c32;
+    const int kj = k0 + krow;
+    const bool kok = active && kj < a.L;
+    const int kcl = min(kj, a.L - 1);
+
+    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+    const short* qp = a.q + base;
+    const int64_t orow = (int64_t)a.H * 64;
+    const short* dop = a.dout + ((int64_t)b * a.L * a.H + h) * 64;
+    const short* lkg = a.lkg + (int64_t)bh * a.NP * 64;
+    const short* gg = a.gg + (int64_t)bh * a.NP * 64;
+
+    short* qbuf = reinterpret_cast<short*>(smem + L::qbuf);
+    short* dobuf = reinterpret_cast<short*>(smem + L::dobuf);
+    short* qtbuf = reinterpret_cast<short*>(smem + L::qtbuf);
+    short* dotbuf = reinterpret_cast<short*>(smem + L::dotbuf);
+    short* tab0 = reinterpret_cast<short*>(smem);
+    short* lkt = reinterpret_cast<short*>(smem + L::lkt);
+    short* gt = reinterpret_cast<short*>(smem + L::gt);
+    short* lqw = reinterpret_cast<short*>(smem + L::lqk) + wave * 32 * LBP;
+    float* dlqw = reinterpret_cast<float*>(smem + L::dlq) + wave * 32 * LKP;
+    float* lse_s = reinterpret_cast<float*>(smem + L::stats);
+    float* delta_s = lse_s + a.NP;
+
+    // ---- prologue ---------------------------------------------------------------------------------
+    F kf[4], vf[4];
+    load_frags(kf, a.k + base + (int64_t)kcl * a.sn, g);
+    load_frags(vf, a.v + base + (int64_t)kcl * a.sn, g);
+    for (int i = threadIdx.x; i < a.NP; i += 256) {
+        lse_s[i] = i < a.L ? a.lse[(int64_t)bh * a.L + i] * LOG2E : INFINITY;
+        delta_s[i] = a.delta[(int64_t)bh * a.NP + i];
+    }
+    if constexpr (HQ) {
+        stage_table_T(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [bucket][d]
+        for (int i = lane; i < 32 * LKP; i += 64) dlqw[i] = 0.f;
+        __syncthreads();
+        if (active) {
+            F ksf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ksf[ks] = scaled(kf[ks], a.scale);
+            lookups_to_lds(lqw, tab0, ksf, 1.f, lane);                   // (k * scale) Wq (:82)
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    u32x4v sq, sdo, slk = {}, sg = {}, sik = {}, siv = {}, siq = {};
+    auto load_tile = [&](int t) {
+        sq = scaled_raw(rows_load(qp, a.sn, t * 32, a.L, false), a.scale);
+        sdo = rows_load(dop, orow, t * 32, a.L, true);
+        if constexpr (HK) slk = rows_load(lkg, 64, t * 32, a.NP, false);
+        if constexpr (HV) sg = rows_load(gg, 64, t * 32, a.NP, false);
+        if constexpr (HK) sik = ids_load(a.idk_t, a.NP, k0, t);
+        if constexpr (HQ) siq = ids_load(a.idq_t, a.NP, k0, t);
+        if constexpr (HV) siv = ids_load(a.idv_t, a.NP, k0, t);
+    };
+    auto store_tile = [&](int buf) {
+        rows_store(qbuf + buf * 32 * KP, sq);
+        rows_store_T(qtbuf + buf * 64 * VTP, sq);
+        rows_store(dobuf + buf * 32 * KP, sdo);
+        rows_store_T(dotbuf + buf * 64 * VTP, sdo);
+        if constexpr (HK) lrows_store(lkt + buf * 32 * LBP, slk);
+        if constexpr (HV) lrows_store(gt + buf * 32 * LBP, sg);
+        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, sik);
+        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, siq);
+        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, siv);
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // ---- query tiles --------------------------------------------------------------------------------
+    f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool more = t + 1 < NT;
+        if (more) load_tile(t + 1);
+        if (active) {
+            // rows = queries of the tile, column = own key: own lookups = rpe_q, side lookups = rpe_k
+            f32x16 s = score_tile<HQ, HK>(qbuf + cur * 32 * KP, kf, smem + L::idq + cur * 128 * IDP,
+                                          smem + L::idk + cur * 128 * IDP, lqw + c32 * LBP, lkt + cur * 32 * LBP, krow, lane);
+            f32x16 dp = {};
+            const short* db = dobuf + cur * 32 * KP;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = TT::mma(TT::load(db + c32 * KP + ks * 16 + g * 8), vf[ks], dp);
+            if constexpr (HV) {
+                uint32_t w[4];
+                lane_ids(w, smem + L::idv + cur * 128 * IDP, krow, g);
+                const short* side = gt + cur * 32 * LBP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] += bf2f(side[acc_row(r, g) * LBP + id_of(w, r)]);
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4v ls = *reinterpret_cast<const f32x4v*>(lse_s + t * 32 + 8 * rr + 4 * g);
+                const f32x4v dl = *reinterpret_cast<const f32x4v*>(delta_s + t * 32 + 8 * rr + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rr + e;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ls[e]));
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - dl[e]);
+                }
+            }
+            if constexpr (HQ) {
+                uint32_t w[4];
+                lane_ids(w, smem + L::idq + cur * 128 * IDP, krow, g);
+                float* row = dlqw + c32 * LKP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), ds[r]);
+            }
+            const short* dot = dotbuf + cur * 64 * VTP;
+            const short* qtb = qtbuf + cur * 64 * VTP;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const F pb = TT::from_acc(s, s2);
+                const F sb = TT::from_acc(ds, s2);
+                dv[0] = TT::mma(TT::load_perm(dot + c32 * VTP, s2, g), pb, dv[0]);
+                dv[1] = TT::mma(TT::load_perm(dot + (c32 + 32) * VTP, s2, g), pb, dv[1]);
+                dk[0] = TT::mma(TT::load_perm(qtb + c32 * VTP, s2, g), sb, dk[0]);
+                dk[1] = TT::mma(TT::load_perm(qtb + (c32 + 32) * VTP, s2, g), sb, dk[1]);
+            }
+        }
+        if (more) {
+            store_tile(nxt);
+            __syncthreads();
+        }
+    }
+
+    // ---- dk += s dLQ Wq^T; bucket gradient rows out ------------------------------------------------
+    if constexpr (HQ) {
+        __syncthreads();
+        stage_table_R(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [d][bucket]
+        __syncthreads();
+        if (active) {
+            const float* row = dlqw + c32 * LKP;
+            short* dst = a.dlq + ((int64_t)bh * a.NP + kj) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = srow_frag(row, ks, g, 1.f);
+                const F db = srow_frag(row, ks, g, a.scale);
+                dk[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dk[0]);
+                dk[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dk[1]);
+            }
+        }
+    }
+    if (kok) {
+        const int64_t off = (int64_t)b * a.dsb + (int64_t)kj * a.dsn + (int64_t)h * a.dsh;
+        store_row64(a.dk + off, dk, g, 1.f);
+        store_row64(a.dv + off, dv, g, 1.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// table gradients: out[bh][a][c] = mul * sum_i X[b,i,h][a] * Y[b,i,h][c]     (64 x 64 per (b,h))
+// ---------------------------------------------------------------------------------------------------
+struct TgArgs {
+    const short *x, *y;
+    int64_t xsb, xsn, xsh, ysb, ysn, ysh;
+    float* out;
+    int H, L;
+    float mul;
+};
+constexpr int TGP = 40;      // pitch of the transposed tiles here: rows are read 16 bytes at a time
+
+__global__ __launch_bounds__(256) void irpe_table_grad_kernel(const TgArgs a) {
+    __shared__ __attribute__((aligned(16))) short xt[2][64 * TGP];
+    __shared__ __attribute__((aligned(16))) short yt[2][64 * TGP];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const short* xp = a.x + (int64_t)b * a.xsb + (int64_t)h * a.xsh;
+    const short* yp = a.y + (int64_t)b * a.ysb + (int64_t)h * a.ysh;
+    const int NT = (a.L + 31) >> 5;
+    const int ta = wave & 1, tc = wave >> 1;
+    u32x4v sx = rows_load(xp, a.xsn, 0, a.L, true), sy = rows_load(yp, a.ysn, 0, a.L, true);
+    rows_store_T(xt[0], sx, TGP);
+    rows_store_T(yt[0], sy, TGP);
+    __syncthreads();
+    f32x16 acc = {};
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < NT) {
+            sx = rows_load(xp, a.xsn, (t + 1) * 32, a.L, true);
+            sy = rows_load(yp, a.ysn, (t + 1) * 32, a.L, true);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            acc = TT::mma(TT::load(xt[cur] + (ta * 32 + c32) * TGP + ks * 16 + g * 8),
+                          TT::load(yt[cur] + (tc * 32 + c32) * TGP + ks * 16 + g * 8), acc);
+        if (t + 1 < NT) {
+            rows_store_T(xt[cur ^ 1], sx, TGP);
+            rows_store_T(yt[cur ^ 1], sy, TGP);
+            __syncthreads();
+        }
+    }
+    float* o = a.out + (int64_t)bh * 64 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(ta * 32 + acc_row(r, g)) * 64 + tc * 32 + c32] = acc[r] * a.mul;
+}
+
+// int32 (Lq x Lk) bucket ids -> zero-padded uint8 (NP x NP), optionally transposed
+__global__ void bucket_bytes_kernel(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NP) return;
+    int v = 0;
+    if (!transpose) { if (i < Lq && j < Lk) v = ids[(int64_t)i * Lk + j]; }
+    else            { if (j < Lq && i < Lk) v = ids[(int64_t)j * Lk + i]; }
+    dst[(int64_t)i * NP + j] = (uint8_t)v;
+}
+
+template <typename K>
+int launch(K kern, const Args& a, size_t lds, hipStream_t st) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+        return CREAM_ERR_LAUNCH;
+    const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
+    hipLaunchKernelGGL(kern, dim3(a.B * a.H * QB), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+template <bool HQ, bool HK, bool HV> int launch_fwd(const Args& a, hipStream_t st) {
+    return launch(irpe_attn_fwd_kernel<HQ, HK, HV>, a, LdsF<HQ, HK, HV>::total, st);
+}
+template <bool HQ, bool HK, bool HV> int launch_bwd(const Args& a, hipStream_t st) {
+    const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV>, a, LdsA<HQ, HK, HV>::total, st);
+    if (rc) return rc;
+    return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV>, a, LdsB<HQ, HK, HV>::fixed + (size_t)a.NP * 8, st);
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int check(const cream_irpe_attn_desc* d, bool bwd) {
+    if (!d || !d->q || !d->k || !d->v || !d->out || !d->lse) return CREAM_ERR_BAD_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->L <= 0 || d->nb <= 0 || d->nb > 64) return CREAM_ERR_BAD_ARG;
+    if (d->NP != (d->L + 31) / 32 * 32) return CREAM_ERR_BAD_ARG;
+    if (d->NP > 2048) return CREAM_ERR_TOO_LARGE;
+    if (d->sn % 8 || d->sh % 8 || d->sb % 8 || !aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v) || !aligned16(d->out))
+        return CREAM_ERR_BAD_ARG;
+    const bool hq = d->wq != nullptr, hk = d->wk != nullptr, hv = d->wv != nullptr;
+    if ((hq && !d->idq) || (hk && !d->idk) || (hv && (!d->idv || !d->sv))) return CREAM_ERR_BAD_ARG;
+    if ((hq && !aligned16(d->idq)) || (hk && !aligned16(d->idk)) || (hv && !aligned16(d->idv))) return CREAM_ERR_BAD_ARG;
+    if (bwd) {
+        if (!d->dout || !d->dq || !d->dk || !d->dv || !d->delta) return CREAM_ERR_BAD_ARG;
+        if (d->dsn % 4 || d->dsh % 4 || d->dsb % 4 || !aligned16(d->dout)) return CREAM_ERR_BAD_ARG;
+        if ((hq && (!d->idq_t || !d->dlq)) || (hk && (!d->idk_t || !d->lkg || !d->dlk)) || (hv && (!d->idv_t || !d->gg)))
+            return CREAM_ERR_BAD_ARG;
+    }
+    return CREAM_OK;
+}
+
+Args to_args(const cream_irpe_attn_desc* d) {
+    Args a{};
+    a.q = (const short*)d->q; a.k = (const short*)d->k; a.v = (const short*)d->v;
+    a.sb = d->sb; a.sn = d->sn; a.sh = d->sh;
+    a.out = (short*)d->out; a.lse = d->lse; a.sv = (short*)d->sv;
+    a.wq = d->wq; a.wk = d->wk; a.wv = d->wv;
+    a.wq_hs = d->wq_hs; a.wk_hs = d->wk_hs; a.wv_hs = d->wv_hs;
+    a.idq = d->idq; a.idk = d->idk; a.idv = d->idv;
+    a.idq_t = d->idq_t; a.idk_t = d->idk_t; a.idv_t = d->idv_t;
+    a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale;
+    a.dout = (const short*)d->dout;
+    a.dq = (short*)d->dq; a.dk = (short*)d->dk; a.dv = (short*)d->dv;
+    a.dsb = d->dsb; a.dsn = d->dsn; a.dsh = d->dsh;
+    a.delta = d->delta; a.lkg = (short*)d->lkg; a.gg = (short*)d->gg; a.dlk = (short*)d->dlk; a.dlq = (short*)d->dlq;
+    return a;
+}
+
+template <template <bool, bool, bool> class Fn>
+int dispatch(const Args& a, hipStream_t st) {
+    const int key = (a.wq ? 4 : 0) | (a.wk ? 2 : 0) | (a.wv ? 1 : 0);
+    switch (key) {
+        case 0: return Fn<false, false, false>::run(a, st);
+        case 1: return Fn<false, false, true>::run(a, st);
+        case 2: return Fn<false, true, false>::run(a, st);
+        case 3: return Fn<false, true, true>::run(a, st);
+        case 4: return Fn<true, false, false>::run(a, st);
+        case 5: return Fn<true, false, true>::run(a, st);
+        case 6: return Fn<true, true, false>::run(a, st);
+        default: return Fn<true, true, true>::run(a, st);
+    }
+}
+template <bool HQ, bool HK, bool HV> struct FwdFn { static int run(const Args& a, hipStream_t st) { return launch_fwd<HQ, HK, HV>(a, st); } };
+template <bool HQ, bool HK, bool HV> struct BwdFn { static int run(const Args& a, hipStream_t st) { return launch_bwd<HQ, HK, HV>(a, st); } };
+
+}  // namespace
+
+extern "C" {
+
+int cream_irpe_padded_len(int L) { return (L + 31) / 32 * 32; }
+
+int cream_irpe_bucket_bytes(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose, void* stream)
+{
+    if (!dst || !ids || Lq <= 0 || Lk <= 0 || NP % 32 || NP < Lq || NP < Lk) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bucket_bytes_kernel, dim3((NP + 255) / 256, NP), dim3(256), 0, (hipStream_t)stream, dst, ids, Lq,
+                       Lk, NP, transpose);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_irpe_attn_fwd(const cream_irpe_attn_desc* d, void* stream)
+{
+    const int rc = check(d, false);
+    if (rc) return rc;
+    return dispatch<FwdFn>(to_args(d), (hipStream_t)stream);
+}
+
+int cream_irpe_attn_bwd(const cream_irpe_attn_desc* d, void* stream)
+{
+    const int rc = check(d, true);
+    if (rc) return rc;
+    return dispatch<BwdFn>(to_args(d), (hipStream_t)stream);
+}
+
+int cream_irpe_table_grad(float* out, const void* x, int64_t xsb, int64_t xsn, int64_t xsh, const void* y, int64_t ysb,
+                          int64_t ysn, int64_t ysh, int B, int H, int L, float mul, void* stream)
+{
+    if (!out || !x || !y || B <= 0 || H <= 0 || L <= 0) return CREAM_ERR_BAD_ARG;
+    if (xsn % 8 || xsh % 8 || xsb % 8 || ysn % 8 || ysh % 8 || ysb % 8 || !aligned16(x) || !aligned16(y)) return CREAM_ERR_BAD_ARG;
+    TgArgs a{(const short*)x, (const short*)y, xsb, xsn, xsh, ysb, ysn, ysh, out, H, L, mul};
+    hipLaunchKernelGGL(irpe_table_grad_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+}  // extern "C"

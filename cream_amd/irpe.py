@@ -159,13 +159,15 @@ class iRPE(nn.Module):
     def bucket_ids(self, x, height=None, width=None):
         """int32 (L, L) bucket matrix for this input (irpe.py:523-583; always int32 here — the
         rpe_index operator is always present)."""
-        L = x.shape[2]
+        return self.bucket_ids_for(x.shape[2], x.device, height, width)
+
+    def bucket_ids_for(self, L, device, height=None, width=None):
         if height is None:
             height = width = int(math.sqrt(L))
         skip = L - height * width
         c = self.rpe_config
         ids, nb = get_bucket_ids_2d(self.method, height, width, skip, c.alpha, c.beta, c.gamma,
-                                    dtype=torch.int32, device=x.device)
+                                    dtype=torch.int32, device=device)
         assert nb == self.num_buckets
         return ids
 

@@ -1,0 +1,197 @@
+"""Fused iRPE attention (contextual rpe on q / k / v) — host side of csrc/irpe_attn.hip.
+
+`attention(qkv, scale, rpe_q, rpe_k, rpe_v)` computes what `RPEAttention.forward` does between the
+qkv and proj linears (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:68-97) in one launch forward and
+two launches (+ one tiny table-gradient product per rpe) backward; nothing of size L^2 is written to
+HBM.  It takes the (B, L, 3, H, 64) bf16 output of the qkv linear as it is (q, k, v are strided views)
+and returns (B, L, H*64) ready for the proj linear.
+
+`usable(...)` says whether a given RPEAttention configuration is covered: bf16 operands (autocast),
+head_dim 64, each rpe either absent or a contextual iRPE with at most 64 buckets (product: 50,
+euclidean / quant: <= 64), no attention dropout in training.  Everything else (bias mode, cross
+method, fp32) takes the composed path of cream_amd.rpe_attention on the HIP rpe_index operator.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib, timing
+
+_BYTES = {}          # (data_ptr, shape, device) -> (ids tensor kept alive, as-is uint8, transposed uint8)
+
+
+def padded_len(L):
+    return (L + 31) // 32 * 32
+
+
+def bucket_bytes(ids):
+    """int32 (L, L) bucket ids -> (NP x NP uint8 as is, NP x NP uint8 transposed), cached per table."""
+    key = (ids.data_ptr(), tuple(ids.shape), str(ids.device))
+    hit = _BYTES.get(key)
+    if hit is not None:
+        return hit[1], hit[2]
+    assert ids.dtype == torch.int32 and ids.dim() == 2 and ids.is_contiguous() and ids.is_cuda
+    Lq, Lk = ids.shape
+    NP = padded_len(max(Lq, Lk))
+    lib = _lib.load()
+    outs = []
+    with torch.cuda.device(ids.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        for tr in (0, 1):
+            dst = torch.empty((NP, NP), dtype=torch.uint8, device=ids.device)
+            _lib.check(lib.cream_irpe_bucket_bytes(dst.data_ptr(), ids.data_ptr(), Lq, Lk, NP, tr, stream),
+                       "cream_irpe_bucket_bytes")
+            outs.append(dst)
+    _BYTES[key] = (ids, outs[0], outs[1])
+    return outs[0], outs[1]
+
+
+def _term(rpe, L, device):
+    """-> (weight parameter, head stride, query-major ids, key-major ids, nb) of one rpe module."""
+    if rpe is None:
+        return None
+    ids = rpe.bucket_ids_for(L, device)
+    asis, tr = bucket_bytes(ids)
+    w = rpe.lookup_table_weight
+    hs = 0 if w.shape[0] == 1 else w.shape[1] * w.shape[2]
+    return w, hs, asis, tr, rpe.num_buckets
+
+
+def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active):
+    if os.environ.get("CREAM_IRPE_FUSED", "1") == "0":
+        return False
+    if device.type != "cuda" or qkv_dtype != torch.bfloat16 or head_dim != 64 or attn_drop_active or L > 2048:
+        return False
+    from .irpe import iRPE
+    nbs = set()
+    for r in rpes:
+        if r is None:
+            continue
+        if type(r) is not iRPE or r.mode != "contextual" or r.num_buckets > 64:
+            return False
+        if r.lookup_table_weight.dtype != torch.float32:
+            return False
+        nbs.add(r.num_buckets)
+    return len(nbs) <= 1
+
+
+def _desc(qkv, scale, terms, out, lse, sv):
+    B, L, _, H, D = qkv.shape
+    d = _lib.IrpeAttnDesc()
+    es = qkv.element_size()
+    base = qkv.data_ptr()
+    sb, sn, s3, sh, _ = qkv.stride()
+    d.q, d.k, d.v = base, base + s3 * es, base + 2 * s3 * es
+    d.sb, d.sn, d.sh = sb, sn, sh
+    d.out, d.lse, d.sv = out.data_ptr(), lse.data_ptr(), (sv.data_ptr() if sv is not None else None)
+    tq, tk, tv = terms
+    nb = 1
+    if tq is not None:                       # rpe_q: bucket_q[j][i] is key-major as stored
+        d.wq, d.wq_hs, d.idq, d.idq_t, nb = tq[0].data_ptr(), tq[1], tq[3].data_ptr(), tq[2].data_ptr(), tq[4]
+    if tk is not None:
+        d.wk, d.wk_hs, d.idk, d.idk_t, nb = tk[0].data_ptr(), tk[1], tk[2].data_ptr(), tk[3].data_ptr(), tk[4]
+    if tv is not None:
+        d.wv, d.wv_hs, d.idv, d.idv_t, nb = tv[0].data_ptr(), tv[1], tv[2].data_ptr(), tv[3].data_ptr(), tv[4]
+    d.B, d.H, d.L, d.NP, d.nb = B, H, L, padded_len(L), nb
+    d.scale = scale
+    return d
+
+
+def _flops(B, H, L, n_terms, bwd):
+    return (2.5 if bwd else 1.0) * 4.0 * B * H * L * L * 64 + (3 if bwd else 1) * n_terms * 2.0 * B * H * L * 64 * 64
+
+
+class _Fused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, scale, wq, wk, wv, terms):
+        B, L, _, H, D = qkv.shape
+        NP = padded_len(L)
+        out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        sv = torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=qkv.device) if terms[2] is not None else None
+        d = _desc(qkv, scale, terms, out, lse, sv)
+        n_terms = sum(t is not None for t in terms)
+        with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, n_terms, False)):
+            rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "cream_irpe_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse, sv if sv is not None else lse)
+        ctx.scale, ctx.terms = scale, terms
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, sv = ctx.saved_tensors
+        terms, scale = ctx.terms, ctx.scale
+        tq, tk, tv = terms
+        if tv is None:
+            sv = None
+        B, L, _, H, D = qkv.shape
+        NP = padded_len(L)
+        dev = qkv.device
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
+        d = _desc(qkv, scale, terms, out, lse, sv)
+        d.dout = dout.data_ptr()
+        es = dqkv.element_size()
+        sb, sn, s3, sh, _ = dqkv.stride()
+        d.dq, d.dk, d.dv = dqkv.data_ptr(), dqkv.data_ptr() + s3 * es, dqkv.data_ptr() + 2 * s3 * es
+        d.dsb, d.dsn, d.dsh = sb, sn, sh
+        delta = torch.empty((B, H, NP), dtype=torch.float32, device=dev)
+        rows = lambda: torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=dev)      # noqa: E731
+        lkg = dlk = gg = dlq = None
+        d.delta = delta.data_ptr()
+        if tk is not None:
+            lkg, dlk = rows(), rows()
+            d.lkg, d.dlk = lkg.data_ptr(), dlk.data_ptr()
+        if tv is not None:
+            gg = rows()
+            d.gg = gg.data_ptr()
+        if tq is not None:
+            dlq = rows()
+            d.dlq = dlq.data_ptr()
+        lib = _lib.load()
+        n_terms = sum(t is not None for t in terms)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            with timing.region("irpe_attn_bwd", flops=_flops(B, H, L, n_terms, True)):
+                rc = lib.cream_irpe_attn_bwd(ctypes.byref(d), stream)
+            _lib.check(rc, "cream_irpe_attn_bwd")
+
+            def table_grad(x, xs, y, ys, mul):
+                part = torch.empty((B, H, 64, 64), dtype=torch.float32, device=dev)
+                _lib.check(lib.cream_irpe_table_grad(part.data_ptr(), x, xs[0], xs[1], xs[2], y, ys[0], ys[1], ys[2],
+                                                     B, H, L, mul, stream), "cream_irpe_table_grad")
+                return part.sum(0)                                   # (H, 64, 64)
+
+            qs = qkv.stride()
+            q_str, row_str = (qs[0], qs[1], qs[3]), (H * NP * 64, 64, NP * 64)
+            do_str = (L * H * 64, H * 64, 64)
+            es_q = qkv.element_size()
+            grads = [None, None, None]
+            if tq is not None:      # d lookup_table_weight(rpe_q) (H', 64, nb) = (scale k)^T dlq
+                g = table_grad(qkv.data_ptr() + qs[2] * es_q, q_str, dlq.data_ptr(), row_str, scale)
+                grads[0] = g
+            if tk is not None:      # (scale q)^T dlk
+                grads[1] = table_grad(qkv.data_ptr(), q_str, dlk.data_ptr(), row_str, scale)
+            if tv is not None:      # (H', nb, 64) = sv^T dout
+                grads[2] = table_grad(sv.data_ptr(), row_str, dout.data_ptr(), do_str, 1.0)
+        res = []
+        for gpart, t, transposed in zip(grads, terms, (True, True, False)):
+            if gpart is None:
+                res.append(None)
+                continue
+            w, nb = t[0], t[4]
+            if w.shape[0] == 1:
+                gpart = gpart.sum(0, keepdim=True)
+            res.append((gpart[:, :, :nb] if transposed else gpart[:, :nb, :]).to(w.dtype).contiguous())
+        return dqkv, None, res[0], res[1], res[2], None
+
+
+def attention(qkv, scale, rpe_q, rpe_k, rpe_v):
+    """qkv (B, L, 3, H, 64) bf16 -> (B, L, H*64)."""
+    assert qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] == 64 and qkv.stride(4) == 1
+    L, dev = qkv.shape[1], qkv.device
+    terms = tuple(_term(r, L, dev) for r in (rpe_q, rpe_k, rpe_v))
+    ws = [t[0] if t is not None else None for t in terms]
+    return _Fused.apply(qkv, float(scale), ws[0], ws[1], ws[2], terms)

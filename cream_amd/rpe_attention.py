@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import irpe_fused
 from .irpe import build_rpe, get_rpe_config
 
 
@@ -68,7 +69,15 @@ class RPEAttention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        qkv = self.qkv(x)
+        hd = C // self.num_heads
+        if irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (self.rpe_q, self.rpe_k, self.rpe_v),
+                             self.training and self.attn_drop.p > 0):
+            # one launch forward, two backward; no (B, H, L, L) tensor exists (csrc/irpe_attn.hip)
+            out = irpe_fused.attention(qkv.view(B, N, 3, self.num_heads, hd), self.scale, self.rpe_q, self.rpe_k,
+                                       self.rpe_v)
+            return self.proj_drop(self.proj(out))
+        q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
         q = q * self.scale                                   # (the reference scales q in place, :73)
         attn = q @ k.transpose(-2, -1)
         if self.rpe_k is not None:

@@ -132,6 +132,53 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
                          int ldt, int B, int H, int N, int gh, int gw, int mr,
                          float scale, int dtype, void* stream);
 
+/* ---- fused attention with iRPE (contextual mode) on queries, keys and values ------------------
+ * Reference: RPEAttention.forward (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:68-97) between the
+ * qkv and proj linears, with iRPE.forward_rpe_transpose / forward_rpe_no_transpose
+ * (irpe.py:585-687) and the rpe_index gather (rpe_ops/rpe_index_cuda.cu:24-40) folded in — see
+ * csrc/irpe_attn.hip for the formulas.  bf16 operands, fp32 accumulation and softmax, head_dim 64,
+ * at most 64 buckets.  A table pointer (wq / wk / wv) that is NULL switches that term off. */
+typedef struct cream_irpe_attn_desc {
+    const void *q, *k, *v;          /* bf16; element (b, n, h, :) at ptr[b*sb + n*sn + h*sh]            */
+    int64_t sb, sn, sh;
+    void* out;                      /* (B, L, H, 64) bf16                                               */
+    float* lse;                     /* (B, H, L)   log-sum-exp of the logits (fwd: out, bwd: in)        */
+    void* sv;                       /* (B, H, NP, 64) bf16 value-side bucket sums (fwd: out, needed with wv) */
+    const float *wq, *wk, *wv;      /* lookup_table_weight of rpe_q / rpe_k (H', 64, nb) and rpe_v (H', nb, 64) */
+    int64_t wq_hs, wk_hs, wv_hs;    /* element stride between heads, 0 for shared_head                   */
+    const uint8_t *idq, *idk, *idv;       /* (NP, NP) query-major bucket ids: idk[i][j] = bucket_k[i][j],
+                                             idv[i][j] = bucket_v[i][j], idq[i][j] = bucket_q[j][i]      */
+    const uint8_t *idq_t, *idk_t, *idv_t; /* the same matrices transposed (key-major), backward only     */
+    int B, H, L, NP, nb;            /* NP = cream_irpe_padded_len(L)                                     */
+    float scale;
+    /* backward only */
+    const void* dout;               /* (B, L, H, 64) bf16                                               */
+    void *dq, *dk, *dv;             /* bf16; element (b, n, h, :) at ptr[b*dsb + n*dsn + h*dsh]          */
+    int64_t dsb, dsn, dsh;
+    float* delta;                   /* (B, H, NP) scratch                                               */
+    void *lkg, *gg;                 /* (B, H, NP, 64) bf16 scratch (needed with wk / wv)                 */
+    void *dlk, *dlq;                /* (B, H, NP, 64) bf16 out: bucket gradients of rpe_k / rpe_q lookups */
+} cream_irpe_attn_desc;
+
+int cream_irpe_padded_len(int L);
+
+/* int32 (Lq, Lk) bucket ids (irpe.py:523-583) -> zero-padded uint8 (NP, NP); transpose != 0 writes
+ * dst[j][i] = ids[i][j].  Done once per (table, device) by the caller. */
+int cream_irpe_bucket_bytes(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose, void* stream);
+
+/* out, lse (and sv) from q, k, v.  One launch. */
+int cream_irpe_attn_fwd(const cream_irpe_attn_desc* d, void* stream);
+
+/* dq, dk, dv and the bucket-gradient rows dlk, dlq from dout (+ out, lse of the forward).  Two launches
+ * (queries own lanes; keys own lanes); no global atomics. */
+int cream_irpe_attn_bwd(const cream_irpe_attn_desc* d, void* stream);
+
+/* Per-(b,h) table gradient  out[b*H+h][a][c] = mul * sum_n X[b,n,h][a] * Y[b,n,h][c]  (64 x 64 fp32):
+ *   d lookup_table_weight(rpe_k) = (scale q)^T dlk, (rpe_q) = (scale k)^T dlq, (rpe_v) = sv^T dout;
+ * the caller sums over b (and h for shared tables).  X, Y bf16 with element strides (sb, sn, sh). */
+int cream_irpe_table_grad(float* out, const void* x, int64_t xsb, int64_t xsn, int64_t xsh, const void* y, int64_t ysb,
+                          int64_t ysn, int64_t ysh, int B, int H, int L, float mul, void* stream);
+
 /* ---- HBM-bound passes of one supernet transformer block ------------------------------------
  * Reference: TransformerEncoderLayer.forward, AutoFormer/model/supernet_transformer.py:251-287
  * (pre-norm block), LayerNormSuper.forward (model/module/layernorm_super.py:26-37), gelu in

@@ -7,8 +7,10 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_pytest_gpu.log 2>&1
+if [ -z "$SKIP_TESTS" ]; then
+timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_pytest_gpu.log 2>&1
 echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
+fi
 timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
@@ -17,11 +19,23 @@ echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
 # counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_|gemm_|ln_|adamw|grad_finalize' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
 done
 cd $REPO
-find $OUT -name '*.csv' | head -20
+# the other measured configurations: config 2 (supernet-T, fixed subnet), config 4 (rpe_index
+# micro-benchmark + one RPEAttention layer), sub-network evaluation, host-side profile of the step
+timeout 300 python bench.py --subnet T --steps 40 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
+echo "config2 exit $?"; cat $OUT/${TAG}_bench_config2.json | cut -c1-400
+timeout 300 python tools/bench_rpe_index.py > $OUT/${TAG}_rpe_index_microbench.jsonl 2> $OUT/${TAG}_rpe_index_microbench.err
+echo "rpe microbench exit $?"; cut -c1-300 $OUT/${TAG}_rpe_index_microbench.jsonl
+timeout 300 python tools/bench_irpe_attention.py > $OUT/${TAG}_irpe_attention.jsonl 2> $OUT/${TAG}_irpe_attention.err
+echo "irpe attention exit $?"; cut -c1-300 $OUT/${TAG}_irpe_attention.jsonl
+timeout 300 python tools/bench_subnet_eval.py > $OUT/${TAG}_subnet_eval.json 2> $OUT/${TAG}_subnet_eval.err
+echo "subnet eval exit $?"; cut -c1-300 $OUT/${TAG}_subnet_eval.json
+timeout 300 python tools/host_profile.py > $OUT/${TAG}_host_profile.txt 2>&1
+echo "host profile exit $?"; head -12 $OUT/${TAG}_host_profile.txt
+find $OUT -name '*.csv' -path "*${TAG}*" | head -20
 # keep the merge small: drop raw traces, keep stats + counter csv
 find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" -delete
 find $OUT -name '*.db' -delete

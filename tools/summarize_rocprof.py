@@ -18,6 +18,10 @@ def short(name):
 def category(k):
     if k.startswith("hipBLASLt GEMM") or "Cijk_" in k:
         return "GEMM library (hipBLASLt)"
+    if "gemm_nt_kernel" in k or "gemm_tn_kernel" in k:
+        return "GEMM (csrc/gemm_mfma.hpp, hand-written MFMA)"
+    if "adamw_mirror" in k:
+        return "optimizer + bf16 operand refresh (csrc/optim.hip)"
     if "attn_rpe2d" in k:
         return "attention (csrc/attn_rpe2d.hip)"
     if re.search(r"(ln_fwd|ln_bwd|gelu_|residual_add|scale_cast|colsum|grad_finalize|rpe_)", k):
