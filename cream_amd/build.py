@@ -40,6 +40,7 @@ def _digest():
     h = hashlib.sha256()
     files = sources() + [os.path.join(INCLUDE, "cream_amd.h")]
     files += sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".h", ".hpp")))
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode()) if 'EXTRA_FLAGS' in globals() else None
     for f in files:
         h.update(f.encode())
         with open(f, "rb") as fh:
@@ -53,6 +54,13 @@ def is_current():
         return False
     with open(STAMP) as fh:
         return fh.read().strip() == _digest()
+
+
+# per-file code generation choices (measured, profiles/r02_irpe_attention.md): kernels that run VALU work on
+# MFMA results every tile (bias gathers, softmax) keep the accumulators in architectural VGPRs — with
+# the default AGPR form the compiler copies every score tile AGPR -> VGPR (240 v_accvgpr moves per
+# iteration in the fused iRPE forward) and the AGPR half of the register file caps occupancy
+EXTRA_FLAGS = {"irpe_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def build(force=False, verbose=False):
@@ -69,6 +77,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         cmd = [hipcc] + HIPCC_FLAGS + [f"-I{INCLUDE}", f"-I{CSRC}", f'-DCREAM_BUILD_TAG="{tag}"',
                                        "-x", "hip" if src.endswith(".hip") else "c++", "-c", src, "-o", obj]
+        cmd[1:1] = EXTRA_FLAGS.get(os.path.basename(src), [])
         if not src.endswith(".hip"):
             # plain host C++: no offload needed (HIP host APIs only)
             cmd = [c for c in cmd if not c.startswith("--offload-arch")]

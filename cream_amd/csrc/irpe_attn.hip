@@ -41,6 +41,8 @@
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "attn_common.hpp"
 #include "cream_amd.h"
 
@@ -149,7 +151,61 @@ __device__ __forceinline__ void lane_ids(uint32_t (&w)[4], const unsigned char* 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) w[rr] = *reinterpret_cast<const uint32_t*>(p + 8 * rr);
 }
-__device__ __forceinline__ int id_of(const uint32_t (&w)[4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+// the staged bytes hold 2 * bucket id: the byte offset of the bucket in a bf16 lookup row
+__device__ __forceinline__ int off2_of(const uint32_t (&w)[4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+// acc += (bf16 at byte offset off2 of row): one v_dot2c_f32_bf16 with (x, 0) . (1, 1) instead of shift + add
+typedef __bf16 hwbf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float add_bf16_at(float acc, const short* row, int off2) {
+    const uint32_t x = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(row) + off2);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hwbf16x2v, x), __builtin_bit_cast(hwbf16x2v, 0x3F803F80u), acc, false);   // (1, 1): a literal — the inline constant 1.0 is not (1, 0) for packed bf16
+}
+
+// row[id_r] += val_r for the 16 (bucket id, value) pairs of this lane — without LDS float atomics
+// (ds_add_f32 retires a few lanes per clock: the kernels were 6x slower with it, profiles/r02_irpe_attention.md).
+// The two lanes that share a row (g = 0 / 1) take turns — the LDS operations of a wave execute in order, so
+// the second half adds onto the first half's sums — and each half goes 8 pairs at a time: 8 reads,
+// duplicates inside the group resolved in registers (the latest earlier match carries the running sum,
+// and the last write to an address is the complete one), 8 writes.
+__device__ __forceinline__ void scatter_add16(float* row, const uint32_t (&w)[4], const f32x16& val, int g) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (g == half) {
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                int id[8];
+                float sum[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    id[v] = off2_of(w, grp * 8 + v);
+                    sum[v] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + 2 * id[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    float base = sum[v];
+#pragma unroll
+                    for (int u = 0; u < v; ++u) base = (id[u] == id[v]) ? sum[u] : base;
+                    sum[v] = base + val[grp * 8 + v];
+                }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) *reinterpret_cast<float*>(reinterpret_cast<char*>(row) + 2 * id[v]) = sum[v];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+}
+
+template <int K> using Slot = std::integral_constant<int, K>;
+constexpr int PF = 1;       // streamed tiles in flight in registers.  Measured at L = 577: 3 in flight cost 48 more VGPRs
+                            // (one workgroup less per CU) and made every kernel slower (fwd 327 -> 424 us) — the loop
+                            // is VALU / LDS bound, not latency bound
+// body(u, Slot<u % PF>) for u = 0 .. n-1
+template <typename Body> __device__ __forceinline__ void stream(int n, Body&& body) {
+    for (int u0 = 0; u0 < n; u0 += PF) {
+        body(u0, Slot<0>{});
+        if constexpr (PF > 1) { if (u0 + 1 < n) body(u0 + 1, Slot<1 % PF>{}); }
+        if constexpr (PF > 2) { if (u0 + 2 < n) body(u0 + 2, Slot<2 % PF>{}); }
+    }
+}
 
 // lookups^T (64 buckets x 32 own rows) = tab(64 buckets x 64 d) . X^T  ->  scr[row][bucket] (bf16) * mul
 __device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, const F (&xb)[4], float mul, int lane) {
@@ -230,13 +286,13 @@ __device__ __forceinline__ f32x16 score_tile(const short* rows, const F (&own)[4
         uint32_t w[4];
         lane_ids(w, own_ids, trow, g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += bf2f(own_row[id_of(w, r)]);
+        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], own_row, off2_of(w, r));
     }
     if constexpr (SIDE) {
         uint32_t w[4];
         lane_ids(w, side_ids, trow, g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += bf2f(side[acc_row(r, g) * LBP + id_of(w, r)]);
+        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], side + acc_row(r, g) * LBP, off2_of(w, r));
     }
     return s;
 }
@@ -381,9 +437,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
             if constexpr (HV) {
                 uint32_t w[4];
                 lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
-                float* row = svw + c32 * LKP;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), s[r]);
+                scatter_add16(svw + c32 * LKP, w, s, g);
             }
         }
         if (more) {
@@ -516,33 +570,36 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
         }
     }
     __syncthreads();                                   // tables consumed: the tile area is free
-    u32x4v sk, sv4, sik = {}, siv = {}, siq = {};
-    sk = rows_load(kp, a.sn, 0, a.L, false);
-    sv4 = rows_load(vp, a.sn, 0, a.L, true);
-    if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
-    if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
-    if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, 0);
-    rows_store(kbuf, sk);
-    rows_store_T(ktbuf, sk);
-    rows_store(vbuf, sv4);
-    if constexpr (HK) ids_store(smem + L::idk, sik);
-    if constexpr (HQ) ids_store(smem + L::idq, siq);
-    if constexpr (HV) ids_store(smem + L::idv, siv);
+    struct Stage { u32x4v k, v, ik, iv, iq; } st[PF];
+    auto issue = [&](Stage& r, int t) {
+        r.k = rows_load(kp, a.sn, t * 32, a.L, false);
+        r.v = rows_load(vp, a.sn, t * 32, a.L, true);
+        if constexpr (HK) r.ik = ids_load(a.idk, a.NP, q0, t);
+        if constexpr (HQ) r.iq = ids_load(a.idq, a.NP, q0, t);
+        if constexpr (HV) r.iv = ids_load(a.idv, a.NP, q0, t);
+    };
+    auto commit = [&](const Stage& r, int t) {
+        const int buf = t & 1;
+        rows_store(kbuf + buf * 32 * KP, r.k);
+        rows_store_T(ktbuf + buf * 64 * VTP, r.k);
+        rows_store(vbuf + buf * 32 * KP, r.v);
+        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
+        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, r.iq);
+        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, r.iv);
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+        if (t < NT) issue(st[t], t);
+    commit(st[0], 0);
     __syncthreads();
     if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
 
     // ---- key tiles ----------------------------------------------------------------------------------
     f32x16 dq[2] = {f32x16{}, f32x16{}};
-    for (int t = 0; t < NT; ++t) {
+    stream(NT, [&](int t, auto slot) {
+        constexpr int K = decltype(slot)::value;
         const int cur = t & 1, nxt = cur ^ 1;
-        const bool more = t + 1 < NT;
-        if (more) {
-            sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
-            sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
-            if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
-            if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
-            if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
-        }
+        if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
             f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
                                           smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
@@ -555,7 +612,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
                 lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
                 const short* row = glw + c32 * LBP;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] += bf2f(row[id_of(w, r)]);
+                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], row, off2_of(w, r));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -566,9 +623,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
             if constexpr (HK) {
                 uint32_t w[4];
                 lane_ids(w, smem + L::idk + cur * 128 * IDP, qrow, g);
-                float* row = dlkw + c32 * LKP;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), s[r]);
+                scatter_add16(dlkw + c32 * LKP, w, s, g);
             }
             const short* ktb = ktbuf + cur * 64 * VTP;
 #pragma unroll
@@ -578,17 +633,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
                 dq[1] = TT::mma(TT::load_perm(ktb + (c32 + 32) * VTP, s2, g), db, dq[1]);
             }
         }
-        if (more) {
-            rows_store(kbuf + nxt * 32 * KP, sk);
-            rows_store_T(ktbuf + nxt * 64 * VTP, sk);
-            rows_store(vbuf + nxt * 32 * KP, sv4);
-            if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
-            if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
-            if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
+        if (t + 1 < NT) {
+            commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
             if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
         }
-    }
+    });
 
     // ---- dq += dLK Wk^T; bucket gradient rows out -------------------------------------------------
     if constexpr (HK) {
@@ -687,37 +737,40 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
         }
     }
     __syncthreads();
-    u32x4v sq, sdo, slk = {}, sg = {}, sik = {}, siv = {}, siq = {};
-    auto load_tile = [&](int t) {
-        sq = scaled_raw(rows_load(qp, a.sn, t * 32, a.L, false), a.scale);
-        sdo = rows_load(dop, orow, t * 32, a.L, true);
-        if constexpr (HK) slk = rows_load(lkg, 64, t * 32, a.NP, false);
-        if constexpr (HV) sg = rows_load(gg, 64, t * 32, a.NP, false);
-        if constexpr (HK) sik = ids_load(a.idk_t, a.NP, k0, t);
-        if constexpr (HQ) siq = ids_load(a.idq_t, a.NP, k0, t);
-        if constexpr (HV) siv = ids_load(a.idv_t, a.NP, k0, t);
+    struct Stage { u32x4v q, dout, lk, gl, ik, iv, iq; } st[PF];
+    auto issue = [&](Stage& r, int t) {
+        r.q = scaled_raw(rows_load(qp, a.sn, t * 32, a.L, false), a.scale);
+        r.dout = rows_load(dop, orow, t * 32, a.L, true);
+        if constexpr (HK) r.lk = rows_load(lkg, 64, t * 32, a.NP, false);
+        if constexpr (HV) r.gl = rows_load(gg, 64, t * 32, a.NP, false);
+        if constexpr (HK) r.ik = ids_load(a.idk_t, a.NP, k0, t);
+        if constexpr (HQ) r.iq = ids_load(a.idq_t, a.NP, k0, t);
+        if constexpr (HV) r.iv = ids_load(a.idv_t, a.NP, k0, t);
     };
-    auto store_tile = [&](int buf) {
-        rows_store(qbuf + buf * 32 * KP, sq);
-        rows_store_T(qtbuf + buf * 64 * VTP, sq);
-        rows_store(dobuf + buf * 32 * KP, sdo);
-        rows_store_T(dotbuf + buf * 64 * VTP, sdo);
-        if constexpr (HK) lrows_store(lkt + buf * 32 * LBP, slk);
-        if constexpr (HV) lrows_store(gt + buf * 32 * LBP, sg);
-        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, sik);
-        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, siq);
-        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, siv);
+    auto commit = [&](const Stage& r, int t) {
+        const int buf = t & 1;
+        rows_store(qbuf + buf * 32 * KP, r.q);
+        rows_store_T(qtbuf + buf * 64 * VTP, r.q);
+        rows_store(dobuf + buf * 32 * KP, r.dout);
+        rows_store_T(dotbuf + buf * 64 * VTP, r.dout);
+        if constexpr (HK) lrows_store(lkt + buf * 32 * LBP, r.lk);
+        if constexpr (HV) lrows_store(gt + buf * 32 * LBP, r.gl);
+        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
+        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, r.iq);
+        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, r.iv);
     };
-    load_tile(0);
-    store_tile(0);
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+        if (t < NT) issue(st[t], t);
+    commit(st[0], 0);
     __syncthreads();
 
     // ---- query tiles --------------------------------------------------------------------------------
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
-    for (int t = 0; t < NT; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        const bool more = t + 1 < NT;
-        if (more) load_tile(t + 1);
+    stream(NT, [&](int t, auto slot) {
+        constexpr int K = decltype(slot)::value;
+        const int cur = t & 1;
+        if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
             // rows = queries of the tile, column = own key: own lookups = rpe_q, side lookups = rpe_k
             f32x16 s = score_tile<HQ, HK>(qbuf + cur * 32 * KP, kf, smem + L::idq + cur * 128 * IDP,
@@ -731,7 +784,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
                 lane_ids(w, smem + L::idv + cur * 128 * IDP, krow, g);
                 const short* side = gt + cur * 32 * LBP;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] += bf2f(side[acc_row(r, g) * LBP + id_of(w, r)]);
+                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], side + acc_row(r, g) * LBP, off2_of(w, r));
             }
             f32x16 ds;
 #pragma unroll
@@ -749,9 +802,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
             if constexpr (HQ) {
                 uint32_t w[4];
                 lane_ids(w, smem + L::idq + cur * 128 * IDP, krow, g);
-                float* row = dlqw + c32 * LKP;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(row + id_of(w, r), ds[r]);
+                scatter_add16(dlqw + c32 * LKP, w, ds, g);
             }
             const short* dot = dotbuf + cur * 64 * VTP;
             const short* qtb = qtbuf + cur * 64 * VTP;
@@ -765,11 +816,11 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
                 dk[1] = TT::mma(TT::load_perm(qtb + (c32 + 32) * VTP, s2, g), sb, dk[1]);
             }
         }
-        if (more) {
-            store_tile(nxt);
+        if (t + 1 < NT) {
+            commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
         }
-    }
+    });
 
     // ---- dk += s dLQ Wq^T; bucket gradient rows out ------------------------------------------------
     if constexpr (HQ) {
@@ -842,14 +893,14 @@ __global__ __launch_bounds__(256) void irpe_table_grad_kernel(const TgArgs a) {
     for (int r = 0; r < 16; ++r) o[(ta * 32 + acc_row(r, g)) * 64 + tc * 32 + c32] = acc[r] * a.mul;
 }
 
-// int32 (Lq x Lk) bucket ids -> zero-padded uint8 (NP x NP), optionally transposed
+// int32 (Lq x Lk) bucket ids -> zero-padded uint8 (NP x NP) holding 2 * id, optionally transposed
 __global__ void bucket_bytes_kernel(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= NP) return;
     int v = 0;
     if (!transpose) { if (i < Lq && j < Lk) v = ids[(int64_t)i * Lk + j]; }
     else            { if (j < Lq && i < Lk) v = ids[(int64_t)j * Lk + i]; }
-    dst[(int64_t)i * NP + j] = (uint8_t)v;
+    dst[(int64_t)i * NP + j] = (uint8_t)(2 * v);      // byte offset of the bucket in a bf16 lookup row
 }
 
 template <typename K>

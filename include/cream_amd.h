@@ -162,8 +162,8 @@ typedef struct cream_irpe_attn_desc {
 
 int cream_irpe_padded_len(int L);
 
-/* int32 (Lq, Lk) bucket ids (irpe.py:523-583) -> zero-padded uint8 (NP, NP); transpose != 0 writes
- * dst[j][i] = ids[i][j].  Done once per (table, device) by the caller. */
+/* int32 (Lq, Lk) bucket ids (irpe.py:523-583) -> zero-padded uint8 (NP, NP) holding 2 * id (the byte
+ * offset of the bucket in a bf16 lookup row; ids < 64); transpose != 0 writes dst[j][i] = 2 * ids[i][j].  Done once per (table, device) by the caller. */
 int cream_irpe_bucket_bytes(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose, void* stream);
 
 /* out, lse (and sv) from q, k, v.  One launch. */

@@ -39,7 +39,7 @@ for rpe_on in ("k", "qkv"):
             step()
         torch.cuda.synchronize()
         timing.reset()
-        timing.enable(True, only=("rpe_index_fwd", "rpe_index_bwd"))
+        timing.enable(True, only=("rpe_index_fwd", "rpe_index_bwd", "irpe_attn_fwd", "irpe_attn_bwd"))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 10
         a.record()
@@ -53,6 +53,7 @@ for rpe_on in ("k", "qkv"):
                    dtype=str(dtype).split(".")[-1], ms_per_fwd_bwd=round(a.elapsed_time(b) / n, 3),
                    kernels={k: dict(launches=v["launches"], avg_us=round(v["avg_ms"] * 1e3, 1),
                                     total_ms_per_iter=round(v["total_ms"] / n, 3),
-                                    GBps=round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
+                                    GBps=round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None,
+                                    TFLOPs=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v.get("flops") else None)
                             for k, v in sorted(ks.items())})
         print(json.dumps(rec), flush=True)

@@ -1,3 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_irpe_fused_gpu.py -q -s 2>&1 | tail -30 | cut -c1-400
+timeout 900 python -m pytest tests/test_irpe_fused_gpu.py tests/test_irpe_gpu.py -q -s 2>&1 | grep "fused irpe\|passed\|failed" | grep -v print | cut -c1-300
+timeout 300 python tools/bench_irpe_attention.py 2>/dev/null | grep bfloat16 | python -c "
+import sys, json
+for l in sys.stdin:
+    d=json.loads(l); print(d['workload'][-10:], d['ms_per_fwd_bwd'], {k:(v['avg_us'], v['TFLOPs']) for k,v in d['kernels'].items()})"
