@@ -24,6 +24,8 @@ Extra objects on the line:
   cpu_baseline  — the oracle (CPU fp32 restatement of the reference step, oracle/) timed on this box's
                   host cores on a bounded sample: best of several thread counts (rank 0, N=1 only),
                   CPU model stated; plus the iRPE pure-PyTorch path at config-4 shapes (B = 2).
+  irpe_config4  — BASELINE config 4 on the device: one RPEAttention layer (DeiT-B-384 + iRPE, L = 577) fwd+bwd
+                  through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only).
 `--subnet T|S` benchmarks ONE fixed published sub-network instead of random sampling (BASELINE
 config 2: AutoFormer-T subnet, bf16, batch 128).
 """
@@ -187,26 +189,63 @@ def cpu_baseline_subprocess(size, seconds, threads=0, irpe=False):
 
 def pmc_traffic(region):
     """HBM bytes per launch of a timed region from the committed rocprofv3 PMC passes
-    (profiles/*_attention_pmc.json: FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md + WRITE_SIZE), averaged over the head counts of the search space.  PMC
-    counters cannot be read from inside this process, so the number is the one measured by
-    tools/gpu_round.sh for the same kernels; None if no such file is committed."""
+    (profiles/*_kernels_pmc.json, written by tools/summarize_pmc.py: FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md + WRITE_SIZE, mean over the launches of the sampled
+    sub-networks).  PMC counters cannot be read from inside this process, so the number is the one
+    measured by tools/gpu_round.sh for the same kernels; None if no such file is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_attention_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernels_pmc.json")))
     if not files:
         return None, None
     rec = json.load(open(files[-1]))
-    want = {"attn_rpe2d_fwd": ("attn_rpe2d_fwd_kernel",),
-            "attn_rpe2d_bwd": ("attn_rpe2d_bwd_q_kernel", "attn_rpe2d_bwd_kv_kernel")}.get(region)
-    if not want:
-        return None, None
-    per_h = {}
-    for k in rec["kernels"]:
-        if k["kernel"] in want:
-            per_h[k["H"]] = per_h.get(k["H"], 0.0) + (k["hbm_read_MB_corrected"] + k["hbm_write_MB"]) * 1e6
-    if not per_h:
-        return None, None
-    return int(sum(per_h.values()) / len(per_h)), os.path.relpath(files[-1], ROOT)
+    val = rec.get("traffic_bytes_per_launch_by_timed_region", {}).get(region)
+    return (val, os.path.relpath(files[-1], ROOT)) if val else (None, None)
+
+
+def irpe_config4_leg(iters=10):
+    """BASELINE config 4 on the device: ONE RPEAttention layer of DeiT-B-384 with iRPE
+    product / contextual (B = 64, H = 12, L = 577, 50 buckets) forward + backward under bf16 autocast —
+    the fused kernels of csrc/irpe_attn.hip — for rpe on keys and on q, k and v; ms per layer and the
+    kernels' share (HIP events on the launch stream)."""
+    from cream_amd.irpe import get_rpe_config
+    from cream_amd.rpe_attention import RPEAttention
+    dev = torch.device("cuda")
+    B, L, C, H = 64, 577, 768, 12
+    out = {}
+    for rpe_on in ("k", "qkv"):
+        torch.manual_seed(0)
+        cfg = get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on=rpe_on)
+        m = RPEAttention(C, num_heads=H, qkv_bias=True, rpe_config=cfg).to(dev)
+        x = torch.randn(B, L, C, device=dev, requires_grad=True)
+        g = torch.randn(B, L, C, device=dev)
+
+        def step():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            y.backward(g)
+            x.grad = None
+            for p in m.parameters():
+                p.grad = None
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        timing.reset()
+        timing.enable(True, only=("irpe_attn_fwd", "irpe_attn_bwd"))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            step()
+        b.record()
+        torch.cuda.synchronize()
+        timing.enable(False)
+        ks = timing.summary()
+        out[rpe_on] = dict(ms_per_layer_fwd_bwd=round(a.elapsed_time(b) / iters, 3),
+                           kernels={k: dict(avg_us=round(v["avg_ms"] * 1e3, 1),
+                                            tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)) for k, v in sorted(ks.items())})
+        del m, x, g
+    timing.reset()
+    return dict(workload="RPEAttention layer fwd+bwd, DeiT-B-384 iRPE product-ctx, B=64 H=12 L=577, bf16 autocast", **out)
 
 
 def main():
@@ -324,7 +363,7 @@ def main():
                             frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
             roof["traffic"], src = pmc_traffic(name) if a.supernet == "S" else (None, None)   # counters were taken on S shapes
             if src:
-                roof["traffic_unit"] = "bytes per launch (mean over H=5,6,7), rocprofv3 PMC pass: " + src
+                roof["traffic_unit"] = "HBM bytes per launch (mean over the sampled sub-networks), rocprofv3 PMC pass: " + src
             roof["launches"] = st["launches"]
             roof["avg_us"] = round(st["avg_ms"] * 1e3, 2)
             roof["timing"] = "separate pass: HIP events around every launch in an op-by-op run right after the timed region"
@@ -357,6 +396,11 @@ def main():
             "parity_unpinned": "AdamW parameter-group rule, soft-target CE, Mixup (timm, not vendored in the reference)",
             "cpu_baseline": cpu,
         }
+        if world == 1 and a.supernet == "S" and not a.subnet and not a.no_kernel_timing and a.dtype == "bf16":
+            try:                                   # after and outside the timed region; must not lose the line
+                line["irpe_config4"] = irpe_config4_leg()
+            except Exception as e:
+                sys.stderr.write(f"[bench] iRPE config-4 leg failed: {e}\n")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

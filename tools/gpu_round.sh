@@ -25,7 +25,7 @@ done
 cd $REPO
 # the other measured configurations: config 2 (supernet-T, fixed subnet), config 4 (rpe_index
 # micro-benchmark + one RPEAttention layer), sub-network evaluation, host-side profile of the step
-timeout 300 python bench.py --subnet T --steps 40 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
+timeout 300 python bench.py --supernet T --subnet T --steps 40 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
 echo "config2 exit $?"; cat $OUT/${TAG}_bench_config2.json | cut -c1-400
 timeout 300 python tools/bench_rpe_index.py > $OUT/${TAG}_rpe_index_microbench.jsonl 2> $OUT/${TAG}_rpe_index_microbench.err
 echo "rpe microbench exit $?"; cut -c1-300 $OUT/${TAG}_rpe_index_microbench.jsonl

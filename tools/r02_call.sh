@@ -1,6 +1,4 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_irpe_fused_gpu.py tests/test_irpe_gpu.py -q -s 2>&1 | grep "fused irpe\|passed\|failed" | grep -v print | cut -c1-300
-timeout 300 python tools/bench_irpe_attention.py 2>/dev/null | grep bfloat16 | python -c "
-import sys, json
-for l in sys.stdin:
-    d=json.loads(l); print(d['workload'][-10:], d['ms_per_fwd_bwd'], {k:(v['avg_us'], v['TFLOPs']) for k,v in d['kernels'].items()})"
+for rep in 1 2 3; do for S in 512 256 384; do
+CREAM_WGRAD_SLOTS=$S timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-kernel-timing 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('slots $S', d['value'], d['ms_per_step'])"
+done; done
