@@ -454,6 +454,109 @@ class BlockOperands:
 _OPS_KEY = '_cream_operands'
 
 
+class PatchOperands:
+    """bf16 operand copy of the patch-embedding weight viewed as (E_super, C*ph*pw) and of its bias — the
+    stem's projection runs on the same NT / TN GEMMs as the block projections (embedding_super.py:27-40 is
+    a stride = kernel convolution, i.e. a GEMM over unfolded patches)."""
+
+    def __init__(self, pe):
+        self.mod = pe.proj
+        wt = pe.proj.weight
+        bf = dict(dtype=torch.bfloat16, device=wt.device)
+        self.w = torch.empty((wt.shape[0], wt.numel() // wt.shape[0]), **bf)
+        self.b = torch.empty((wt.shape[0],), **bf)
+        self.key = self._key()
+        self.versions = None
+        self._table = None
+
+    def _key(self):
+        return (self.mod.weight.data_ptr(),)
+
+    def jobs(self, grads=False, states=None, weight_decay=0.0):
+        m = self.mod
+        out = []
+        for prm, mir in ((m.weight, self.w), (m.bias, self.b)):
+            st = states[prm] if states else (None, None)
+            view = prm.detach().view(self.w.shape) if prm is m.weight else prm.detach()
+            grad = (prm.grad.view(self.w.shape) if prm is m.weight else prm.grad) if grads else None
+            stv = tuple(t.view(view.shape) if t is not None else None for t in st)
+            out.append((prm, param_job(view, grad, stv[0], stv[1], mir, None, weight_decay=weight_decay)))
+        return out
+
+    def refresh(self):
+        if self._table is None:
+            self._table = JobTable([j for _, j in self.jobs()], self.w.device)
+        self._table.launch(update=False)
+        self.mark_fresh()
+
+    def mark_fresh(self):
+        self.versions = (self.mod.weight._version, self.mod.bias._version)
+
+    def stale(self):
+        return self.versions != (self.mod.weight._version, self.mod.bias._version)
+
+
+def patch_operands(pe, fresh=True):
+    ops = pe.__dict__.get(_OPS_KEY)
+    if ops is None or ops.key != ops._key():
+        ops = pe.__dict__[_OPS_KEY] = PatchOperands(pe)
+    if fresh and ops.stale():
+        ops.refresh()
+    return ops
+
+
+class PatchEmbedFunction(torch.autograd.Function):
+    """y (B*P, E) = patches (B*P, K) . W[:E]^T + b[:E] on the own GEMMs; backward = the split-K TN product
+    (weight and bias gradient in one launch) added into the active rows of the conv weight's gradient.  The
+    images need no gradient."""
+
+    @staticmethod
+    def forward(ctx, patches, weight, bias, pe, E):
+        ops = patch_operands(pe)
+        K = ops.w.shape[1]
+        y = linear_fwd(patches, ops.w, ops.b, E, K)
+        ctx.save_for_backward(patches)
+        ctx.pe, ctx.E, ctx.K = pe, E, K
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        pe, E, K = ctx.pe, ctx.E, ctx.K
+        dy = dy.to(torch.bfloat16).contiguous()
+        parts, bparts = linear_wgrad_parts(dy, patches, want_bias=True)
+        w = pe.proj.weight
+        gw = parts.sum(0).view(E, *w.shape[1:])
+        gb = bparts.sum(0)
+        return None, _pad_rows(gw, w.shape[0]), _pad_rows(gb, w.shape[0]), None, None
+
+
+def _pad_rows(g, rows):
+    if g.shape[0] == rows:
+        return g
+    out = g.new_zeros((rows,) + tuple(g.shape[1:]))
+    out[:g.shape[0]] = g
+    return out
+
+
+def patch_embed(pe, x):
+    """PatchembedSuper.forward on the device under bf16 autocast (embedding_super.py:27-40)."""
+    B, C, H, W = x.shape
+    ph, pw = pe.patch_size
+    gh, gw = H // ph, W // pw
+    E = pe.sample_embed_dim
+    patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * ph * pw)
+    patches = patches.to(torch.bfloat16)
+    y = PatchEmbedFunction.apply(patches, pe.proj.weight, pe.proj.bias, pe, E)
+    return y.view(B, gh * gw, E)
+
+
+def patch_embed_supported(pe, x):
+    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and not pe.scale and pe.sample_embed_dim % 8 == 0 and pe.proj.bias is not None
+            and (pe.proj.weight.numel() // pe.proj.weight.shape[0]) % 64 == 0)
+
+
 def operands(blk, fresh=True):
     """The block's BlockOperands (created on first use, re-created when the module moved), refreshed
     if a parameter's version counter moved since the copies were written.  The native optimizer

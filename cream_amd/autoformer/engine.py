@@ -113,6 +113,15 @@ class NativeAdamW(torch.optim.Optimizer):
                     j.weight_decay = wd[p]
                     jobs.append(j)
                     done.add(p)
+        for m in self.model.modules():
+            if hasattr(m, 'proj') and hasattr(m, 'patch_size') and hasattr(m, 'sample_embed_dim'):     # PatchembedSuper
+                ops = _block.patch_operands(m, fresh=False)
+                self._ops.append(ops)
+                for p, j in ops.jobs(grads=True, states=states):
+                    if p in wd:
+                        j.weight_decay = wd[p]
+                        jobs.append(j)
+                        done.add(p)
         for p in wd:
             if p not in done:
                 jobs.append(_block.param_job(p.detach(), p.grad, states[p][0], states[p][1], weight_decay=wd[p]))

@@ -243,6 +243,10 @@ class PatchembedSuper(nn.Module):
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
         ph, pw = self.patch_size
         gh, gw = H // ph, W // pw
+        if x.is_cuda:
+            from . import block as _block
+            if _block.patch_embed_supported(self, x):        # own GEMMs (csrc/gemm_mfma.hpp), bf16 autocast
+                return _block.patch_embed(self, x)
         patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
         y = F.linear(patches, self.sampled_weight.reshape(self.sample_embed_dim, -1), self.sampled_bias)
         return y * self.sampled_scale if self.scale else y

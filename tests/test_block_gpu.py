@@ -508,3 +508,30 @@ def test_block_at_bench_batch_matches_oracle(E, H, R):
             continue
         tol = B128_TOL["weights"] if name.endswith("weight") and "norm" not in name else B128_TOL["small"]
         assert errs[name] < tol, (name, errs[name])
+
+
+def test_patch_embedding_on_own_gemms_matches_fp32():
+    """PatchembedSuper under bf16 autocast runs the NT / TN GEMMs of csrc/gemm_mfma.hpp (embedding_super.py:27-40
+    is a stride = kernel convolution = a GEMM over unfolded patches): output, weight and bias gradient against the
+    fp32 module; rows beyond the sampled width receive exactly zero gradient."""
+    from cream_amd import timing
+    from cream_amd.autoformer.modules import PatchembedSuper
+    torch.manual_seed(5)
+    pe = PatchembedSuper(img_size=224, patch_size=16, in_chans=3, embed_dim=448).to(DEV)
+    pe.set_sample_config(384)
+    x = torch.randn(16, 3, 224, 224, device=DEV)
+    gy = torch.randn(16, 196, 384, device=DEV)
+    ref = pe(x)
+    gw_ref, gb_ref = torch.autograd.grad(ref, [pe.proj.weight, pe.proj.bias], gy)
+    timing.reset()
+    timing.enable(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = pe(x)
+    gw, gb = torch.autograd.grad(y, [pe.proj.weight, pe.proj.bias], gy.to(y.dtype))
+    timing.enable(False)
+    assert {"gemm_nt", "gemm_tn_wgrad"} <= set(timing.summary()), "the native GEMMs did not run"
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())      # noqa: E731
+    errs = dict(y=rel(y, ref), gw=rel(gw, gw_ref), gb=rel(gb, gb_ref))
+    print("[patch embed]", errs)
+    assert y.dtype == torch.bfloat16 and errs["y"] < 1e-2 and errs["gw"] < 1e-2 and errs["gb"] < 1e-2
+    assert float(gw[384:].abs().max()) == 0.0 and float(gb[384:].abs().max()) == 0.0
