@@ -38,6 +38,13 @@ SIGNATURES = {
     "cream_rpe_index_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cream_rpe_index_fwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "cream_rpe_index_bwd_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "cream_im2patch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cream_stem_assemble": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "cream_stem_bwd_chunks": (_i, [_i]),
+    "cream_stem_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cream_tail_chunks": (_i, [_i]),
+    "cream_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "cream_tail_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cream_irpe_padded_len": (_i, [_i]),
     "cream_irpe_bucket_bytes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_irpe_attn_fwd": (_i, [_vp, _vp]),

@@ -539,6 +539,79 @@ def _pad_rows(g, rows):
     return out
 
 
+class StemFunction(torch.autograd.Function):
+    """img (B, C, H, W) fp32 -> x0 (B, N, E) fp32, the input of the first block: patch embedding on the own
+    GEMMs + class token + position embedding (supernet_transformer.py:147-155) in three launches
+    (cream_im2patch, NT GEMM, cream_stem_assemble); backward in three (cream_stem_bwd, TN GEMM, one sum)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, cls, pos, pe, E):
+        lib = _lib.load()
+        B, C, H, W = img.shape
+        ph, pw = pe.patch_size
+        P = (H // ph) * (W // pw)
+        N = P + 1
+        dev = img.device
+        ops = patch_operands(pe)
+        K = ops.w.shape[1]
+        img = img.contiguous()
+        patches = torch.empty((B * P, K), dtype=torch.bfloat16, device=dev)
+        stream = _stream()
+        _lib.check(lib.cream_im2patch(_p(patches), _p(img), B, C, H, W, ph, pw, stream), "cream_im2patch")
+        y = linear_fwd(patches, ops.w, ops.b, E, K)
+        x0 = torch.empty((B, N, E), dtype=torch.float32, device=dev)
+        cls_e = cls.detach().reshape(-1)[:E].contiguous()
+        _lib.check(lib.cream_stem_assemble(_p(x0), _p(y), _p(cls_e), _p(pos) if pos is not None else ctypes.c_void_p(0),
+                                           pos.shape[-1] if pos is not None else 0, B, N, E, stream), "cream_stem_assemble")
+        ctx.save_for_backward(patches)
+        ctx.pe, ctx.E, ctx.K, ctx.dims = pe, E, K, (B, N)
+        ctx.shapes = (tuple(weight.shape), tuple(bias.shape), tuple(cls.shape), tuple(pos.shape) if pos is not None else None)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (patches,) = ctx.saved_tensors
+        lib = _lib.load()
+        E, K = ctx.E, ctx.K
+        B, N = ctx.dims
+        dev = dx0.device
+        dx0 = dx0.contiguous()
+        dy = torch.empty((B * (N - 1), E), dtype=torch.bfloat16, device=dev)
+        psum = torch.empty((lib.cream_stem_bwd_chunks(B), N, E), dtype=torch.float32, device=dev)
+        _lib.check(lib.cream_stem_bwd(_p(dy), _p(psum), _p(dx0), B, N, E, _stream()), "cream_stem_bwd")
+        parts, bparts = linear_wgrad_parts(dy, patches, want_bias=True)
+        wshape, bshape, cshape, pshape = ctx.shapes
+        gw = torch.zeros((wshape[0], K), dtype=torch.float32, device=dev)
+        gb = torch.zeros(bshape, dtype=torch.float32, device=dev)
+        torch.sum(parts, dim=0, out=gw[:E])
+        torch.sum(bparts, dim=0, out=gb[:E])
+        tok = psum.sum(0)                                            # (N, E): sum of dx0 over the batch
+        gcls = torch.zeros(cshape, dtype=torch.float32, device=dev)
+        gcls.view(-1)[:E] = tok[0]
+        gpos = None
+        if pshape is not None:
+            gpos = torch.zeros(pshape, dtype=torch.float32, device=dev)
+            gpos.view(N, pshape[-1])[:, :E] = tok
+        return None, gw.view(wshape), gb, gcls, gpos, None, None
+
+
+def stem_supported(model, x):
+    pe = model.patch_embed_super
+    E = model.sample_embed_dim[0]
+    pos = model.pos_embed if model.abs_pos else None
+    if not (patch_embed_supported(pe, x) and x.dtype == torch.float32 and pe.patch_size[1] % 8 == 0 and E % 4 == 0):
+        return False
+    if pos is not None and (pos.shape[0] != 1 or pos.shape[-1] % 4 or pos.dtype != torch.float32):
+        return False
+    return not (model.training and (model.sample_dropout or 0.0) > 0.0)
+
+
+def stem(model, x):
+    pe = model.patch_embed_super
+    pos = model.pos_embed if model.abs_pos else None
+    return StemFunction.apply(x, pe.proj.weight, pe.proj.bias, model.cls_token, pos, pe, model.sample_embed_dim[0])
+
+
 def patch_embed(pe, x):
     """PatchembedSuper.forward on the device under bf16 autocast (embedding_super.py:27-40)."""
     B, C, H, W = x.shape
@@ -810,9 +883,16 @@ class StackFunction(torch.autograd.Function):
     otherwise the same kernels are driven op by op from here (`_block_forward/_block_backward`)."""
 
     @staticmethod
-    def forward(ctx, x, scales, blks):
+    def forward(ctx, x, scales, blks, *tail_args):
+        """With tail_w / tail_b (the final LayerNorm's SUPER parameters) the node also covers the end of
+        forward_features (supernet_transformer.py:166-170): returns mean over tokens 1.. of LayerNorm(x) as
+        (B, E) fp32 — the last block's output is consumed pending, never materialised (native driver only)."""
+        tail_w, tail_b, tail_eps = (tuple(tail_args) + (None, None, 1e-5)[len(tail_args):])[:3]
+        ctx.ntail = len(tail_args)
+        ctx.tail = tail_w is not None
         if NATIVE_BLOCK:
-            return StackFunction._forward_native(ctx, x, scales, blks)
+            return StackFunction._forward_native(ctx, x, scales, blks, tail_w, tail_b, tail_eps)
+        assert tail_w is None, "the fused tail needs the native block driver"
         B, N, E = x.shape
         M = B * N
         cur = x.contiguous().view(M, E)
@@ -835,7 +915,7 @@ class StackFunction(torch.autograd.Function):
         return out.view(B, N, E)
 
     @staticmethod
-    def _forward_native(ctx, x, scales, blks):
+    def _forward_native(ctx, x, scales, blks, tail_w=None, tail_b=None, tail_eps=1e-5):
         B, N, E = x.shape
         lib = _lib.load()
         x = x.contiguous()
@@ -855,14 +935,27 @@ class StackFunction(torch.autograd.Function):
             descs.append(d)
             wss.append(ws)
             cur, pend_f, pend_s = wp + off_x1, wp + off_f, (sc_ptr + (2 * i + 1) * B * 4 if sc_ptr else 0)
-        out = torch.empty((B, N, E), dtype=torch.float32, device=dev)
-        _lib.check(lib.cream_residual_add(out.data_ptr(), cur, pend_f, pend_s, B * N * E, N * E, stream), "cream_residual_add")
         ctx.native = True
         ctx.blks = list(blks)
         ctx.descs = descs
         ctx.xptrs = xptrs
         ctx.shape = (B, N, E)
         ctx.has_scales = scales is not None
+        if tail_w is not None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            pooled, xm = torch.empty((B, E), **f32), torch.empty((B, E), **f32)
+            stats = torch.empty((2, B * N), **f32)
+            part = torch.empty((B, lib.cream_tail_chunks(N), E), **f32)
+            gamma, beta = tail_w.detach()[:E].contiguous(), tail_b.detach()[:E].contiguous()
+            _lib.check(lib.cream_tail_fwd(pooled.data_ptr(), xm.data_ptr(), part.data_ptr(), stats[0].data_ptr(),
+                                          stats[1].data_ptr(), cur, pend_f, pend_s, gamma.data_ptr(), beta.data_ptr(), B, N, E,
+                                          tail_eps, stream), "cream_tail_fwd")
+            ctx.tail_ptrs = (cur, pend_f, pend_s)
+            ctx.tail_shapes = (tuple(tail_w.shape), tuple(tail_b.shape))
+            ctx.save_for_backward(x, *wss, *([scales] if scales is not None else []), xm, stats, gamma)
+            return pooled
+        out = torch.empty((B, N, E), dtype=torch.float32, device=dev)
+        _lib.check(lib.cream_residual_add(out.data_ptr(), cur, pend_f, pend_s, B * N * E, N * E, stream), "cream_residual_add")
         ctx.save_for_backward(x, *wss, *([scales] if scales is not None else []))
         return out
 
@@ -886,12 +979,15 @@ class StackFunction(torch.autograd.Function):
             dx, df, pb2 = _block_backward(blks[i], ctx.dims[i], dp1, tens[i * ns:(i + 1) * ns], dx, df, pb2,
                                           prev_scale, i > 0)
         join_side_stream(dx.device)           # every parameter gradient of the run is complete
-        return dx.view(B, N, E), None, None
+        return (dx.view(B, N, E), None, None) + (None, None, None)[:ctx.ntail]
 
     @staticmethod
     def _backward_native(ctx, dout):
         blks = ctx.blks
         tens = ctx.saved_tensors
+        tail = None
+        if ctx.tail:
+            tens, tail = tens[:-3], tens[-3:]
         scales = tens[-1] if ctx.has_scales else None
         wss = tens[1:1 + len(blks)]
         B, N, E = ctx.shape
@@ -906,8 +1002,26 @@ class StackFunction(torch.autograd.Function):
             side_st, side = None, stream
         sc_ptr = scales.data_ptr() if scales is not None else 0
         L = len(blks)
-        dx_t = dout.contiguous().view(M, E)
-        df_t, part = scale_cast_colsum(dx_t, scales[L - 1, 1] if scales is not None else None, N)
+        tail_grads = (None, None)
+        if tail is not None:
+            xm, stats, gamma = tail
+            g = dout.contiguous().float()
+            dx_t = torch.empty((M, E), dtype=torch.float32, device=dev)
+            df_t = torch.empty((M, E), dtype=torch.bfloat16, device=dev)
+            part = torch.empty((lib.cream_ln_partials(), E), dtype=torch.float32, device=dev)
+            x1p, fp, sp = ctx.tail_ptrs
+            _lib.check(lib.cream_tail_bwd(dx_t.data_ptr(), df_t.data_ptr(), part.data_ptr(), g.data_ptr(), x1p, fp,
+                                          stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), sp, B, N, E, stream),
+                       "cream_tail_bwd")
+            wshape, bshape = ctx.tail_shapes
+            gw = torch.zeros(wshape, dtype=torch.float32, device=dev)
+            gb = torch.zeros(bshape, dtype=torch.float32, device=dev)
+            torch.sum(g * xm, dim=0, out=gw[:E])
+            torch.sum(g, dim=0, out=gb[:E])
+            tail_grads = (gw, gb)
+        else:
+            dx_t = dout.contiguous().view(M, E)
+            df_t, part = scale_cast_colsum(dx_t, scales[L - 1, 1] if scales is not None else None, N)
         keep = [dx_t, df_t, part]
         dx, df, pb2, pb2_parts, pb2_stride = dx_t.data_ptr(), df_t.data_ptr(), part.data_ptr(), part.shape[0], E
         ws = None
@@ -934,7 +1048,7 @@ class StackFunction(torch.autograd.Function):
             pb2, pb2_parts, pb2_stride = wp + off_pl1 + 2 * E * 4, lib.cream_ln_partials(), 3 * E
         join_side_stream(dev)                 # every parameter gradient of the run is complete
         out = ws[off_dx:off_dx + M * E * 4].view(torch.float32).view(B, N, E)
-        return out, None, None
+        return (out, None, None) + (tail_grads[0], tail_grads[1], None)[:ctx.ntail]
 
 
 class BlockFunction:
@@ -947,4 +1061,4 @@ class BlockFunction:
         if dp1 is not None or dp2 is not None:
             ones = torch.ones(x.shape[0], device=x.device, dtype=torch.float32)
             scales = torch.stack([dp1 if dp1 is not None else ones, dp2 if dp2 is not None else ones]).unsqueeze(0)
-        return StackFunction.apply(x, scales, [blk])
+        return StackFunction.apply(x, scales, [blk], None, None, 1e-5)

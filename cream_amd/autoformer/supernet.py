@@ -11,6 +11,8 @@ Semantics kept from the reference:
   * gp=True: mean over tokens 1.. AFTER the final LayerNorm (:161-165).
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -154,6 +156,9 @@ class TransformerEncoderLayer(nn.Module):
                 self.ffn_layer_norm.get_complexity(n) + self.fc1.get_complexity(n) + self.fc2.get_complexity(n))
 
 
+NATIVE_ENDS = os.environ.get('CREAM_NATIVE_ENDS', '1') != '0'     # stem / tail of forward_features on csrc/stem_tail.hip (bf16 mode)
+
+
 class Vision_TransformerSuper(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
@@ -275,12 +280,16 @@ class Vision_TransformerSuper(nn.Module):
     def forward_features(self, x):
         B = x.shape[0]
         E = self.sample_embed_dim[0]
-        x = self.patch_embed_super(x)
-        cls = self.cls_token[..., :E].expand(B, -1, -1)
-        x = torch.cat((cls, x), dim=1)        # promotes like the reference (fp32 stream under autocast)
-        if self.abs_pos:
-            x = x + self.pos_embed[..., :E]
-        x = F.dropout(x, p=self.sample_dropout, training=self.training)
+        if x.is_cuda and NATIVE_ENDS and _block.stem_supported(self, x):
+            # bf16 throughput mode: unfold + GEMM + class token + position embedding in three launches
+            x = _block.stem(self, x)
+        else:
+            x = self.patch_embed_super(x)
+            cls = self.cls_token[..., :E].expand(B, -1, -1)
+            x = torch.cat((cls, x), dim=1)        # promotes like the reference (fp32 stream under autocast)
+            if self.abs_pos:
+                x = x + self.pos_embed[..., :E]
+            x = F.dropout(x, p=self.sample_dropout, training=self.training)
         active = [blk for blk in self.blocks if not blk.is_identity_layer]
         if active and _bf16_autocast(x) and all(b.fused and _block.supported(b, x) for b in active):
             # bf16 throughput mode: the whole run of blocks is ONE autograd node on the HIP kernels
@@ -290,7 +299,11 @@ class Vision_TransformerSuper(nn.Module):
                 # all drop-path draws of this forward in three launches instead of 3 per block
                 keep = self._keep_prob(tuple(probs), x.device)
                 scales = torch.floor(keep + torch.rand(len(active), 2, B, device=x.device)) / keep
-            x = _block.StackFunction.apply(x, scales, active)
+            if (NATIVE_ENDS and _block.NATIVE_BLOCK and self.pre_norm and self.gp and x.shape[1] > 1
+                    and self.norm.weight.dtype == torch.float32 and self.norm.bias is not None):
+                # ... and the final LayerNorm + token mean ride on the same node (the last block's output stays pending)
+                return _block.StackFunction.apply(x, scales, active, self.norm.weight, self.norm.bias, self.norm.eps)
+            x = _block.StackFunction.apply(x, scales, active, None, None, 1e-5)
         else:
             for blk in self.blocks:
                 x = blk(x)

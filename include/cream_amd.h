@@ -132,6 +132,40 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
                          int ldt, int B, int H, int N, int gh, int gw, int mr,
                          float scale, int dtype, void* stream);
 
+/* ---- the two ends of the supernet around the block stack (csrc/stem_tail.hip) --------------------
+ * Reference: Vision_TransformerSuper.forward_features, AutoFormer/model/supernet_transformer.py:147-172
+ * (patch embedding embedding_super.py:27-40, class token + position embedding :150-155, final LayerNorm and
+ * token mean :166-170 for pre_norm / gp models). */
+
+/* patches (B*gh*gw, C*ph*pw) bf16 = unfold(img (B, C, H, W) fp32): the GEMM operand of the stride = kernel conv. */
+int cream_im2patch(void* patches, const float* img, int B, int C, int H, int W, int ph, int pw, void* stream);
+
+/* x0 (B, N, E) fp32: row 0 = cls[:E] + pos[0, :E], row n = y[b, n-1, :] (bf16, (B, N-1, E)) + pos[n, :E];
+ * pos may be NULL (abs_pos off); ld_pos = row stride of the position embedding (its super width). */
+int cream_stem_assemble(float* x0, const void* y, const float* cls, const float* pos, int64_t ld_pos, int B, int N, int E,
+                        void* stream);
+
+/* dy (B, N-1, E) bf16 = dx0[:, 1:, :]; psum (cream_stem_bwd_chunks(B), N, E) fp32 = sums of dx0 over chunks of 16
+ * images (position-embedding / class-token gradient = their sum, fixed order). */
+int cream_stem_bwd_chunks(int B);
+int cream_stem_bwd(void* dy, float* psum, const float* dx0, int B, int N, int E, void* stream);
+
+/* pooled (B, E) fp32 = mean over tokens 1.. of LayerNorm(x1 + sample_scale[b] * f) (f bf16 may be NULL);
+ * also writes xm (B, E) = the token mean before the affine map (-> gamma gradient), mean / rstd (B*N) and
+ * uses part (B, cream_tail_chunks(N), E) as scratch.  Two launches. */
+int cream_tail_chunks(int N);
+int cream_tail_fwd(float* pooled, float* xm, float* part, float* mean, float* rstd, const float* x1, const void* f,
+                   const float* sample_scale, const float* gamma, const float* beta, int B, int N, int E, float eps,
+                   void* stream);
+
+/* Backward of cream_tail_fwd given g = d loss / d pooled (B, E): dx (B*N, E) fp32 residual-stream gradient,
+ * dx_scaled = bf16(sample_scale[b] * dx) (the gradient of f) and partial (cream_ln_partials(), E) = column
+ * sums of dx_scaled (bias gradient of the projection that produced f).  gamma / beta gradients are
+ * sum_b g * xm and sum_b g (caller). */
+int cream_tail_bwd(float* dx, void* dx_scaled, float* partial, const float* g, const float* x1, const void* f,
+                   const float* mean, const float* rstd, const float* gamma, const float* sample_scale, int B, int N,
+                   int E, void* stream);
+
 /* ---- fused attention with iRPE (contextual mode) on queries, keys and values ------------------
  * Reference: RPEAttention.forward (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:68-97) between the
  * qkv and proj linears, with iRPE.forward_rpe_transpose / forward_rpe_no_transpose

@@ -535,3 +535,39 @@ def test_patch_embedding_on_own_gemms_matches_fp32():
     print("[patch embed]", errs)
     assert y.dtype == torch.bfloat16 and errs["y"] < 1e-2 and errs["gw"] < 1e-2 and errs["gb"] < 1e-2
     assert float(gw[384:].abs().max()) == 0.0 and float(gb[384:].abs().max()) == 0.0
+
+
+def test_native_stem_and_tail_match_the_module_path():
+    """forward_features' two ends on csrc/stem_tail.hip (unfold + GEMM + class token + position embedding; final
+    LayerNorm + token mean riding on the block stack's node, supernet_transformer.py:147-172) against the same
+    model with the ends evaluated by the framework: pooled features and every parameter gradient, incl. exactly
+    zero gradient outside the sampled width."""
+    from cream_amd.autoformer import engine, supernet as SN
+    torch.manual_seed(3)
+    model = engine.build_supernet("S", drop_path_rate=0.0).to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[384] * 2, mlp_ratio=[3.5, 4.0], num_heads=[6, 5])
+    model.set_sample_config(cfg)
+    model.train()
+    x = torch.randn(8, 3, 224, 224, device=DEV)
+    gy = torch.randn(8, 384, device=DEV)
+    res = {}
+    for native in (False, True):
+        SN.NATIVE_ENDS = native
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model.forward_features(x)
+        y.backward(gy)
+        names = ["patch_embed_super.proj.weight", "patch_embed_super.proj.bias", "cls_token", "pos_embed", "norm.weight",
+                 "norm.bias", "blocks.0.fc1.weight", "blocks.1.attn.qkv.weight", "blocks.0.attn_layer_norm.weight"]
+        prm = dict(model.named_parameters())
+        res[native] = [y.detach().float().clone()] + [prm[n].grad.detach().clone() for n in names]
+    SN.NATIVE_ENDS = True
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))        # noqa: E731
+    errs = {n: rel(a, b) for n, a, b in zip(["y"] + names, res[True], res[False])}
+    print("[native ends]", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert res[True][0].dtype == torch.float32 and res[True][0].shape == (8, 384)
+    for k, v in errs.items():
+        assert v < 2e-2, (k, v)
+    prm = dict(model.named_parameters())
+    assert float(prm["norm.weight"].grad[384:].abs().max()) == 0.0
+    assert float(prm["pos_embed"].grad[..., 384:].abs().max()) == 0.0 and float(prm["cls_token"].grad[..., 384:].abs().max()) == 0.0
