@@ -25,6 +25,7 @@ gradients are accumulated into `p.grad` directly and announced through the `on_g
 (the gradient reducer starts a block's all-reduce the moment its last gradient exists).
 """
 import ctypes
+import os
 
 import torch
 
@@ -257,6 +258,7 @@ WGRAD_SIDE_STREAM = True
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
+        # (stream priorities were tried — side stream at 0 / main at -1 and the reverse: no change in step time)
         st = _side_streams[device] = torch.cuda.Stream(device=device)
     return st
 
