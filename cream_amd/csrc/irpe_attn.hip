@@ -253,13 +253,28 @@ __device__ __forceinline__ void load_frags(F (&f)[4], const short* row, int g) {
     for (int ks = 0; ks < 4; ++ks) f[ks] = TT::load(row + ks * 16 + g * 8);
 }
 
+// A operand of a product that contracts over the 32 streamed tokens of a ROW-major [32][KP] tile (rows = tokens):
+// MFMA row = column dt*32 + (lane & 31) of the tile, contraction indices in the permuted order of from_acc
+// (acc_row(s2*8 + e, g)): two ds_read_b64_tr_b16 — the transpose happens on the way to the matrix cores, so no
+// transposed copy of the tile is staged (8 conflicting 2-byte LDS stores per thread and tile, and 9 KB per buffer).
+__device__ __forceinline__ F load_perm_tr(const short* rows, int dt, int s2, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int gi = lane & 15, q = lane >> 4;
+    const short* p0 = rows + (16 * s2 + 4 * (q >> 1) + (gi >> 2)) * KP + dt * 32 + 16 * (q & 1) + (gi & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p0)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p0 + 8 * KP)));
+    return F{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
 template <bool HQ, bool HK, bool HV> struct LdsF {
     static constexpr int kbuf = 0;                                   // 2 x [32][KP] bf16
-    static constexpr int vtbuf = kbuf + 2 * 32 * KP * 2;             // 2 x [64][VTP] bf16
-    static constexpr int idk = vtbuf + 2 * 64 * VTP * 2;             // 2 x [128][IDP] bytes
+    static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP] bf16 (read transposed: load_perm_tr)
+    static constexpr int idk = vbuf + 2 * 32 * KP * 2;               // 2 x [128][IDP] bytes
     static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
     static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
     static constexpr int wkT = idq + (HQ ? 2 * 128 * IDP : 0);       // [64 buckets][KP] bf16
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     const short* vp = a.v + base;
 
     short* kbuf = reinterpret_cast<short*>(smem + L::kbuf);
-    short* vtbuf = reinterpret_cast<short*>(smem + L::vtbuf);
+    short* vbuf = reinterpret_cast<short*>(smem + L::vbuf);
     short* wkT = reinterpret_cast<short*>(smem + L::wkT);
     short* wqT = reinterpret_cast<short*>(smem + L::wqT);
     short* wvT = reinterpret_cast<short*>(smem + L::wvT);
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     for (int ks = 0; ks < 4; ++ks) qs[ks] = scaled(qs[ks], a.scale);          // q * scale in q's dtype (:73)
     u32x4v sk, sv4 = {}, sik = {}, siv = {}, siq = {};
     sk = rows_load(kp, a.sn, 0, a.L, false);
+    if constexpr (!HV) sv4 = rows_load(vp, a.sn, 0, a.L, true);
     if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
     if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
     if constexpr (HK) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
         for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f;
     }
     rows_store(kbuf, sk);
+    if constexpr (!HV) rows_store(vbuf, sv4);
     if constexpr (HK) ids_store(smem + L::idk, sik);
     if constexpr (HQ) ids_store(smem + L::idq, siq);
     __syncthreads();
@@ -369,6 +386,67 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     }
     if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
 
+    f32x16 o[2] = {f32x16{}, f32x16{}};
+    float l4[4] = {0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY;
+    if constexpr (!HV) {
+        // ---- single pass, online softmax (no bucket sums to rescale): running maximum m, o and l rescaled ----
+        float lrun = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            const bool more = t + 1 < NT;
+            if (more) {
+                sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
+                sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
+                if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
+                if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
+            }
+            if (active) {
+                f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
+                                              smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+                if (t == NT - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * 32 + acc_row(r, g) >= a.L) s[r] = -INFINITY;
+                }
+                float t4[4] = {s[0], s[1], s[2], s[3]};
+#pragma unroll
+                for (int r = 4; r < 16; ++r) t4[r & 3] = fmaxf(t4[r & 3], s[r]);
+                float tm = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+                tm = fmaxf(tm, __shfl_xor(tm, 32));
+                const float mn = fmaxf(m, tm);                       // finite: every tile has a valid key
+                const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+                const float mLn = mn * LOG2E;
+                m = mn;
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -mLn));
+                    s[r] = p;
+                    ps[r & 3] += p;
+                }
+                lrun = lrun * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                const short* vb = vbuf + cur * 32 * KP;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const F pb = TT::from_acc(s, s2);
+                    o[0] = TT::mma(load_perm_tr(vb, 0, s2, lane), pb, o[0]);
+                    o[1] = TT::mma(load_perm_tr(vb, 1, s2, lane), pb, o[1]);
+                }
+            }
+            if (more) {
+                rows_store(kbuf + nxt * 32 * KP, sk);
+                rows_store(vbuf + nxt * 32 * KP, sv4);
+                if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
+                if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
+                __syncthreads();
+                if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+            }
+        }
+        l4[0] = lrun;                                  // (lrun already holds this lane's half; halves are added below)
+    } else {
     // ---- pass 1: row maxima ----------------------------------------------------------------------
     // tiles 0..NT-1 (pass 1) and again 0..NT-1 (pass 2) form one stream of staged tiles
     float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -393,20 +471,18 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
             for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], s[r]);
         }
         rows_store(kbuf + nxt * 32 * KP, sk);
-        if (with_v) rows_store_T(vtbuf + nxt * 64 * VTP, sv4);
+        if (with_v) rows_store(vbuf + nxt * 32 * KP, sv4);
         if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
         if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
         if constexpr (HV) { if (with_v) ids_store(smem + L::idv + nxt * 128 * IDP, siv); }
         __syncthreads();
         if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
     }
-    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     m = fmaxf(m, __shfl_xor(m, 32));
     const float mL = m * LOG2E;
 
     // ---- pass 2: probabilities, P.V, bucket sums -------------------------------------------------
-    f32x16 o[2] = {f32x16{}, f32x16{}};
-    float l4[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < NT; ++t) {
         const int cur = (NT + t) & 1, nxt = cur ^ 1;
         const bool more = t + 1 < NT;
@@ -427,12 +503,12 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                 s[r] = p;
                 l4[r & 3] += p;
             }
-            const short* vt = vtbuf + cur * 64 * VTP;
+            const short* vb = vbuf + cur * 32 * KP;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const F pb = TT::from_acc(s, s2);
-                o[0] = TT::mma(TT::load_perm(vt + c32 * VTP, s2, g), pb, o[0]);
-                o[1] = TT::mma(TT::load_perm(vt + (c32 + 32) * VTP, s2, g), pb, o[1]);
+                o[0] = TT::mma(load_perm_tr(vb, 0, s2, lane), pb, o[0]);
+                o[1] = TT::mma(load_perm_tr(vb, 1, s2, lane), pb, o[1]);
             }
             if constexpr (HV) {
                 uint32_t w[4];
@@ -442,13 +518,14 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
         }
         if (more) {
             rows_store(kbuf + nxt * 32 * KP, sk);
-            rows_store_T(vtbuf + nxt * 64 * VTP, sv4);
+            rows_store(vbuf + nxt * 32 * KP, sv4);
             if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
             if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
             if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
             __syncthreads();
             if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
         }
+    }
     }
     if (!active) return;
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
@@ -480,8 +557,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
 template <bool HQ, bool HK, bool HV> struct LdsA {
     static constexpr int kbuf = 0;                                   // 2 x [32][KP]   K rows
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP]   V rows
-    static constexpr int ktbuf = vbuf + 2 * 32 * KP * 2;             // 2 x [64][VTP]  K^T
-    static constexpr int stage_end = ktbuf + 2 * 64 * VTP * 2;       // (tables are staged over this area outside the loop)
+    static constexpr int stage_end = vbuf + 2 * 32 * KP * 2;         // (two tables are staged over this area outside the loop)
     static constexpr int idk = stage_end;
     static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
     static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
@@ -519,7 +595,6 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
 
     short* kbuf = reinterpret_cast<short*>(smem + L::kbuf);
     short* vbuf = reinterpret_cast<short*>(smem + L::vbuf);
-    short* ktbuf = reinterpret_cast<short*>(smem + L::ktbuf);
     short* tab0 = reinterpret_cast<short*>(smem);                    // tables staged over the tile area
     short* tab1 = tab0 + 64 * KP;
     short* wqT = reinterpret_cast<short*>(smem + L::wqT);
@@ -581,7 +656,6 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
     auto commit = [&](const Stage& r, int t) {
         const int buf = t & 1;
         rows_store(kbuf + buf * 32 * KP, r.k);
-        rows_store_T(ktbuf + buf * 64 * VTP, r.k);
         rows_store(vbuf + buf * 32 * KP, r.v);
         if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
         if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, r.iq);
@@ -625,12 +699,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
                 lane_ids(w, smem + L::idk + cur * 128 * IDP, qrow, g);
                 scatter_add16(dlkw + c32 * LKP, w, s, g);
             }
-            const short* ktb = ktbuf + cur * 64 * VTP;
+            const short* kb = kbuf + cur * 32 * KP;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const F db = TT::from_acc(s, s2);
-                dq[0] = TT::mma(TT::load_perm(ktb + c32 * VTP, s2, g), db, dq[0]);
-                dq[1] = TT::mma(TT::load_perm(ktb + (c32 + 32) * VTP, s2, g), db, dq[1]);
+                dq[0] = TT::mma(load_perm_tr(kb, 0, s2, lane), db, dq[0]);
+                dq[1] = TT::mma(load_perm_tr(kb, 1, s2, lane), db, dq[1]);
             }
         }
         if (t + 1 < NT) {
@@ -666,9 +740,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
 template <bool HQ, bool HK, bool HV> struct LdsB {
     static constexpr int qbuf = 0;                                   // 2 x [32][KP]   (s q) rows
     static constexpr int dobuf = qbuf + 2 * 32 * KP * 2;             // 2 x [32][KP]   dO rows
-    static constexpr int qtbuf = dobuf + 2 * 32 * KP * 2;            // 2 x [64][VTP]  (s q)^T
-    static constexpr int dotbuf = qtbuf + 2 * 64 * VTP * 2;          // 2 x [64][VTP]  dO^T
-    static constexpr int stage_end = dotbuf + 2 * 64 * VTP * 2;
+    static constexpr int stage_end = dobuf + 2 * 32 * KP * 2;
     static constexpr int idk = stage_end;                            // key-major id tiles
     static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
     static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
@@ -706,8 +778,6 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
 
     short* qbuf = reinterpret_cast<short*>(smem + L::qbuf);
     short* dobuf = reinterpret_cast<short*>(smem + L::dobuf);
-    short* qtbuf = reinterpret_cast<short*>(smem + L::qtbuf);
-    short* dotbuf = reinterpret_cast<short*>(smem + L::dotbuf);
     short* tab0 = reinterpret_cast<short*>(smem);
     short* lkt = reinterpret_cast<short*>(smem + L::lkt);
     short* gt = reinterpret_cast<short*>(smem + L::gt);
@@ -750,9 +820,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
     auto commit = [&](const Stage& r, int t) {
         const int buf = t & 1;
         rows_store(qbuf + buf * 32 * KP, r.q);
-        rows_store_T(qtbuf + buf * 64 * VTP, r.q);
         rows_store(dobuf + buf * 32 * KP, r.dout);
-        rows_store_T(dotbuf + buf * 64 * VTP, r.dout);
         if constexpr (HK) lrows_store(lkt + buf * 32 * LBP, r.lk);
         if constexpr (HV) lrows_store(gt + buf * 32 * LBP, r.gl);
         if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
@@ -804,16 +872,15 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
                 lane_ids(w, smem + L::idq + cur * 128 * IDP, krow, g);
                 scatter_add16(dlqw + c32 * LKP, w, ds, g);
             }
-            const short* dot = dotbuf + cur * 64 * VTP;
-            const short* qtb = qtbuf + cur * 64 * VTP;
+            const short* qb = qbuf + cur * 32 * KP;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const F pb = TT::from_acc(s, s2);
                 const F sb = TT::from_acc(ds, s2);
-                dv[0] = TT::mma(TT::load_perm(dot + c32 * VTP, s2, g), pb, dv[0]);
-                dv[1] = TT::mma(TT::load_perm(dot + (c32 + 32) * VTP, s2, g), pb, dv[1]);
-                dk[0] = TT::mma(TT::load_perm(qtb + c32 * VTP, s2, g), sb, dk[0]);
-                dk[1] = TT::mma(TT::load_perm(qtb + (c32 + 32) * VTP, s2, g), sb, dk[1]);
+                dv[0] = TT::mma(load_perm_tr(db, 0, s2, lane), pb, dv[0]);
+                dv[1] = TT::mma(load_perm_tr(db, 1, s2, lane), pb, dv[1]);
+                dk[0] = TT::mma(load_perm_tr(qb, 0, s2, lane), sb, dk[0]);
+                dk[1] = TT::mma(load_perm_tr(qb, 1, s2, lane), sb, dk[1]);
             }
         }
         if (t + 1 < NT) {

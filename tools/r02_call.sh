@@ -1,12 +1,6 @@
 #!/bin/bash
-python - <<'PY'
-import torch, ctypes
-print("torch priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None)
-for p in (-2,-1,0,1,2):
-    try:
-        s=torch.cuda.Stream(priority=p); print("prio",p,"->",s.priority)
-    except Exception as e: print("prio",p,"ERR",e)
-PY
-for rep in 1 2; do for V in 0 1 -1; do
-CREAM_SIDE_PRIORITY=$V timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-kernel-timing 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('side_prio $V', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
-done; done
+timeout 900 python -m pytest tests/test_irpe_fused_gpu.py tests/test_irpe_gpu.py -q 2>&1 | tail -3 | cut -c1-300
+timeout 300 python tools/bench_irpe_attention.py 2>/dev/null | grep bfloat16 | python -c "
+import sys, json
+for l in sys.stdin:
+    d=json.loads(l); print(d['workload'][-10:], d['ms_per_fwd_bwd'], {k:(v['avg_us'], v['TFLOPs']) for k,v in d['kernels'].items()})"
