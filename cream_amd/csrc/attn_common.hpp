@@ -210,6 +210,32 @@ __device__ __forceinline__ float bucket_from_slots(const float* slot, int u, int
     return x;
 }
 
+// A operand of a product that contracts over the 32 tokens of a ROW-major [32][pitch] bf16 tile (rows = tokens):
+// MFMA row = column dt*32 + (lane & 31) of the tile, contraction indices in the permuted order of from_acc /
+// load_perm (acc_row(s*8 + e, g)).  Two ds_read_b64_tr_b16: the transpose happens on the way to the matrix cores,
+// so no transposed copy of the tile has to be staged (that copy cost 8 bank-conflicting 2-byte LDS stores per
+// thread and tile).  Lane i of a 16-lane group supplies the address of row i>>2, columns 4(i&3).. of a 4 x 16
+// block and receives column i, rows 0..3; with a pitch of 72 elements the four rows fall on disjoint banks.
+__device__ __forceinline__ bf16x8 load_perm_tr(const short* rows, int pitch, int dt, int s, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int gi = lane & 15, q = lane >> 4;
+    const short* p0 = rows + (16 * s + 4 * (q >> 1) + (gi >> 2)) * pitch + dt * 32 + 16 * (q & 1) + (gi & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p0)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p0 + 8 * pitch)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// the same operand for either data type: bf16 reads the row-major tile through the transposing LDS read, fp32
+// (no 32-bit transposing read) reads the transposed copy
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::frag perm_operand(const typename Tr<T>::elem* rm, int rm_pitch,
+                                                             const typename Tr<T>::elem* tr, int tr_pitch, int dt, int s,
+                                                             int lane) {
+    if constexpr (sizeof(typename Tr<T>::elem) == 2) return load_perm_tr(rm, rm_pitch, dt, s, lane);
+    else return Tr<T>::load_perm(tr + ((lane & 31) + 32 * dt) * tr_pitch, s, lane >> 5);
+}
+
 // make LDS traffic of this wave visible to its own later reads (in-order LDS, compiler fence)
 __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -532,7 +532,11 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     auto commit = [&](int u) {
         E* dst = (u & 1) ? buf1 : buf0;
         if (u < nt) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
-        else if (u < 2 * nt) tile_store<T, 32, 64, false, true>(ring[u % PF], nullptr, 0, dst, vp);
+        else if (u < 2 * nt) {
+            // V tiles: bf16 keeps them row-major (the P.V product reads them through ds_read_b64_tr_b16)
+            if constexpr (sizeof(E) == 2) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
+            else tile_store<T, 32, 64, false, true>(ring[u % PF], nullptr, 0, dst, vp);
+        }
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) issue(u);
@@ -645,8 +649,8 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
 #pragma unroll
                 for (int st2 = 0; st2 < S32; ++st2) {
                     const F pb = TT::from_acc(s[t], st2);
-                    o[0] = TT::mma(TT::load_perm(vb + c32 * vp, st2, g), pb, o[0]);
-                    o[1] = TT::mma(TT::load_perm(vb + (c32 + 32) * vp, st2, g), pb, o[1]);
+                    o[0] = TT::mma(perm_operand<T>(vb, kp, vb, vp, 0, st2, lane), pb, o[0]);
+                    o[1] = TT::mma(perm_operand<T>(vb, kp, vb, vp, 1, st2, lane), pb, o[1]);
                     if constexpr (FAST) ox = TT::mma(TT::load_perm(oht + c32 * otp + t * 32, st2, g), pb, ox);
                     else ox = TT::mma(TT::onehot_perm(masks + t * 32, st2, g, c32), pb, ox);
                 }
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
         delta += __shfl_xor(delta, 32);
     }
     if (active && g == 0) a.delta[bh * NP + qi] = delta;
-    if (grp == 0) tile_store_g<T, 32, 64, true, true>(sk, kbuf(0), rp, ktbuf(0), ktp, gt);
+    if (grp == 0) tile_store_g<T, 32, 64, true, sizeof(E) != 2>(sk, kbuf(0), rp, ktbuf(0), ktp, gt);      // bf16: K^T is read with tr16
     else tile_store_g<T, 32, 64, true, false>(sk, vbuf(0), rp, nullptr, 0, gt);
     __syncthreads();                                  // tables, masks, first tiles in place
     PROF_MARK();
@@ -882,14 +886,14 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
 #pragma unroll
             for (int st = 0; st < S32; ++st) {
                 const F db = TT::from_acc(sacc, st);
-                dq[0] = TT::mma(TT::load_perm(ktb + c32 * ktp, st, g), db, dq[0]);
-                dq[1] = TT::mma(TT::load_perm(ktb + (c32 + 32) * ktp, st, g), db, dq[1]);
+                dq[0] = TT::mma(perm_operand<T>(kbuf(cur), rp, ktb, ktp, 0, st, lane), db, dq[0]);
+                dq[1] = TT::mma(perm_operand<T>(kbuf(cur), rp, ktb, ktp, 1, st, lane), db, dq[1]);
                 if constexpr (FAST) dx = TT::mma(TT::load_perm(oht + c32 * otp + t * 32, st, g), db, dx);
                 else dx = TT::mma(TT::onehot_perm(masks + t * 32, st, g, c32), db, dx);
             }
         }
         if (t + 1 < nt) {
-            if (grp == 0) tile_store_g<T, 32, 64, true, true>(sk, kbuf(cur ^ 1), rp, ktbuf(cur ^ 1), ktp, gt);
+            if (grp == 0) tile_store_g<T, 32, 64, true, sizeof(E) != 2>(sk, kbuf(cur ^ 1), rp, ktbuf(cur ^ 1), ktp, gt);
             else tile_store_g<T, 32, 64, true, false>(sk, vbuf(cur ^ 1), rp, nullptr, 0, gt);
             __syncthreads();
         }
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     };
     auto store_set = [&](int i) {
         if (grp == 0) {
-            tile_store_g<T, 32, 64, true, true>(sq, qbuf(i), rp, qtbuf(i), tpt, gt);
+            tile_store_g<T, 32, 64, true, sizeof(E) != 2>(sq, qbuf(i), rp, qtbuf(i), tpt, gt);     // bf16: Q^T / dO^T are read with tr16
             tile_store_g<T, 64, 32, true, false>(sdl, spbuf(i), tpt, nullptr, 0, gt);
             if constexpr (EH == 128) {
                 const int c = gt & 127, row = c >> 2, cc = c & 3;
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                 tile_store_g<T, 32, 32, true, false>(sde, debuf(i), ep, nullptr, 0, gt);
             }
         } else {
-            tile_store_g<T, 32, 64, true, true>(sq, dbuf(i), rp, dtbuf(i), tpt, gt);
+            tile_store_g<T, 32, 64, true, sizeof(E) != 2>(sq, dbuf(i), rp, dtbuf(i), tpt, gt);
             tile_store_g<T, 64, 32, true, false>(sdl, dlbuf(i), tpt, nullptr, 0, gt);
         }
     };
@@ -1078,8 +1082,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                 const F db = TT::from_acc(pacc, st);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = TT::mma(TT::load_perm(dtbuf(cur) + (c32 + 32 * dt) * tpt, st, g), pb, dv[dt]);
-                    dk[dt] = TT::mma(TT::load_perm(qtbuf(cur) + (c32 + 32 * dt) * tpt, st, g), db, dk[dt]);
+                    dv[dt] = TT::mma(perm_operand<T>(dbuf(cur), rp, dtbuf(cur), tpt, dt, st, lane), pb, dv[dt]);
+                    dk[dt] = TT::mma(perm_operand<T>(qbuf(cur), rp, qtbuf(cur), tpt, dt, st, lane), db, dk[dt]);
                 }
             }
         }
@@ -1089,11 +1093,12 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
             const int job = jj == 0 ? job0 : job1;
             if (job < 8) {
                 const int tab = job >> 1, dt = job & 1;
-                const E* xT = (tab < 2 ? qtbuf(cur) : dtbuf(cur)) + (c32 + 32 * dt) * tpt;
+                const E* xR = tab < 2 ? qbuf(cur) : dbuf(cur);
+                const E* xT = tab < 2 ? qtbuf(cur) : dtbuf(cur);
                 const E* rT = (tab < 2 ? dlbuf(cur) : spbuf(cur)) + ((tab & 1) * 32 + c32) * tpt;
 #pragma unroll
                 for (int st = 0; st < S32; ++st)
-                    tacc[jj] = TT::mma(TT::load_perm(xT, st, g), TT::load_perm(rT, st, g), tacc[jj]);
+                    tacc[jj] = TT::mma(perm_operand<T>(xR, rp, xT, tpt, dt, st, lane), TT::load_perm(rT, st, g), tacc[jj]);
             }
         }
         PROF_LOOP(t);
