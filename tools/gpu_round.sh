@@ -14,13 +14,22 @@ fi
 timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
 # counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_|gemm_|ln_|adamw|grad_finalize' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
+done
+# BASELINE config 4: rocprofv3 kernel trace + HBM counters of the rpe_index kernels, stall counters of both kernel families
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_rpe_prof -o rpe -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_rpe_prof.err
+i=0
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TA_BUSY_avr SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'rpe_gather|rpe_scatter' -d $OUT/${TAG}_rpepmc_$i -o pmc --output-format csv -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_rpepmc_$i.err
+  echo "rpe pmc $i exit $?"
+  [ $i -ge 3 ] && timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_attn' -d $OUT/${TAG}_irpepmc_$i -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_irpepmc_$i.err
 done
 cd $REPO
 # the other measured configurations: config 2 (supernet-T, fixed subnet), config 4 (rpe_index
