@@ -57,3 +57,36 @@ def enable_fast_path(caller):
     model.forward_features = ours.Vision_TransformerSuper.forward_features
     model._cream_fast_path = True
     return caller
+
+
+def enable_irpe_fast_path(caller):
+    """Patch a caller module that defines `RPEAttention` with the reference's attribute names
+    (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:45-97: qkv, proj, attn_drop, proj_drop, rpe_q / rpe_k / rpe_v,
+    scale, num_heads): its `forward` is replaced by cream_amd.rpe_attention.RPEAttention.forward, which runs the
+    fused kernels of csrc/irpe_attn.hip (`cream_irpe_attn_fwd / _bwd`) when the layer is covered — CUDA, bf16
+    operands, head_dim 64, contextual rpe modules built from the drop-in `irpe` (<= 64 buckets) — and otherwise
+    computes exactly what the reference's forward computes, on the drop-in `rpe_index` operator."""
+    from cream_amd.rpe_attention import RPEAttention as ours
+    cls = caller.RPEAttention
+    if not getattr(cls, "_cream_fast_path", False):
+        cls._cream_reference_forward = cls.forward
+        cls.forward = ours.forward
+        cls._cream_fast_path = True
+    return caller
+
+
+def install_irpe(reference_dir=None, fast_path=True):
+    """`import irpe`, `import rpe_ops.rpe_index`, `import rpe_index_cpp` resolve to the MI355X implementations
+    (install()); with `reference_dir` (e.g. .../iRPE/DeiT-with-iRPE) the reference's unchanged
+    `rpe_vision_transformer.py` is imported from there and — with `fast_path` — its RPEAttention patched
+    (enable_irpe_fast_path).  Returns the caller module, or None without a reference directory."""
+    import importlib
+    install()
+    if not reference_dir:
+        return None
+    for k in [k for k in sys.modules if k in ("irpe", "rpe_vision_transformer", "rpe_index_cpp") or k.startswith("rpe_ops")]:
+        del sys.modules[k]
+    if reference_dir not in sys.path:
+        sys.path.append(reference_dir)                # AFTER the drop-in directory: `irpe` stays ours
+    caller = importlib.import_module("rpe_vision_transformer")
+    return enable_irpe_fast_path(caller) if fast_path else caller

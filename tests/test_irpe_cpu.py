@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from fixture_utils import fill_params  # noqa: E402
 
 from cream_amd import irpe as I  # noqa: E402
+import refshim  # noqa: E402
 
 METH = dict(product=I.METHOD.PRODUCT, euc=I.METHOD.EUCLIDEAN, quant=I.METHOD.QUANT,
             cross_rows=I.METHOD.CROSS_ROWS, cross_cols=I.METHOD.CROSS_COLS)
@@ -208,3 +209,38 @@ def run_attention_L577(rpe_on, device, tol, autocast=False):
             worst = max(worst, max_rel(dict(att.named_parameters())[k[len(rpe_on) + 6:]].grad.cpu(), v))
     assert worst < tol, worst
     return worst
+
+
+@pytest.mark.skipif(not refshim.have_reference(), reason="needs the reference checkout")
+def test_reference_rpe_attention_through_the_patched_caller():
+    """The reference's UNCHANGED rpe_vision_transformer.py imported next to the drop-in `irpe`, its RPEAttention
+    patched onto our forward (dropin.install_irpe): same parameters, same inputs -> the reference-made fixture.
+    (On the CPU the patched forward takes the composed path; on the device under bf16 autocast the same patched
+    class runs the fused kernels — tests/test_irpe_gpu.py exercises that forward through cream_amd.rpe_attention.)"""
+    import cream_amd.dropin as d
+    refshim._install_easydict()
+    refshim._install_timm_stub()
+    caller = d.install_irpe(refshim.IRPE)
+    try:
+        assert caller.RPEAttention._cream_fast_path and caller.__file__.startswith(refshim.IRPE)
+        irpe = sys.modules["irpe"]
+        assert os.path.dirname(irpe.__file__) == d.PATH                      # the drop-in, not the reference's
+        fix = load_npz("irpe_attention.npz")
+        cfg = irpe.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="qkv")
+        att = caller.RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg)
+        fill_params(att, seed=19)
+        with torch.no_grad():
+            for n, p in att.named_parameters():
+                if "lookup_table" in n:
+                    p.copy_(0.3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))))
+        g = torch.Generator().manual_seed(41)
+        x = torch.randn(2, 197, 192, generator=g, requires_grad=True)
+        gy = torch.randn(2, 197, 192, generator=g)
+        y = att(x)
+        y.backward(gy)
+        assert max_rel(y.detach(), fix["y"]) < 1e-5 and max_rel(x.grad, fix["dx"]) < 1e-5
+    finally:
+        if refshim.IRPE in sys.path:
+            sys.path.remove(refshim.IRPE)
+        for k in [k for k in sys.modules if k in ("irpe", "rpe_vision_transformer", "rpe_index_cpp") or k.startswith("rpe_ops")]:
+            del sys.modules[k]
