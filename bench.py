@@ -207,6 +207,7 @@ def irpe_config4_leg(iters=10):
     product / contextual (B = 64, H = 12, L = 577, 50 buckets) forward + backward under bf16 autocast —
     the fused kernels of csrc/irpe_attn.hip — for rpe on keys and on q, k and v; ms per layer and the
     kernels' share (HIP events on the launch stream)."""
+    from cream_amd import timing
     from cream_amd.irpe import get_rpe_config
     from cream_amd.rpe_attention import RPEAttention
     dev = torch.device("cuda")

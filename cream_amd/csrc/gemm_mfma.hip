@@ -138,11 +138,12 @@ int cream_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128), steps = (M + 63) / 64;
-    // all workgroups resident at once and at most one per CU (256 slots — one more workgroup than slots costs
-    // a whole extra round), at most 16 splits: every split is another fp32 partial tile through HBM (written
-    // here, read by cream_grad_finalize: 128 MB per block at 512 slots).  Measured A/B in one call, 3 runs
-    // each: 256 / 384 / 512 slots -> 11.60 / 11.60 / 11.65 ms per step
-    constexpr int slots = 256;
+    // all workgroups resident at once (2 per CU: 512 slots — one more workgroup than slots costs a whole
+    // extra round), at most 16 splits: every split is another fp32 partial tile through HBM (written
+    // here, read by cream_grad_finalize).  Measured A/B in one call, 3 runs each: 256 / 384 / 512 slots ->
+    // 11.60 / 11.60 / 11.65 ms per step (fewer partial bytes vs. a 1.5x slower kernel: 78 vs 53 us standalone);
+    // 512 keeps the kernel itself at its best rate
+    constexpr int slots = 512;
     int s = slots / tiles;
     if (s > 16) s = 16;
     if (s > steps) s = steps;

@@ -128,7 +128,7 @@ def test_new_entry_points_validate_arguments_without_launching():
     assert lib.cream_linear_wgrad_parts(0x1000, None, 0x1000, 0x1000, 10, 8, 8, 0, None) == -1            # S < 1
     assert lib.cream_linear_wgrad_parts(None, None, 0x1000, 0x1000, 10, 8, 8, 1, None) == -1
     assert lib.cream_linear_wgrad_splits(25216, 384, 384) == 16 and lib.cream_linear_wgrad_splits(64, 384, 384) == 1
-    assert lib.cream_linear_wgrad_splits(25216, 1344, 384) == 7           # 33 tiles x 7 = 231 <= 256 resident workgroups
+    assert lib.cream_linear_wgrad_splits(25216, 1344, 384) == 15          # 33 tiles x 15 = 495 <= 512 resident workgroups
     assert lib.cream_gemm_rows_per_colsum_slab() == 128
     assert lib.cream_param_job_tiles(96, 64) == 1 and lib.cream_param_job_tiles(97, 65) == 4 and lib.cream_param_job_tiles(0, 5) == 0
     assert lib.cream_adamw_step(None, None, 0, 0, 1, 1e-3, 0.9, 0.999, 1e-8, 1, None) == 0      # nothing to do

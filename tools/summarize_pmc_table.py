@@ -40,8 +40,6 @@ def main():
                     out.append(f"{name} {100 * m[c] / w:.0f} % of wave cycles")
         if m.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in m:
             out.append(f"LDS bank-conflict cycles {100 * m['SQ_LDS_BANK_CONFLICT'] / m['SQ_LDS_IDX_ACTIVE']:.0f} % of LDS-active cycles")
-        if "TA_BUSY_avr" in m:
-            out.append(f"TA busy {m['TA_BUSY_avr']:.0f} %")
         print(f"* `{k}`: " + "; ".join(out))
 
 
