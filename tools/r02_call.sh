@@ -1,3 +1,2 @@
 #!/bin/bash
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-bash tools/gpu_round.sh r02z 40
+timeout 900 python -m pytest tests/test_comm_gpu.py -q -s 2>&1 | grep -v "^$" | tail -25 | cut -c1-300
