@@ -75,6 +75,7 @@ SIGNATURES = {
     "cream_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_fwd_seg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_gelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "cream_linear_gelu_fwd_pad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
     "cream_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_dgrad_seg": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_dgrad_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
@@ -99,7 +100,7 @@ class GradJob(ctypes.Structure):
 
 class BlockDesc(ctypes.Structure):
     """struct cream_block_desc of include/cream_amd.h."""
-    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "reserved0", "reserved1")] +
+    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "F_valid", "reserved1")] +
                 [(n, _f) for n in ("eps1", "eps2", "attn_scale", "reserved_f")] +
                 [(n, _vp) for n in ("wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj", "w1", "w1_t", "b1",
                                     "w2", "w2_t", "b2")] +

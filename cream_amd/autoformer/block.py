@@ -681,7 +681,10 @@ def supported(blk, x):
                                       and (blk.sample_attn_dropout or 0.0) == 0.0 and a.proj_drop.p == 0.0))
             and fused_attention.grid_of(x.shape[1], a.max_relative_position) is not None
             and a.rel_pos_embed_k.embeddings_table_v.shape[1] == 64
-            and blk.sample_embed_dim % 8 == 0 and blk.sample_ffn_embed_dim_this_layer % 8 == 0
+            and blk.sample_embed_dim % 8 == 0
+            # a hidden width that is not a multiple of 8 (supernet-T: 216 x 3.5 = 756) runs padded, native driver only
+            and (blk.sample_ffn_embed_dim_this_layer % 8 == 0
+                 or (NATIVE_BLOCK and (blk.sample_ffn_embed_dim_this_layer + 7) // 8 * 8 <= blk.fc1.weight.shape[0]))
             and blk.sample_out_dim == blk.sample_embed_dim
             and a.qkv.bias is not None and a.proj.bias is not None and blk.fc1.bias is not None
             and blk.fc2.bias is not None)
@@ -834,7 +837,9 @@ def _block_desc(blk, B, N):
         t.mr = at.max_relative_position
         ent = blk.__dict__[_DESC_KEY] = (t, key)
     d = _lib.BlockDesc.from_buffer_copy(ent[0])
-    d.B, d.N, d.E, d.H, d.F = B, N, blk.sample_embed_dim, at.sample_num_heads, blk.sample_ffn_embed_dim_this_layer
+    F = blk.sample_ffn_embed_dim_this_layer
+    d.B, d.N, d.E, d.H, d.F = B, N, blk.sample_embed_dim, at.sample_num_heads, (F + 7) // 8 * 8
+    d.F_valid = F if F % 8 else 0
     d.gh, d.gw = fused_attention.grid_of(N, d.mr)
     d.attn_scale = float(at.sample_scale)
     return d

@@ -183,7 +183,8 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     TRY(cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
                          at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
-    TRY(cream_linear_gelu_fwd(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F, E, d->ld_w1, stream));
+    TRY(cream_linear_gelu_fwd_pad(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
+                                  d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
     TRY(cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
 }

@@ -90,16 +90,23 @@ int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bi
     return launch_nt<EPI_BIAS>(p, (hipStream_t)stream);
 }
 
-int cream_linear_gelu_fwd(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int K,
-                          int64_t ldw, void* stream)
+int cream_linear_gelu_fwd_pad(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int Nvalid,
+                              int K, int64_t ldw, void* stream)
 {
     const int rc = check_nt(gp, x, w, M, N, K, ldw, K);
     if (rc) return rc < 0 ? rc : CREAM_OK;
-    if (!g || !bias || !aligned16(g)) return CREAM_ERR_BAD_ARG;
+    if (!g || !bias || !aligned16(g) || Nvalid <= 0 || Nvalid > N) return CREAM_ERR_BAD_ARG;
     NtParams p = plain(gp, x, w, M, N, K, ldw);
     p.bias = (const uint16_t*)bias;
     p.out2 = (uint16_t*)g;
+    p.nvalid = Nvalid;
     return launch_nt<EPI_BIAS_GELU>(p, (hipStream_t)stream);
+}
+
+int cream_linear_gelu_fwd(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int K,
+                          int64_t ldw, void* stream)
+{
+    return cream_linear_gelu_fwd_pad(gp, g, x, w, bias, M, N, N, K, ldw, stream);
 }
 
 int cream_linear_dgrad(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt, void* stream)

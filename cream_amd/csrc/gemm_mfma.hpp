@@ -62,6 +62,7 @@ struct NtParams {
     const uint16_t* aux;    // EPI_MUL_COLSUM: element-wise factor (M x N) bf16, row stride ldaux
     int64_t ldaux;
     float* colsum;          // EPI_MUL_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
+    int nvalid;             // EPI_BIAS_GELU: columns n >= nvalid are written as zeros (N padded up to a multiple of 8)
 };
 
 // erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
@@ -313,6 +314,14 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                 phi_parts(h1, c1, e1);
                 gb[e] = f2bf_pair(h0 * c0, h1 * c1);
                 pb[e] = f2bf_pair(fmaf(h0 * 0.3989422804014327f, e0, c0), fmaf(h1 * 0.3989422804014327f, e1, c1));
+            }
+            if (n + 8 > p.nvalid) {                             // padded columns: exact zeros (their gradients vanish)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t keep = (n + 2 * e < p.nvalid ? 0x0000FFFFu : 0u) | (n + 2 * e + 1 < p.nvalid ? 0xFFFF0000u : 0u);
+                    pb[e] &= keep;
+                    gb[e] &= keep;
+                }
             }
             *reinterpret_cast<u32x4v*>(o) = pb;
             *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;

@@ -315,6 +315,9 @@ int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bi
                          int64_t ldw, int nseg, int64_t nseg_stride, void* stream);
 int cream_linear_gelu_fwd(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N,
                           int K, int64_t ldw, void* stream);
+/* The same with N rounded up to a multiple of 8: outputs of columns n >= Nvalid are written as zeros. */
+int cream_linear_gelu_fwd_pad(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int Nvalid,
+                              int K, int64_t ldw, void* stream);
 int cream_linear_dgrad(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
                        void* stream);
 int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int N, int K, int64_t ldwt,
@@ -378,7 +381,9 @@ int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 typedef struct cream_block_desc {
     int32_t B, N, E, H, F;        /* batch, tokens, embed dim, heads (head dim 64), mlp hidden     */
     int32_t gh, gw, mr;           /* token grid (N = gh*gw + 1) and max_relative_position          */
-    int32_t reserved0, reserved1;
+    int32_t F_valid, reserved1;     /* F_valid > 0: F is the sampled hidden width rounded UP to a multiple of 8 and only the
+                                       first F_valid hidden units exist (the fc1 epilogue writes zeros for the rest, which
+                                       makes every product over the padded columns vanish); 0: F itself is exact */
     float eps1, eps2, attn_scale;
     float reserved_f;
     /* bf16 operand copies of the SUPER weights (written by cream_adamw_step), read in place:

@@ -571,3 +571,36 @@ def test_native_stem_and_tail_match_the_module_path():
     prm = dict(model.named_parameters())
     assert float(prm["norm.weight"].grad[384:].abs().max()) == 0.0
     assert float(prm["pos_embed"].grad[..., 384:].abs().max()) == 0.0 and float(prm["cls_token"].grad[..., 384:].abs().max()) == 0.0
+
+
+def test_hidden_width_not_multiple_of_8_runs_padded_on_the_native_path():
+    """supernet-T samples embed_dim 216 with mlp_ratio 3.5 -> a hidden width of 756: the native block pads it to
+    760 (the fc1 epilogue writes zeros for the 4 extra hidden units, so every product over them vanishes) instead
+    of leaving the fast path.  Against the fp32 module path; gradients of the padding rows / columns exactly zero."""
+    from cream_amd.autoformer import engine
+    torch.manual_seed(9)
+    model = engine.build_supernet("T", drop_path_rate=0.0).to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[216] * 2, mlp_ratio=[3.5, 3.5], num_heads=[3, 4])
+    model.set_sample_config(cfg)
+    model.train()
+    assert model.blocks[0].sample_ffn_embed_dim_this_layer == 756
+    x = torch.randn(8, 3, 224, 224, device=DEV)
+    gy = torch.randn(8, 216, device=DEV)
+    ref = model.forward_features(x)                                   # fp32 module path
+    ref.backward(gy)
+    names = ["blocks.0.fc1.weight", "blocks.0.fc2.weight", "blocks.0.fc1.bias", "blocks.1.attn.qkv.weight", "norm.weight"]
+    prm = dict(model.named_parameters())
+    want = [prm[n].grad.clone() for n in names]
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = model.forward_features(x)
+    assert "StackFunction" in type(y.grad_fn).__name__, "the native block path did not run"
+    y.backward(gy)
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max().clamp_min(1e-30))      # noqa: E731
+    errs = dict(y=rel(y, ref.detach()), **{n: rel(prm[n].grad, w) for n, w in zip(names, want)})
+    print("[F = 756 padded]", {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 3e-2, (k, v)
+    assert float(prm["blocks.0.fc1.weight"].grad[756:].abs().max()) == 0.0
+    assert float(prm["blocks.0.fc2.weight"].grad[:, 756:].abs().max()) == 0.0
+    assert float(prm["blocks.0.fc1.bias"].grad[756:].abs().max()) == 0.0
