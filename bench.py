@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory: shortens the dispatch of back-to-back kernels (a step is ~330 launches);
+# measured +3.3 % images/s in a same-box A/B.  Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -1,3 +1,8 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_block_gpu.py -q -x -s -k padded 2>&1 | grep "padded\|passed\|failed\|Error" | cut -c1-400
-timeout 300 python bench.py --supernet T --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('T', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+for rep in 1 2; do
+timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-kernel-timing 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default(now 1)', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+HIP_FORCE_DEV_KERNARG=0 timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-kernel-timing 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('forced 0', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+done
+for E in "AMD_DIRECT_DISPATCH=0" "GPU_MAX_HW_QUEUES=2" "HIP_LAUNCH_BLOCKING=0"; do
+env $E timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-kernel-timing 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$E', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+done
