@@ -64,6 +64,7 @@ struct FwdArgs {
     int H, NP;
     RelGeom G;
     float scale;
+    int nitems;                                      // B * H (forward: persistent workgroups walk them)
 };
 
 struct BwdArgs {
@@ -83,6 +84,7 @@ struct BwdArgs {
     int H, NP;
     RelGeom G;
     float scale;
+    int nitems;                                      // B * H (dQ kernel: persistent workgroups walk them)
 };
 
 // ---- pieces shared by forward and backward ---------------------------------------------
@@ -501,22 +503,40 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     short* oht = ohr + NP * OHP;
     const int otp = oht_pitch(NP);
 
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    // waves beyond the query tiles only help staging; the fast instantiation is launched with exactly
+    // nt waves, and saying so lets the accumulators start from the MFMA's inline zero operand
+    const bool active = FAST ? true : wave < nt;
+    const int qi = wave * 32 + c32;
+    const bool qok = qi < N;
+    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
+
+    // ---- once per workgroup: tables, key slot masks, one-hot operands (the same for every (b, h)) -----------
+    // The workgroup is PERSISTENT: it walks (b, h) items blockIdx.x, + gridDim.x, ... so that this setup — a
+    // quarter of a one-item workgroup's time, all CUs bursting on the tables at once — is paid once per CU.
+    {
+        TabRegs rv, rk;
+        tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
+        if constexpr (tables_in_lds<T>()) tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
+        tab_store_T<T>(rv, tvt);
+        if constexpr (tables_in_lds<T>()) tab_store_R<T>(rk, tkr);
+    }
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
+    if constexpr (FAST) {
+        __syncthreads();
+        fill_onehot(ohr, oht, masks, NP);
+    }
+
+    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    const int b = item / a.H, h = item - b * a.H;
     const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
     const E* qp = reinterpret_cast<const E*>(a.q) + base;
     const E* kpg = reinterpret_cast<const E*>(a.k) + base;
     const E* vpg = reinterpret_cast<const E*>(a.v) + base;
-    // waves beyond the query tiles only help staging; the fast instantiation is launched with exactly
-    // nt waves, and saying so lets the accumulators start from the MFMA's inline zero operand
-    const bool active = FAST ? true : wave < nt;
 
     PROF_DECL
     PROF_MARK();
-    const int qi = wave * 32 + c32;
-    const bool qok = qi < N;
-    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
     F qb[S64];
     load_row<T>(qb, qp + (int64_t)min(qi, N - 1) * a.sn, g);
     // K tiles 0..nt-1 and then V tiles 0..nt-1 form ONE stream of 2*nt staged tiles: tile u is
@@ -541,19 +561,9 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
 #pragma unroll
     for (int u = 0; u < PF; ++u) issue(u);
 
-    // ---- workgroup prologue: tables, key slot masks, first K tile ---------------------------
-    {
-        TabRegs rv, rk;
-        tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
-        if constexpr (tables_in_lds<T>()) tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
-        tab_store_T<T>(rv, tvt);
-        if constexpr (tables_in_lds<T>()) tab_store_R<T>(rk, tkr);
-    }
-    for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
-    if constexpr (FAST) {
-        __syncthreads();
-        fill_onehot(ohr, oht, masks, NP);
-    }
+    // ---- item prologue: first K tile (the barrier also separates this item's staging and scratch use from the
+    // previous item's last tile and epilogue, and publishes the once-per-workgroup setup) ---------------------
+    __syncthreads();
     commit(0);
     issue(PF);
     __syncthreads();
@@ -661,7 +671,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
                 issue(nt + t + 1 + PF);
             }
         }
-    if (!active) return;
+    if (active) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; ox[r] *= inv_l; }
     PROF_MARK();
@@ -679,6 +689,20 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     if (qok) store_rows_64<T>(reinterpret_cast<E*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64, o, g);
     PROF_MARK();
     PROF_FLUSH();
+    }   // active
+    }   // items
+}
+
+// one persistent workgroup per CU (the forward's LDS footprint allows exactly one)
+int fwd_persistent_grid() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 bool fast_geometry(const RelGeom& G) { return G.n == 197 && G.gh == G14 && G.gw == G14 && G.mr == G14; }
@@ -695,7 +719,10 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
             return CREAM_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(B * a.H), dim3(waves * 64), lds, st, a);
+    FwdArgs aa = a;
+    aa.nitems = B * a.H;
+    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -760,10 +787,34 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     short* oht = ohr + NP * OHP;
     const int otp = oht_pitch(NP);
 
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    const int64_t bh = (int64_t)b * a.H + h;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const bool active = wave < nt;
+    const int qi = wave * 32 + c32;
+    const bool qok = qi < N;
+    const int qcl = min(qi, N - 1);
+    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
+    const int grp = wave >> 2, gt = threadIdx.x & 255;
+    // ---- once per (persistent) workgroup: tables, key slot masks, one-hot operands ----------------------------
+    {
+        TabRegs rk, rv;
+        tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
+        if constexpr (tables_in_lds<T>()) tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
+        tab_store_T<T>(rk, tkt);
+        if constexpr (tables_in_lds<T>()) {
+            tab_store_R<T>(rk, tkr);
+            tab_store_R<T>(rv, tvr);
+        }
+    }
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
+    if constexpr (FAST) {
+        __syncthreads();
+        fill_onehot(ohr, oht, masks, NP);
+    }
+    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    __syncthreads();                                  // previous item done with the staged tiles / setup published
+    const int b = item / a.H, h = item - b * a.H;
+    const int64_t bh = (int64_t)b * a.H + h;
     const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
     const E* qp = reinterpret_cast<const E*>(a.q) + base;
     const E* kpg = reinterpret_cast<const E*>(a.k) + base;
@@ -771,17 +822,11 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
     const int64_t orow = (int64_t)a.H * 64;                               // token stride of out / dout
     const E* dop = reinterpret_cast<const E*>(a.dout) + ((int64_t)b * N * a.H + h) * 64;
     const E* outp = reinterpret_cast<const E*>(a.out) + ((int64_t)b * N * a.H + h) * 64;
-    const bool active = wave < nt;
 
     PROF_DECL
     PROF_MARK();
-    const int qi = wave * 32 + c32;
-    const bool qok = qi < N;
-    const int qcl = min(qi, N - 1);
-    const int qr = qi > 0 ? (qi - 1) / G.gw : 0, qc = qi > 0 ? (qi - 1) - qr * G.gw : 0;
     F qb[S64], dob[S64];
     float delta = 0.f;
-    const int grp = wave >> 2, gt = threadIdx.x & 255;
     TileRegs<T, 32, 64> sk;
     {
         F ob[S64];
@@ -793,21 +838,6 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
         if (grp == 0) tile_load_g<T, 32, 64>(sk, kpg, a.sn, 0, N, 0, gt);
         else tile_load_g<T, 32, 64>(sk, vpg, a.sn, 0, N, 0, gt);
 
-        {
-            TabRegs rk, rv;
-            tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
-            if constexpr (tables_in_lds<T>()) tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
-            tab_store_T<T>(rk, tkt);
-            if constexpr (tables_in_lds<T>()) {
-                tab_store_R<T>(rk, tkr);
-                tab_store_R<T>(rv, tvr);
-            }
-        }
-        for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
-        if constexpr (FAST) {
-            __syncthreads();
-            fill_onehot(ohr, oht, masks, NP);
-        }
 
         // delta_i = dO_i . O_i  (this lane holds half of the 64 d-values; the partner the rest)
         if (!qok) { zero_frags<T, S64>(qb); zero_frags<T, S64>(dob); }
@@ -899,7 +929,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
         }
     }
     PROF_MARK();
-    if (!active) return;
+    if (active) {
 
     float bk[32];
     if constexpr (FAST) slots_to_buckets14(bk, scr, dx, lane, wave == 0, min(qr, G14 - 1), qc);
@@ -912,6 +942,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
                          dq, g);
     PROF_MARK();
     PROF_FLUSH();
+    }   // active
+    }   // items
 }
 
 // LDS of the dK/dV kernel: 2 x [Q | dO rows, Q^T | dO^T, qe | de rows, dL'^T | S'^T tiles] | lse2 | delta
@@ -945,11 +977,15 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     float* lse2 = reinterpret_cast<float*>(smem + 2 * SET);               // [NP]
     float* dlt_s = lse2 + NP;                                             // delta [NP]
 
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    const int64_t bh = (int64_t)b * a.H + h;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    // persistent workgroup: (b, h) items blockIdx.x, + gridDim.x, ... (after the first round the workgroups of
+    // the CUs are out of step, so their prologue loads no longer hit HBM all at once)
+    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    __syncthreads();                                  // previous item done with the staged tiles and lse / delta
+    const int b = item / a.H, h = item - b * a.H;
+    const int64_t bh = (int64_t)b * a.H + h;
     const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
     const E* qp = reinterpret_cast<const E*>(a.q) + base;
     const E* kpg = reinterpret_cast<const E*>(a.k) + base;
@@ -1131,6 +1167,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     }
     PROF_MARK();
     PROF_FLUSH();
+    }   // items
 }
 
 template <typename T, bool FAST>
@@ -1146,14 +1183,16 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
             return CREAM_ERR_LAUNCH;
         attr_done = true;
     }
-    const dim3 grid(B * a.H);
-    hipLaunchKernelGGL(kq, grid, dim3(512), bwd_q_lds_bytes<T>(a.NP, a.NP / 32, FAST), st, a);
+    BwdArgs aa = a;
+    aa.nitems = B * a.H;
+    const int pgrid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    hipLaunchKernelGGL(kq, dim3(pgrid), dim3(512), bwd_q_lds_bytes<T>(a.NP, a.NP / 32, FAST), st, aa);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
 #ifdef PROBE_SKIP_KV                     // tools/probes/attn_probe.hip: keep the dQ kernel's phase stamps
     (void)kkv;
     return CREAM_OK;
 #endif
-    hipLaunchKernelGGL(kkv, grid, dim3(512), bwd_kv_lds_bytes<T>(a.NP), st, a);
+    hipLaunchKernelGGL(kkv, dim3(pgrid), dim3(512), bwd_kv_lds_bytes<T>(a.NP), st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
