@@ -49,6 +49,14 @@ namespace gemm {
 
 enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3 };
 
+// Phase timestamps for tools/probes/gemm_nt_probe.hip (compiled out of the library)
+#ifdef GEMM_PROFILE
+__device__ long long* g_gemm_prof = nullptr;
+#define GPROF(i) do { if (threadIdx.x == 0 && g_gemm_prof) g_gemm_prof[(long long)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GPROF(i) do {} while (0)
+#endif
+
 struct NtParams {
     const uint16_t* A;      // (M x K) bf16, row stride lda
     const uint16_t* B;      // element (n, k) at B[(n / nseg) * nseg_stride + (n % nseg) * ldb + (k / kseg) * kseg_stride + k % kseg]
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
     float* const ctile = reinterpret_cast<float*>(smem);
 
+    GPROF(0);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -238,6 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     };
     for (int s = 0; s < nfull; ++s) {                           // (the tail step lives outside the loop: one
         top_of_step(s);                                         //  accumulator live range, no phi copies)
+        if (s == 0) GPROF(1);
         step(s % NST, 8, No{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         step(nfull % NST, rem >> 3, Yes{});
     }
 
+    GPROF(2);
     // ---- epilogue: accumulators -> LDS (fp32, [BM][BN + 4]) -> (row, 8 columns) chunks -------------
     constexpr int CPR = BN / 8;                                 // chunks per tile row
     constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             p.colsum[(int64_t)(m0 / BM) * p.N + n0 + tid] = s;
         }
     }
+    GPROF(3);
 }
 
 

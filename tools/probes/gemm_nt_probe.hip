@@ -15,6 +15,7 @@
 #include <cstring>
 #include <vector>
 
+#define GEMM_PROFILE 1
 #include "gemm_mfma.hpp"
 
 using namespace cream;
@@ -78,6 +79,28 @@ static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
     const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm;
     hipLaunchKernelGGL(v.kern, dim3(ntn * ntm), dim3(v.nt), 0, st, p);
 }
+
+// phase timestamps of one variant on one shape: per workgroup start -> first data -> end of K loop -> end
+static void phase_profile(const Variant& v, const NtParams& p) {
+    const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, nwg = ntn * ntm;
+    long long* d; CK(hipMalloc(&d, (size_t)nwg * 8 * 8)); CK(hipMemset(d, 0, (size_t)nwg * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(cream::gemm::g_gemm_prof), &d, sizeof(d)));
+    for (int i = 0; i < 3; ++i) launch(v, p);
+    CK(hipDeviceSynchronize());
+    std::vector<long long> h((size_t)nwg * 8);
+    CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    double a = 0, b = 0, c = 0; long long tmin = 1LL << 62, tmax = 0;
+    for (int w = 0; w < nwg; ++w) {
+        const long long* t = &h[(size_t)w * 8];
+        a += (double)(t[1] - t[0]); b += (double)(t[2] - t[1]); c += (double)(t[3] - t[2]);
+        tmin = t[0] < tmin ? t[0] : tmin; tmax = t[3] > tmax ? t[3] : tmax;
+    }
+    printf("    phases of %-30s workgroups %d: start->first tile %.0f, K loop %.0f, epilogue %.0f ticks (mean per workgroup); kernel span %lld ticks\n",
+           v.name, nwg, a / nwg, b / nwg, c / nwg, tmax - tmin);
+    long long* z = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(cream::gemm::g_gemm_prof), &z, sizeof(z)));
+    hipFree(d);
+}
+
 __global__ void gelu_accuracy(float* out) {
     float worst_g = 0.f, worst_d = 0.f;
     for (int i = threadIdx.x; i < 200000; i += blockDim.x) {
@@ -317,6 +340,7 @@ int main(int argc, char** argv)
             const bool bad = hm[0] > 0.02f || hm[1] > 0.02f || hm[2] > 1e-3f;
             printf("    %-34s %7.1f us %6.0f TF/s  %5.2fx lib   err out %.2e gelu %.2e colsum %.2e %s\n", v.name, us, fl / us / 1e6,
                    lib_us > 0 ? lib_us / us : 0.0, hm[0], hm[1], hm[2], bad ? " <-- WRONG" : "");
+            if (getenv("GEMM_PHASES")) phase_profile(v, p);
         }
         hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dh); hipFree(dcs);
         fflush(stdout);
