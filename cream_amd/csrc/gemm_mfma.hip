@@ -24,17 +24,33 @@ namespace {
 using namespace cream;
 using namespace cream::gemm;
 
+int num_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// persistent launch: as many workgroups as the chip holds at once (OCC per CU, a multiple of 8 so that a
+// workgroup's tiles stay on its XCD), or one per tile if there are fewer tiles.  Same-box A/B of the step with
+// the same kernel launched one tile per workgroup: 10.97 -> 10.86 ms; per GEMM against the previous kernel
+// 3-8 % (profiles/r02_gemm_probe.txt)
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
     if (p.N >= 640) {
-        constexpr int BM = 128, BN = 128;
-        const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, 2>), dim3(grid), dim3(256), 0, st, p);
+        constexpr int BM = 128, BN = 128, OCC = 2;
+        const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
     } else {
-        constexpr int BM = 128, BN = 64;
-        const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, 3>), dim3(grid), dim3(256), 0, st, p);
+        constexpr int BM = 128, BN = 64, OCC = 3;
+        const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
     }
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }

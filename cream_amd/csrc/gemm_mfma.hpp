@@ -102,14 +102,20 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
 }
 
-__host__ __device__ constexpr int nt_lds_bytes(int BM, int BN, int NST) {
-    return NST * (BM + BN) * 64 * 2 > BM * (BN + 4) * 4 ? NST * (BM + BN) * 64 * 2 : BM * (BN + 4) * 4;
-}
+__host__ __device__ constexpr int nt_lds_bytes(int BM, int BN, int NST) { return NST * (BM + BN) * 64 * 2; }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BM x BN tile, WM x WN waves, NST LDS stages (prefetch distance NST - 1 K-steps, counted vmcnt: the
 // loads of later steps stay in flight across the per-step barrier), OCC = workgroups per CU wanted.
+//
+// PERSISTENT tile loop: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0 or
+// gridDim.x == number of tiles, so that a workgroup's tiles stay on its XCD).  Phase stamps of the
+// one-tile-per-workgroup version: at K = 384 a workgroup spent a third of its life between
+// launch and its first staged tile and a sixth in the epilogue.  Here the first K-step of the NEXT tile is
+// requested before the epilogue of the current one — into stage 0, while the epilogue takes the accumulators
+// through the LDS of stage 1 in two half-tile passes (XOR-swizzled fp32 rows without padding: 64 rows x BN
+// floats are exactly one stage) — so its latency hides behind the epilogue instead of idling the workgroup.
 template <int BM, int BN, int WM, int WN, int NST, int EPI, int OCC>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const NtParams p)
 {
@@ -119,43 +125,48 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     constexpr int TM = WTM / 32, TN = WTN / 32;                 // MFMA tiles per wave
     constexpr int STAGE = (BM + BN) * BK;                       // bf16 elements per stage
     constexpr int NPIECE = (BM + BN) / 8 / NW;                  // 1-KB pieces (8 rows) per wave and stage
-    constexpr int CP = BN + 4;                                  // fp32 pitch of the epilogue tile
+    constexpr int HM = BM / 2;                                  // rows of one epilogue pass
+    constexpr int NCH = BN / 4;                                 // 4-float chunks per epilogue row
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
-    static_assert(NST >= 2 && NST <= 4, "stages");
-    __shared__ __attribute__((aligned(1024))) char smem[nt_lds_bytes(BM, BN, NST)];
+    static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
+    static_assert(WM == 2 && HM * BN * 4 <= STAGE * 2, "one epilogue pass = the rows of one wave row, inside one stage");
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE * 2];
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
-    float* const ctile = reinterpret_cast<float*>(smem);
+    float* const ctile = reinterpret_cast<float*>(smem + STAGE * 2);           // stage 1
 
     GPROF(0);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int ntn = (p.N + BN - 1) / BN;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+    const int ntn = (p.N + BN - 1) / BN, ntiles = ntn * ((p.M + BM - 1) / BM);
     const int K = p.K;
 
-    // ---- per-lane sources of this wave's pieces (row + this lane's k-chunk; the K offset moves per step)
-    const uint16_t* src[NPIECE];
+    // ---- per-lane sources of this wave's pieces for a tile (row + this lane's k-chunk; the K offset moves per step)
     int cch[NPIECE];                                            // the k-chunk (8 values) this lane fetches
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int piece = wave + NW * i, row = piece * 8 + (lane >> 3);
+        const int row = (wave + NW * i) * 8 + (lane >> 3);
         cch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
-        if (row < BM) {
-            src[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + cch[i];
-        } else {
-            const int n = min(n0 + row - BM, p.N - 1);
-            const int seg = (n >= p.nseg) + (n >= 2 * p.nseg);  // at most 3 row segments (q | k | v): no division
-            src[i] = p.B + seg * p.nseg_stride + (int64_t)(n - seg * p.nseg) * p.ldb + cch[i];
-        }
     }
+    auto sources = [&](const uint16_t* (&src)[NPIECE], int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int piece = wave + NW * i, row = piece * 8 + (lane >> 3);
+            if (row < BM) {
+                src[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + cch[i];
+            } else {
+                const int n = min(n0 + row - BM, p.N - 1);
+                const int seg = (n >= p.nseg) + (n >= 2 * p.nseg);  // at most 3 row segments (q | k | v): no division
+                src[i] = p.B + seg * p.nseg_stride + (int64_t)(n - seg * p.nseg) * p.ldb + cch[i];
+            }
+        }
+    };
     // TAIL: the last K-step of a K that is not a multiple of 64 — chunks beyond K re-read the last
     // valid chunk (their products are zeroed in `step`), so no load leaves the row.
     // kb: wave-uniform K offset of the B operand for the step being issued (contraction segments)
     int64_t kb = 0;
     int kin = 0;                                                // position inside the current segment
-    auto issue = [&](int k0, int buf, auto tail) {
+    auto issue = [&](const uint16_t* const (&src)[NPIECE], int k0, int buf, auto tail) {
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
             const bool isA = i < BM / 8 / NW;                    // pieces wave + NW i < BM / 8 hold A rows
@@ -175,10 +186,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     };
 
     f32x16 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // one K-step from stage `buf`; vc = valid 8-wide chunks (8 unless TAIL).  Fragments are double
     // buffered in registers: the reads of sub-step ks+1 are issued BEFORE the MFMAs of sub-step ks
@@ -224,144 +231,174 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     };
     using No = std::integral_constant<bool, false>;
     using Yes = std::integral_constant<bool, true>;
-
-    // ---- main loop: at the top of step s the loads of steps s .. s+D-1 are in flight (D = NST - 1);
-    //      wait for step s only (counted vmcnt), barrier (stage (s-1) % NST is then free for everyone),
-    //      issue step s+D into it, multiply step s.  Raw s_barrier: __syncthreads() would drain vmcnt.
-    constexpr int D = NST - 1;
     const int nfull = K / BK, rem = K % BK, nk = nfull + (rem ? 1 : 0);
-    auto issue_step = [&](int s) {                              // s < nk
-        if (s < nfull) issue(s * BK, s % NST, No{}); else issue(s * BK, s % NST, Yes{});
-    };
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nk) issue_step(s);
-    auto top_of_step = [&](int s) {
-        const int later = min(D - 1, nk - 1 - s);               // load groups younger than step s's
-        if (later >= 2) wait_vmcnt<2 * NPIECE>();
-        else if (later == 1) wait_vmcnt<NPIECE>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + D < nk) issue_step(s + D);
-    };
-    for (int s = 0; s < nfull; ++s) {                           // (the tail step lives outside the loop: one
-        top_of_step(s);                                         //  accumulator live range, no phi copies)
-        if (s == 0) GPROF(1);
-        step(s % NST, 8, No{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (rem) {
-        top_of_step(nfull);
-        step(nfull % NST, rem >> 3, Yes{});
-    }
 
-    GPROF(2);
-    // ---- epilogue: accumulators -> LDS (fp32, [BM][BN + 4]) -> (row, 8 columns) chunks -------------
+    // epilogue geometry: a thread owns an 8-column chunk of rows r0, r0 + RPP, ... of each half tile
     constexpr int CPR = BN / 8;                                 // chunks per tile row
     constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
+    constexpr int NJ = HM / RPP;                                // rows per thread and half
     const int cc = tid % CPR, r0 = tid / CPR;
-    const int n = n0 + cc * 8;
-    const bool ncol_ok = n < p.N;                               // N % 8 == 0: a chunk is all in or all out
-    // side inputs of this thread's chunks are requested NOW: their latency hides behind the LDS round trip
-    // of the accumulators instead of being paid once per row inside the store loop
-    u32x4v auxv[EPI == EPI_MUL_COLSUM ? BM / RPP : 1];
-    if constexpr (EPI == EPI_MUL_COLSUM) {
+
+    int orig = blockIdx.x;
+    const uint16_t* src[NPIECE];
+    int t = xcd_remap(orig, ntiles);
+    int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+    sources(src, m0, n0);
+    if (nk > 0) { if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{}); }
+
+    for (;;) {
 #pragma unroll
-        for (int j = 0; j < BM / RPP; ++j) {
-            const int m = m0 + r0 + j * RPP;
-            auxv[j] = (m < p.M && ncol_ok) ? *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n) : u32x4v{0, 0, 0, 0};
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+        // ---- main loop: at the top of step s the loads of step s are in flight (the only group); wait for them,
+        //      barrier (the other stage is then free for everyone — on the first step of a tile that is the
+        //      previous tile's epilogue LDS), issue step s+1 into it, multiply step s.  Raw s_barrier:
+        //      __syncthreads() would drain vmcnt.
+        auto top_of_step = [&](int s) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + 1 < nk) { if (s + 1 < nfull) issue(src, (s + 1) * BK, (s + 1) & 1, No{}); else issue(src, (s + 1) * BK, (s + 1) & 1, Yes{}); }
+        };
+        for (int s = 0; s < nfull; ++s) {                       // (the tail step lives outside the loop: one
+            top_of_step(s);                                     //  accumulator live range, no phi copies)
+            if (s == 0) GPROF(1);
+            step(s & 1, 8, No{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-    }
-    u32x4v braw = u32x4v{0, 0, 0, 0};
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        if (p.bias && ncol_ok) braw = *reinterpret_cast<const u32x4v*>(p.bias + n);
-    }
-    __syncthreads();                                            // every wave is done with the stages
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int ml = wm * WTM + tm * 32 + c32;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int nl = wn * WTN + tn * 32 + 8 * r4 + 4 * g;
-                *reinterpret_cast<f32x4v*>(ctile + ml * CP + nl) =
-                    f32x4v{acc[tn][tm][4 * r4], acc[tn][tm][4 * r4 + 1], acc[tn][tm][4 * r4 + 2], acc[tn][tm][4 * r4 + 3]};
-            }
+        if (rem) {
+            top_of_step(nfull);
+            step(nfull & 1, rem >> 3, Yes{});
         }
-    __syncthreads();
-    float bv[8];
+        GPROF(2);
+
+        // ---- next tile: its first K-step goes to stage 0 now, behind a barrier (every wave is done with the stages)
+        const int n = n0 + cc * 8;
+        const bool ncol_ok = n < p.N;                           // N % 8 == 0: a chunk is all in or all out
+        const int cur_m0 = m0, cur_n0 = n0;
+        const int next = orig + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        __syncthreads();
+        if (has_next) {
+            orig = next;
+            t = xcd_remap(orig, ntiles);
+            m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
+            sources(src, m0, n0);
+            kb = 0; kin = 0;
+            if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{});
+        }
+
+        // ---- epilogue: two passes of HM rows: accumulators -> LDS (fp32, swizzled [HM][BN]) -> (row, 8 columns) chunks
+        u32x4v braw = u32x4v{0, 0, 0, 0};
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+            if (p.bias && ncol_ok) braw = *reinterpret_cast<const u32x4v*>(p.bias + n);
+        }
+        float bv[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        bv[2 * e] = __uint_as_float(braw[e] << 16);
-        bv[2 * e + 1] = __uint_as_float(braw[e] & 0xFFFF0000u);
-    }
-    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < 4; ++e) {
+            bv[2 * e] = __uint_as_float(braw[e] << 16);
+            bv[2 * e + 1] = __uint_as_float(braw[e] & 0xFFFF0000u);
+        }
+        float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < BM / RPP; ++j) {
-        const int row = r0 + j * RPP, m = m0 + row;
-        if (m >= p.M || !ncol_ok) continue;
-        const f32x4v lo = *reinterpret_cast<const f32x4v*>(ctile + row * CP + cc * 8);
-        const f32x4v hi = *reinterpret_cast<const f32x4v*>(ctile + row * CP + cc * 8 + 4);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        uint16_t* o = p.out + (int64_t)m * p.ldo + n;
-        if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
+        for (int half = 0; half < 2; ++half) {
+            // side inputs of this thread's chunks are requested before the LDS round trip of the accumulators
+            u32x4v auxv[EPI == EPI_MUL_COLSUM ? NJ : 1];
+            if constexpr (EPI == EPI_MUL_COLSUM) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bv[e];
-            *reinterpret_cast<u32x4v*>(o) =
-                u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])};
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
-            // fc1 under autocast yields bf16 h; gelu runs in fp32 ON that bf16 value and casts back
-            // (supernet_transformer.py:14-16, :276-277).  gelu'(h) = Phi(h) + h phi(h) reuses Phi and the
-            // exponential: it is written INSTEAD of h (the backward needs nothing else of h).
-            u32x4v pb, gb;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t hb = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
-                const float h0 = __uint_as_float(hb << 16), h1 = __uint_as_float(hb & 0xFFFF0000u);
-                float c0, e0, c1, e1;
-                phi_parts(h0, c0, e0);
-                phi_parts(h1, c1, e1);
-                gb[e] = f2bf_pair(h0 * c0, h1 * c1);
-                pb[e] = f2bf_pair(fmaf(h0 * 0.3989422804014327f, e0, c0), fmaf(h1 * 0.3989422804014327f, e1, c1));
-            }
-            if (n + 8 > p.nvalid) {                             // padded columns: exact zeros (their gradients vanish)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t keep = (n + 2 * e < p.nvalid ? 0x0000FFFFu : 0u) | (n + 2 * e + 1 < p.nvalid ? 0xFFFF0000u : 0u);
-                    pb[e] &= keep;
-                    gb[e] &= keep;
+                for (int j = 0; j < NJ; ++j) {
+                    const int m = cur_m0 + half * HM + r0 + j * RPP;
+                    auxv[j] = (m < p.M && ncol_ok) ? *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n) : u32x4v{0, 0, 0, 0};
                 }
             }
-            *reinterpret_cast<u32x4v*>(o) = pb;
-            *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
-        } else {   // EPI_MUL_COLSUM
-            const u32x4v fb = auxv[j];
-            u32x4v db;
+            if (half) __syncthreads();                          // pass 0 has been read
+            if (wm == half) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                db[e] = f2bf_pair(v[2 * e] * __uint_as_float(fb[e] << 16), v[2 * e + 1] * __uint_as_float(fb[e] & 0xFFFF0000u));
-                cs[2 * e] += __uint_as_float(db[e] << 16);              // sums of the ROUNDED values written
-                cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const int ml = tm * 32 + c32;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int ch = (wn * WTN + tn * 32 + 8 * r4 + 4 * g) >> 2;
+                            *reinterpret_cast<f32x4v*>(ctile + ml * BN + ((ch ^ (ml & (NCH - 1))) << 2)) =
+                                f32x4v{acc[tn][tm][4 * r4], acc[tn][tm][4 * r4 + 1], acc[tn][tm][4 * r4 + 2], acc[tn][tm][4 * r4 + 3]};
+                        }
+                    }
             }
-            *reinterpret_cast<u32x4v*>(o) = db;
-        }
-    }
-    if constexpr (EPI == EPI_MUL_COLSUM) {
-        __syncthreads();                                        // the fp32 tile has been consumed
-        float* red = ctile;                                     // [RPP][BN]
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[r0 * BN + cc * 8 + e] = cs[e];
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-            float s = 0.f;
+            for (int j = 0; j < NJ; ++j) {
+                const int row = r0 + j * RPP, m = cur_m0 + half * HM + row;
+                if (m >= p.M || !ncol_ok) continue;
+                const int swz = row & (NCH - 1);
+                const f32x4v lo = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (((2 * cc) ^ swz) << 2));
+                const f32x4v hi = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (((2 * cc + 1) ^ swz) << 2));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                uint16_t* o = p.out + (int64_t)m * p.ldo + n;
+                if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
 #pragma unroll
-            for (int r = 0; r < RPP; ++r) s += red[r * BN + tid];   // fixed order
-            p.colsum[(int64_t)(m0 / BM) * p.N + n0 + tid] = s;
+                    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                    *reinterpret_cast<u32x4v*>(o) =
+                        u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])};
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+                    // fc1 under autocast yields bf16 h; gelu runs in fp32 ON that bf16 value and casts back
+                    // (supernet_transformer.py:14-16, :276-277).  gelu'(h) = Phi(h) + h phi(h) reuses Phi and the
+                    // exponential: it is written INSTEAD of h (the backward needs nothing else of h).
+                    u32x4v pb, gb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t hb = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
+                        const float h0 = __uint_as_float(hb << 16), h1 = __uint_as_float(hb & 0xFFFF0000u);
+                        float c0, e0, c1, e1;
+                        phi_parts(h0, c0, e0);
+                        phi_parts(h1, c1, e1);
+                        gb[e] = f2bf_pair(h0 * c0, h1 * c1);
+                        pb[e] = f2bf_pair(fmaf(h0 * 0.3989422804014327f, e0, c0), fmaf(h1 * 0.3989422804014327f, e1, c1));
+                    }
+                    if (n + 8 > p.nvalid) {                     // padded columns: exact zeros (their gradients vanish)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t keep = (n + 2 * e < p.nvalid ? 0x0000FFFFu : 0u) | (n + 2 * e + 1 < p.nvalid ? 0xFFFF0000u : 0u);
+                            pb[e] &= keep;
+                            gb[e] &= keep;
+                        }
+                    }
+                    *reinterpret_cast<u32x4v*>(o) = pb;
+                    *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
+                } else {   // EPI_MUL_COLSUM
+                    const u32x4v fb = auxv[j];
+                    u32x4v db;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        db[e] = f2bf_pair(v[2 * e] * __uint_as_float(fb[e] << 16), v[2 * e + 1] * __uint_as_float(fb[e] & 0xFFFF0000u));
+                        cs[2 * e] += __uint_as_float(db[e] << 16);              // sums of the ROUNDED values written
+                        cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
+                    }
+                    *reinterpret_cast<u32x4v*>(o) = db;
+                }
+            }
         }
+        if constexpr (EPI == EPI_MUL_COLSUM) {
+            __syncthreads();                                    // the fp32 half tile has been consumed
+            float* red = ctile;                                 // [RPP][BN]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[r0 * BN + cc * 8 + e] = cs[e];
+            __syncthreads();
+            if (tid < BN && cur_n0 + tid < p.N) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) sum += red[r * BN + tid];   // fixed order
+                p.colsum[(int64_t)(cur_m0 / BM) * p.N + cur_n0 + tid] = sum;
+            }
+        }
+        GPROF(3);
+        if (!has_next) break;
+        // (the first top_of_step of the next tile starts with a barrier: nobody loads into stage 1 — this
+        //  epilogue's LDS — before every thread is past its reads)
     }
-    GPROF(3);
 }
 
 
