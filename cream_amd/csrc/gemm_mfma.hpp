@@ -432,13 +432,16 @@ __device__ __forceinline__ bf16x4 tr16(const uint16_t* p) {
         reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p)));
 }
 
-template <int OCC>
+// BM tokens per step, NST LDS stages (NST - 1 steps of loads in flight across the per-step barrier, counted vmcnt)
+template <int OCC, int BM = 64, int NST = 2>
 __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
 {
-    constexpr int BT = 128, BM = 64;                            // output tile edge, tokens per step
+    constexpr int BT = 128;                                     // output tile edge
     constexpr int STAGE = 2 * BM * BT;                          // bf16 elements per stage ([dY | X] tiles)
     constexpr int NPIECE = 2 * BM / 4 / 4;                      // 1-KB pieces (4 rows of 256 B) per wave and stage
-    __shared__ __attribute__((aligned(1024))) uint16_t lds[2 * STAGE];
+    constexpr int PPO = BM / 4;                                 // pieces per operand tile
+    static_assert(BM % 16 == 0 && NPIECE >= 2 && NST >= 2 && NST <= 4, "steps");
+    __shared__ __attribute__((aligned(1024))) uint16_t lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
@@ -458,17 +461,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     int rowin[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int piece = wave + 4 * i, r = (piece & 15) * 4 + (lane >> 4);     // token row inside the step
+        const int piece = wave + 4 * i, r = (piece % PPO) * 4 + (lane >> 4);    // token row inside the step
         const int c = (lane & 15) ^ ((r & 3) << 2);                             // source chunk of this LDS position
         rowin[i] = r;
-        if (piece < 16) src[i] = p.dY + min(n0 + c * 8, p.N - 8);               // N, K % 8 == 0: whole chunks
+        if (piece < PPO) src[i] = p.dY + min(n0 + c * 8, p.N - 8);              // N, K % 8 == 0: whole chunks
         else src[i] = p.X + min(k0 + c * 8, p.K - 8);
     }
     auto issue = [&](int step, int buf) {
         const int m0 = step * BM;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
-            const bool isY = i < 4;                                               // pieces wave + 4 i < 16
+            const bool isY = i < NPIECE / 2;                                      // pieces wave + 4 i < PPO
             const int m = min(m0 + rowin[i], p.M - 1);
             const uint16_t* s = src[i] + (int64_t)m * (isY ? p.ldy : p.ldx);
             __builtin_amdgcn_global_load_lds(
@@ -539,17 +542,24 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     // the token tail (rows beyond M: only the very last step of the last split) is handled after it
     const bool tail = s_hi > s_lo && s_hi * BM > p.M;
     const int s_full = tail ? s_hi - 1 : s_hi;
+    constexpr int D = NST - 1;
     auto run = [&](auto with_bias) {
-        if (s_lo < s_hi) issue(s_lo, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (s_lo + d < s_hi) issue(s_lo + d, d);
         for (int st = s_lo; st < s_full; ++st) {
-            const int buf = (st - s_lo) & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (st + 1 < s_hi) issue(st + 1, buf ^ 1);
+            const int buf = (st - s_lo) % NST;
+            const int later = min(D - 1, s_hi - 1 - st);            // load groups younger than this step's
+            if (later >= 2) wait_vmcnt<2 * NPIECE>();
+            else if (later == 1) wait_vmcnt<NPIECE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                           // (raw: __syncthreads() would drain vmcnt)
+            asm volatile("" ::: "memory");
+            if (st + D < s_hi) issue(st + D, (st + D - s_lo) % NST);
             step(buf, with_bias);
         }
         if (tail) {
-            const int buf = (s_full - s_lo) & 1;
+            const int buf = (s_full - s_lo) % NST;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             uint16_t* Yt = lds + buf * STAGE;                   // zero the token rows beyond M in both tiles

@@ -203,16 +203,22 @@ static void tn_tests(const char* only) {
         ref_tn<<<(unsigned)((nw + 255) / 256), 256>>>(dref, dbref, p);
         CK(hipMemset(dparts, 0xFF, nw * 4 * t.S)); CK(hipMemset(dbias, 0xFF, (size_t)t.N * 4 * t.S)); CK(hipMemset(dmax, 0, 16));
         const int grid = ((t.N + 127) / 128) * ((t.K + 127) / 128) * t.S;
-        hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
-        check_tn<<<(unsigned)((nw + 255) / 256), 256>>>(dmax, dref, dbref, p);
-        float hm[4]; CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
-        hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, 0, p);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        const double us = ms(e0, e1) / 20 * 1e3, fl = 2.0 * t.M * t.N * t.K;
-        printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  %7.1f us %6.0f TF/s  err dW %.2e bias %.2e %s\n", t.what, t.M, t.N, t.K, t.S, grid, us,
-               fl / us / 1e6, hm[0], hm[1], (hm[0] > 1e-3f || hm[1] > 1e-3f) ? " <-- WRONG" : "");
+        struct TV { const char* name; void (*k)(const TnParams); };
+        const TV tvs[] = {{"64 tok x 2 stages occ2", gemm_tn_kernel<2, 64, 2>}, {"32 tok x 4 stages occ2", gemm_tn_kernel<2, 32, 4>},
+                          {"32 tok x 3 stages occ3", gemm_tn_kernel<3, 32, 3>}, {"32 tok x 2 stages occ3", gemm_tn_kernel<3, 32, 2>}};
+        for (const TV& tv : tvs) {
+            CK(hipMemset(dparts, 0xFF, nw * 4 * t.S)); CK(hipMemset(dbias, 0xFF, (size_t)t.N * 4 * t.S)); CK(hipMemset(dmax, 0, 16));
+            hipLaunchKernelGGL(tv.k, dim3(grid), dim3(256), 0, 0, p);
+            check_tn<<<(unsigned)((nw + 255) / 256), 256>>>(dmax, dref, dbref, p);
+            float hm[4]; CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(tv.k, dim3(grid), dim3(256), 0, 0, p);
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(tv.k, dim3(grid), dim3(256), 0, 0, p);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            const double us = ms(e0, e1) / 20 * 1e3, fl = 2.0 * t.M * t.N * t.K;
+            printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  %-24s %7.1f us %6.0f TF/s  err dW %.2e bias %.2e %s\n", t.what, t.M, t.N, t.K, t.S, grid,
+                   tv.name, us, fl / us / 1e6, hm[0], hm[1], (hm[0] > 1e-3f || hm[1] > 1e-3f) ? " <-- WRONG" : "");
+        }
         hipFree(dy); hipFree(dx); hipFree(dparts); hipFree(dbias); hipFree(dref); hipFree(dbref);
     }
 }
