@@ -46,18 +46,20 @@ def _restatement(qkv, scale, mods):
     return out.transpose(1, 2).reshape(q.shape[0], L, -1)
 
 
-CASES = [("k", True, 50), ("k", False, 197), ("q", True, 50), ("v", True, 50), ("qk", True, 197), ("kv", False, 50),
-         ("qkv", True, 197), ("qkv", False, 50), ("k", True, 577), ("qkv", True, 577), ("", True, 50)]
+CASES = [("k", True, 50, "product"), ("k", False, 197, "product"), ("q", True, 50, "product"), ("v", True, 50, "product"),
+         ("qk", True, 197, "product"), ("kv", False, 50, "product"), ("qkv", True, 197, "product"), ("qkv", False, 50, "product"),
+         ("k", True, 577, "product"), ("qkv", True, 577, "product"), ("", True, 50, "product"),
+         ("qkv", True, 197, "euc"), ("qkv", False, 197, "quant"), ("k", True, 196, "euc")]      # 196: skip = 0 (no class token)
 
 
-@pytest.mark.parametrize("rpe_on,shared,L", CASES)
-def test_fused_irpe_attention_matches_restatement(rpe_on, shared, L):
+@pytest.mark.parametrize("rpe_on,shared,L,method", CASES)
+def test_fused_irpe_attention_matches_restatement(rpe_on, shared, L, method):
     from cream_amd import irpe as I, irpe_fused
     B, H = 2, 3
     torch.manual_seed(11)
     mods = [None, None, None]
     if rpe_on:
-        cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=shared, skip=1, rpe_on=rpe_on)
+        cfg = I.get_rpe_config(ratio=1.9, method=method, mode="ctx", shared_head=shared, skip=0 if L == 196 else 1, rpe_on=rpe_on)
         mods = list(I.build_rpe(cfg, head_dim=64, num_heads=H))
     for m in mods:
         if m is not None:
@@ -79,10 +81,14 @@ def test_fused_irpe_attention_matches_restatement(rpe_on, shared, L):
     for name, a, b in zip([c for c, m in zip("qkv", mods) if m is not None], got[1:], want[1:]):
         errs["dW" + name] = max_rel(a.float(), b.float())
         assert a.shape == b.shape
-    print(f"[fused irpe {rpe_on or 'none'} shared={shared} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
+    print(f"[fused irpe {rpe_on or 'none'} {method} shared={shared} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
     assert all(torch.isfinite(t).all() for t in got)
+    # product (50 buckets): 2x the worst measured (6.5e-3: bf16 P, dS and lookups).  euclidean / quant at ratio 1.9 have 8
+    # buckets and ONE of them holds 85-95 % of all (query, key) pairs: its bucket gradient is a near-cancelling sum
+    # (sum_j dS_ij = 0 for a softmax), which amplifies the same bf16 noise — measured up to 2.6e-2 on the rpe_k table
+    bound = 1.3e-2 if method == "product" else 5e-2
     for k, v in errs.items():
-        assert v < 1.3e-2, (k, v, errs)                     # 2x the worst measured (6.5e-3: bf16 P, dS and lookups)
+        assert v < bound, (k, v, errs)
 
 
 def test_module_takes_the_fused_path_under_autocast():
