@@ -67,6 +67,8 @@ struct Args {
     short* sv;                        // (B, H, NP, 64) bucket sums of P (value side), bf16
     const float *wq, *wk, *wv;        // (H', 64, nb), (H', 64, nb), (H', nb, 64) fp32
     int64_t wq_hs, wk_hs, wv_hs;      // head strides (0: shared)
+    const float *bq, *bk;             // bias mode (irpe.py:622-624): (H', nb) tables, used when wq / wk is null
+    int64_t bq_hs, bk_hs;
     const uint8_t *idq, *idk, *idv;         // (NP, NP) query-major:  [i][j] = bucket_q[j][i], bucket_k[i][j], bucket_v[i][j]
     const uint8_t *idq_t, *idk_t, *idv_t;   // (NP, NP) key-major:    [j][i] of the same
     int B, H, L, NP, nb;
@@ -223,6 +225,14 @@ __device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, con
         row[32 + acc_row(r, g)] = f2bf(a1[r] * mul);
     }
 }
+// bias mode: the lookups do not depend on the token — every row of a [32][LBP] block is the head's bias table
+__device__ __forceinline__ void bias_rows_to_lds(short* scr, const float* bias, int nb, int lane) {
+    const int c32 = lane & 31, g = lane >> 5;
+    short* row = scr + c32 * LBP + g * 32;
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) row[e] = f2bf(g * 32 + e < nb ? bias[g * 32 + e] : 0.f);
+}
+
 // this lane's half of a bf16 lookup row (buckets ks*16 + g*8 .. +7, ks = 0..3) -> global row of 64
 __device__ __forceinline__ void lrow_to_global(short* dst, const short* row, int g) {
 #pragma unroll
@@ -314,7 +324,8 @@ __device__ __forceinline__ f32x16 score_tile(const short* rows, const F (&own)[4
 
 // rpe_q lookups of a staged key tile, shared by the four waves: waves 0 and 1 each compute one half of
 // the buckets.  Ends with a workgroup barrier.
-__device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const short* kb, float scale, int wave, int lane) {
+__device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const short* kb, float scale, int wave, int lane, bool ctx) {
+    if (!ctx) return;                                  // bias mode: both tile buffers were filled once, nothing changes per tile
     if (wave < 2) {
         const int c32 = lane & 31, g = lane >> 5;
         f32x16 acc = {};
@@ -369,8 +380,11 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     if constexpr (!HV) sv4 = rows_load(vp, a.sn, 0, a.L, true);
     if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
     if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
-    if constexpr (HK) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);
-    if constexpr (HQ) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+    if constexpr (HK) { if (a.wk) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }
+    if constexpr (HQ) {
+        if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+        else if (wave < 2) bias_rows_to_lds(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);   // both tile buffers
+    }
     if constexpr (HV) {
         stage_table_T(wvT, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);            // Wv (nb x 64): dst[d][u]
         for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f;
@@ -381,10 +395,13 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     if constexpr (HQ) ids_store(smem + L::idq, siq);
     __syncthreads();
     if constexpr (HK) {
-        if (active) lookups_to_lds(lkw, wkT, qs, 1.f, lane);
+        if (active) {
+            if (a.wk) lookups_to_lds(lkw, wkT, qs, 1.f, lane);
+            else bias_rows_to_lds(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
+        }
         wave_lds_fence();
     }
-    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
+    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     f32x16 o[2] = {f32x16{}, f32x16{}};
     float l4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                 if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
                 if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
                 __syncthreads();
-                if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+                if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
             }
         }
         l4[0] = lrun;                                  // (lrun already holds this lane's half; halves are added below)
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
         if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
         if constexpr (HV) { if (with_v) ids_store(smem + L::idv + nxt * 128 * IDP, siv); }
         __syncthreads();
-        if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+        if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
     }
     m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     m = fmaxf(m, __shfl_xor(m, 32));
@@ -523,7 +540,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
             if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
             if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
             __syncthreads();
-            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
         }
     }
     }
@@ -627,14 +644,18 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
     if (active && g == 0) a.delta[(int64_t)bh * a.NP + qi] = delta;
     const float lseL = qok ? a.lse[(int64_t)bh * a.L + qi] * LOG2E : INFINITY;
 
-    if constexpr (HK) stage_table_T(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);       // [bucket][d]
+    if constexpr (HK) { if (a.wk) stage_table_T(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }      // [bucket][d]
     if constexpr (HV) stage_table_R(tab1, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);       // [bucket][d]
-    if constexpr (HQ) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+    if constexpr (HQ) {
+        if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
+        else if (wave < 2) bias_rows_to_lds(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+    }
     if constexpr (HK) { for (int i = lane; i < 32 * LKP; i += 64) dlkw[i] = 0.f; }
     __syncthreads();
     if (active) {
         if constexpr (HK) {
-            lookups_to_lds(lkw, tab0, qs, 1.f, lane);
+            if (a.wk) lookups_to_lds(lkw, tab0, qs, 1.f, lane);
+            else bias_rows_to_lds(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
             wave_lds_fence();
             lrow_to_global(a.lkg + ((int64_t)bh * a.NP + qi) * 64, lkw + c32 * LBP, g);
         }
@@ -666,7 +687,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
         if (t < NT) issue(st[t], t);
     commit(st[0], 0);
     __syncthreads();
-    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane);
+    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     // ---- key tiles ----------------------------------------------------------------------------------
     f32x16 dq[2] = {f32x16{}, f32x16{}};
@@ -710,15 +731,18 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
         if (t + 1 < NT) {
             commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
-            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane);
+            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
         }
     });
 
     // ---- dq += dLK Wk^T; bucket gradient rows out -------------------------------------------------
     if constexpr (HK) {
-        __syncthreads();                               // every wave is done with the tile area
-        stage_table_R(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);      // [d][bucket]
-        __syncthreads();
+        const bool ctx = a.wk != nullptr;              // bias mode: no dependence on q, only the bucket gradient rows leave
+        if (ctx) {
+            __syncthreads();                           // every wave is done with the tile area
+            stage_table_R(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb);  // [d][bucket]
+            __syncthreads();
+        }
         if (active) {
             const float* row = dlkw + c32 * LKP;
             short* dst = a.dlk + ((int64_t)bh * a.NP + qi) * 64;
@@ -726,8 +750,10 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const F db = srow_frag(row, ks, g, 1.f);
                 *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = db;
-                dq[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dq[0]);
-                dq[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dq[1]);
+                if (ctx) {
+                    dq[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dq[0]);
+                    dq[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dq[1]);
+                }
             }
         }
     }
@@ -795,14 +821,18 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
         delta_s[i] = a.delta[(int64_t)bh * a.NP + i];
     }
     if constexpr (HQ) {
-        stage_table_T(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [bucket][d]
+        if (a.wq) stage_table_T(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [bucket][d]
         for (int i = lane; i < 32 * LKP; i += 64) dlqw[i] = 0.f;
         __syncthreads();
         if (active) {
-            F ksf[4];
+            if (a.wq) {
+                F ksf[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ksf[ks] = scaled(kf[ks], a.scale);
-            lookups_to_lds(lqw, tab0, ksf, 1.f, lane);                   // (k * scale) Wq (:82)
+                for (int ks = 0; ks < 4; ++ks) ksf[ks] = scaled(kf[ks], a.scale);
+                lookups_to_lds(lqw, tab0, ksf, 1.f, lane);               // (k * scale) Wq (:82)
+            } else {
+                bias_rows_to_lds(lqw, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+            }
             wave_lds_fence();
         }
     }
@@ -891,18 +921,23 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
 
     // ---- dk += s dLQ Wq^T; bucket gradient rows out ------------------------------------------------
     if constexpr (HQ) {
-        __syncthreads();
-        stage_table_R(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [d][bucket]
-        __syncthreads();
+        const bool ctx = a.wq != nullptr;
+        if (ctx) {
+            __syncthreads();
+            stage_table_R(tab0, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);  // [d][bucket]
+            __syncthreads();
+        }
         if (active) {
             const float* row = dlqw + c32 * LKP;
             short* dst = a.dlq + ((int64_t)bh * a.NP + kj) * 64;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = srow_frag(row, ks, g, 1.f);
-                const F db = srow_frag(row, ks, g, a.scale);
-                dk[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dk[0]);
-                dk[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dk[1]);
+                if (ctx) {
+                    const F db = srow_frag(row, ks, g, a.scale);
+                    dk[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dk[0]);
+                    dk[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dk[1]);
+                }
             }
         }
     }
@@ -998,7 +1033,8 @@ int check(const cream_irpe_attn_desc* d, bool bwd) {
     if (d->NP > 2048) return CREAM_ERR_TOO_LARGE;
     if (d->sn % 8 || d->sh % 8 || d->sb % 8 || !aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v) || !aligned16(d->out))
         return CREAM_ERR_BAD_ARG;
-    const bool hq = d->wq != nullptr, hk = d->wk != nullptr, hv = d->wv != nullptr;
+    const bool hq = d->wq != nullptr || d->bq != nullptr, hk = d->wk != nullptr || d->bk != nullptr, hv = d->wv != nullptr;
+    if ((d->wq && d->bq) || (d->wk && d->bk)) return CREAM_ERR_BAD_ARG;
     if ((hq && !d->idq) || (hk && !d->idk) || (hv && (!d->idv || !d->sv))) return CREAM_ERR_BAD_ARG;
     if ((hq && !aligned16(d->idq)) || (hk && !aligned16(d->idk)) || (hv && !aligned16(d->idv))) return CREAM_ERR_BAD_ARG;
     if (bwd) {
@@ -1017,6 +1053,7 @@ Args to_args(const cream_irpe_attn_desc* d) {
     a.out = (short*)d->out; a.lse = d->lse; a.sv = (short*)d->sv;
     a.wq = d->wq; a.wk = d->wk; a.wv = d->wv;
     a.wq_hs = d->wq_hs; a.wk_hs = d->wk_hs; a.wv_hs = d->wv_hs;
+    a.bq = d->bq; a.bk = d->bk; a.bq_hs = d->bq_hs; a.bk_hs = d->bk_hs;
     a.idq = d->idq; a.idk = d->idk; a.idv = d->idv;
     a.idq_t = d->idq_t; a.idk_t = d->idk_t; a.idv_t = d->idv_t;
     a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale;
@@ -1029,7 +1066,7 @@ Args to_args(const cream_irpe_attn_desc* d) {
 
 template <template <bool, bool, bool> class Fn>
 int dispatch(const Args& a, hipStream_t st) {
-    const int key = (a.wq ? 4 : 0) | (a.wk ? 2 : 0) | (a.wv ? 1 : 0);
+    const int key = ((a.wq || a.bq) ? 4 : 0) | ((a.wk || a.bk) ? 2 : 0) | (a.wv ? 1 : 0);
     switch (key) {
         case 0: return Fn<false, false, false>::run(a, st);
         case 1: return Fn<false, false, true>::run(a, st);

@@ -7,9 +7,10 @@ HBM.  It takes the (B, L, 3, H, 64) bf16 output of the qkv linear as it is (q, k
 and returns (B, L, H*64) ready for the proj linear.
 
 `usable(...)` says whether a given RPEAttention configuration is covered: bf16 operands (autocast),
-head_dim 64, each rpe either absent or a contextual iRPE with at most 64 buckets (product: 50,
-euclidean / quant: <= 64), no attention dropout in training.  Everything else (bias mode, cross
-method, fp32) takes the composed path of cream_amd.rpe_attention on the HIP rpe_index operator.
+head_dim 64, each rpe either absent or an iRPE with at most 64 buckets (product: 50, euclidean /
+quant: <= 64) — contextual, or bias mode on q / k (the lookups are then the bias table itself,
+irpe.py:622-624) — no attention dropout in training.  Everything else (cross method, fp32) takes
+the composed path of cream_amd.rpe_attention on the HIP rpe_index operator.
 """
 import ctypes
 import os
@@ -48,14 +49,15 @@ def bucket_bytes(ids):
 
 
 def _term(rpe, L, device):
-    """-> (weight parameter, head stride, query-major ids, key-major ids, nb) of one rpe module."""
+    """-> (table parameter, head stride, query-major ids, key-major ids, nb, bias mode) of one rpe module."""
     if rpe is None:
         return None
     ids = rpe.bucket_ids_for(L, device)
     asis, tr = bucket_bytes(ids)
-    w = rpe.lookup_table_weight
-    hs = 0 if w.shape[0] == 1 else w.shape[1] * w.shape[2]
-    return w, hs, asis, tr, rpe.num_buckets
+    bias = rpe.mode == "bias"
+    w = rpe.lookup_table_bias if bias else rpe.lookup_table_weight
+    hs = 0 if w.shape[0] == 1 else w[0].numel()
+    return w, hs, asis, tr, rpe.num_buckets, bias
 
 
 def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active):
@@ -68,9 +70,10 @@ def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active):
     for r in rpes:
         if r is None:
             continue
-        if type(r) is not iRPE or r.mode != "contextual" or r.num_buckets > 64:
+        if type(r) is not iRPE or r.mode not in ("contextual", "bias") or r.num_buckets > 64:
             return False
-        if r.lookup_table_weight.dtype != torch.float32:
+        w = r.lookup_table_bias if r.mode == "bias" else r.lookup_table_weight
+        if w.dtype != torch.float32 or not w.is_contiguous():
             return False
         nbs.add(r.num_buckets)
     return len(nbs) <= 1
@@ -88,9 +91,17 @@ def _desc(qkv, scale, terms, out, lse, sv):
     tq, tk, tv = terms
     nb = 1
     if tq is not None:                       # rpe_q: bucket_q[j][i] is key-major as stored
-        d.wq, d.wq_hs, d.idq, d.idq_t, nb = tq[0].data_ptr(), tq[1], tq[3].data_ptr(), tq[2].data_ptr(), tq[4]
+        d.idq, d.idq_t, nb = tq[3].data_ptr(), tq[2].data_ptr(), tq[4]
+        if tq[5]:
+            d.bq, d.bq_hs = tq[0].data_ptr(), tq[1]
+        else:
+            d.wq, d.wq_hs = tq[0].data_ptr(), tq[1]
     if tk is not None:
-        d.wk, d.wk_hs, d.idk, d.idk_t, nb = tk[0].data_ptr(), tk[1], tk[2].data_ptr(), tk[3].data_ptr(), tk[4]
+        d.idk, d.idk_t, nb = tk[2].data_ptr(), tk[3].data_ptr(), tk[4]
+        if tk[5]:
+            d.bk, d.bk_hs = tk[0].data_ptr(), tk[1]
+        else:
+            d.wk, d.wk_hs = tk[0].data_ptr(), tk[1]
     if tv is not None:
         d.wv, d.wv_hs, d.idv, d.idv_t, nb = tv[0].data_ptr(), tv[1], tv[2].data_ptr(), tv[3].data_ptr(), tv[4]
     d.B, d.H, d.L, d.NP, d.nb = B, H, L, padded_len(L), nb
@@ -169,10 +180,13 @@ class _Fused(torch.autograd.Function):
             do_str = (L * H * 64, H * 64, 64)
             es_q = qkv.element_size()
             grads = [None, None, None]
-            if tq is not None:      # d lookup_table_weight(rpe_q) (H', 64, nb) = (scale k)^T dlq
-                g = table_grad(qkv.data_ptr() + qs[2] * es_q, q_str, dlq.data_ptr(), row_str, scale)
-                grads[0] = g
-            if tk is not None:      # (scale q)^T dlk
+            if tq is not None and tq[5]:   # bias mode: d lookup_table_bias (H', nb) = the bucket gradient rows summed
+                grads[0] = dlq[:, :, :L].sum((0, 2), dtype=torch.float32)
+            elif tq is not None:    # d lookup_table_weight(rpe_q) (H', 64, nb) = (scale k)^T dlq
+                grads[0] = table_grad(qkv.data_ptr() + qs[2] * es_q, q_str, dlq.data_ptr(), row_str, scale)
+            if tk is not None and tk[5]:
+                grads[1] = dlk[:, :, :L].sum((0, 2), dtype=torch.float32)
+            elif tk is not None:    # (scale q)^T dlk
                 grads[1] = table_grad(qkv.data_ptr(), q_str, dlk.data_ptr(), row_str, scale)
             if tv is not None:      # (H', nb, 64) = sv^T dout
                 grads[2] = table_grad(sv.data_ptr(), row_str, dout.data_ptr(), do_str, 1.0)
@@ -184,6 +198,9 @@ class _Fused(torch.autograd.Function):
             w, nb = t[0], t[4]
             if w.shape[0] == 1:
                 gpart = gpart.sum(0, keepdim=True)
+            if t[5]:
+                res.append(gpart[:, :nb].to(w.dtype).contiguous())
+                continue
             res.append((gpart[:, :, :nb] if transposed else gpart[:, :nb, :]).to(w.dtype).contiguous())
         return dqkv, None, res[0], res[1], res[2], None
 

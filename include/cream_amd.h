@@ -192,6 +192,10 @@ typedef struct cream_irpe_attn_desc {
     float* delta;                   /* (B, H, NP) scratch                                               */
     void *lkg, *gg;                 /* (B, H, NP, 64) bf16 scratch (needed with wk / wv)                 */
     void *dlk, *dlq;                /* (B, H, NP, 64) bf16 out: bucket gradients of rpe_k / rpe_q lookups */
+    /* bias mode of rpe_q / rpe_k (irpe.py:622-624: lookup_table_bias (H', nb), no dependence on q / k): give the
+     * table here INSTEAD of wq / wk; its gradient is the sum of the dlq / dlk rows over batch and tokens (caller) */
+    const float *bq, *bk;
+    int64_t bq_hs, bk_hs;
 } cream_irpe_attn_desc;
 
 int cream_irpe_padded_len(int L);

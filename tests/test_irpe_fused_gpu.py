@@ -1,7 +1,7 @@
 """Fused iRPE attention (csrc/irpe_attn.hip) on the MI355X against an fp32 restatement of
 RPEAttention.forward's core (rpe_vision_transformer.py:68-97 + irpe.py:585-687) evaluated on the SAME
 bf16-rounded inputs — forward, dq/dk/dv and the three lookup-table gradients — for every subset of
-rpe_q / rpe_k / rpe_v, shared and per-head tables, L = 50 / 197 / 577.  The pinned comparison with the
+rpe_q / rpe_k / rpe_v, shared and per-head tables, contextual and bias mode (irpe.py:622-624), L = 50 / 197 / 577.  The pinned comparison with the
 reference itself is tests/test_irpe_gpu.py::test_rpe_attention_L577_on_gpu (reference-made fixture; under
 autocast RPEAttention takes this kernel)."""
 import pytest
@@ -32,10 +32,17 @@ def _restatement(qkv, scale, mods):
         w = m.lookup_table_weight.float()
         return w[0] if w.shape[0] == 1 else w.unsqueeze(0)
 
-    if rk is not None:
+    def bias_of(m):                                                            # (1, H', L, L), irpe.py:622-624
+        return m.lookup_table_bias.float()[:, ids_of(m).flatten()].view(1, -1, L, L)
+
+    if rk is not None and rk.mode == "bias":
+        a = a + bias_of(rk)
+    elif rk is not None:
         lk = (qs @ w_of(rk)).to(torch.bfloat16).float()                        # the autocast matmul's output dtype
         a = a + lk.gather(-1, ids_of(rk).expand(*lk.shape[:2], L, L))
-    if rq is not None:
+    if rq is not None and rq.mode == "bias":
+        a = a + bias_of(rq).transpose(2, 3)
+    elif rq is not None:
         lq = ((k * scale) @ w_of(rq)).to(torch.bfloat16).float()
         a = a + lq.gather(-1, ids_of(rq).expand(*lq.shape[:2], L, L)).transpose(2, 3)
     p = a.softmax(-1)
@@ -49,29 +56,40 @@ def _restatement(qkv, scale, mods):
 CASES = [("k", True, 50, "product"), ("k", False, 197, "product"), ("q", True, 50, "product"), ("v", True, 50, "product"),
          ("qk", True, 197, "product"), ("kv", False, 50, "product"), ("qkv", True, 197, "product"), ("qkv", False, 50, "product"),
          ("k", True, 577, "product"), ("qkv", True, 577, "product"), ("", True, 50, "product"),
-         ("qkv", True, 197, "euc"), ("qkv", False, 197, "quant"), ("k", True, 196, "euc")]      # 196: skip = 0 (no class token)
+         ("qkv", True, 197, "euc"), ("qkv", False, 197, "quant"), ("k", True, 196, "euc"),      # 196: skip = 0 (no class token)
+         ("k", True, 197, "product", "bias"), ("qk", False, 197, "product", "bias"), ("q", False, 50, "quant", "bias"),
+         ("qkv", False, 577, "product", "bias")]                                                # bias q / k + contextual v
 
 
-@pytest.mark.parametrize("rpe_on,shared,L,method", CASES)
-def test_fused_irpe_attention_matches_restatement(rpe_on, shared, L, method):
+def _table(m):
+    return m.lookup_table_bias if m.mode == "bias" else m.lookup_table_weight
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_fused_irpe_attention_matches_restatement(case):
     from cream_amd import irpe as I, irpe_fused
+    rpe_on, shared, L, method = case[:4]
+    mode = case[4] if len(case) > 4 else "ctx"
     B, H = 2, 3
     torch.manual_seed(11)
     mods = [None, None, None]
     if rpe_on:
-        cfg = I.get_rpe_config(ratio=1.9, method=method, mode="ctx", shared_head=shared, skip=0 if L == 196 else 1, rpe_on=rpe_on)
+        kw = dict(ratio=1.9, method=method, shared_head=shared, skip=0 if L == 196 else 1)
+        cfg = I.get_rpe_config(mode=mode, rpe_on=rpe_on.replace("v", "") if mode == "bias" else rpe_on, **kw)
+        if mode == "bias" and "v" in rpe_on:          # bias mode does not exist on the value side (irpe.py:468-470)
+            cfg.rpe_v = I.get_rpe_config(mode="ctx", rpe_on="v", **kw).rpe_v
         mods = list(I.build_rpe(cfg, head_dim=64, num_heads=H))
     for m in mods:
         if m is not None:
             m.to(DEV)
             with torch.no_grad():
-                m.lookup_table_weight.copy_(0.3 * torch.randn_like(m.lookup_table_weight))
-            m.lookup_table_weight.requires_grad_()
+                _table(m).copy_(0.3 * torch.randn_like(_table(m)))
+            _table(m).requires_grad_()
     qkv = (0.8 * torch.randn(B, L, 3, H, 64, device=DEV)).to(torch.bfloat16).requires_grad_()
     gy = torch.randn(B, L, H * 64, device=DEV).to(torch.bfloat16)
     assert irpe_fused.usable(qkv.dtype, qkv.device, 64, L, mods, False)
     y = irpe_fused.attention(qkv, 0.125, *mods)
-    params = [m.lookup_table_weight for m in mods if m is not None]
+    params = [_table(m) for m in mods if m is not None]
     got = torch.autograd.grad(y, [qkv] + params, gy)
     ref = _restatement(qkv, 0.125, mods)
     want = torch.autograd.grad(ref, [qkv] + params, gy.float())
@@ -81,7 +99,7 @@ def test_fused_irpe_attention_matches_restatement(rpe_on, shared, L, method):
     for name, a, b in zip([c for c, m in zip("qkv", mods) if m is not None], got[1:], want[1:]):
         errs["dW" + name] = max_rel(a.float(), b.float())
         assert a.shape == b.shape
-    print(f"[fused irpe {rpe_on or 'none'} {method} shared={shared} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
+    print(f"[fused irpe {rpe_on or 'none'} {method} {mode} shared={shared} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
     assert all(torch.isfinite(t).all() for t in got)
     # product (50 buckets): 2x the worst measured (6.5e-3: bf16 P, dS and lookups).  euclidean / quant at ratio 1.9 have 8
     # buckets and ONE of them holds 85-95 % of all (query, key) pairs: its bucket gradient is a near-cancelling sum
