@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
                                                      const uint16_t* __restrict__ res, const float* __restrict__ sscale,
                                                      int rows_per_sample) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: row bases in SGPRs
     if (row >= M) return;
     const int nch = E >> 2;
     const float* xr = x + (int64_t)row * E;
@@ -111,15 +111,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
 // partial[p][0][c] = sum dy*xhat (dgamma), partial[p][1][c] = sum dy (dbeta) over its rows,
 // partial[p][2][c] = column sums of the bf16 values written to dxs (the bias gradient of the
 // projection whose output gradient dxs is), zero without dxs
+// PRE: 0 = loads as they are needed (x, dy; then dres after the row reductions); 1 = all three row operands requested
+// before the reductions; 2 = as 1, and the NEXT row's operands are requested before this row's reductions (two rows
+// in flight per wave).  Same arithmetic in the same order in all three.
 template <int MAXC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uint16_t* __restrict__ dxs,
+struct LnRowIn {
+    f32x4v x[MAXC], r[MAXC];
+    u32x2v dy[MAXC];
+    float mu, rs, sc;
+};
+
+template <int MAXC, bool WITH_RES>
+__device__ __forceinline__ void ln_row_request(LnRowIn<MAXC>& in, int row, int lane, int nch, int E,
+                                               const uint16_t* __restrict__ dy, const float* __restrict__ x,
+                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                               const float* __restrict__ dres, const float* __restrict__ sscale,
+                                               int rows_per_sample) {
+    // row base as an opaque scalar: keeps the accesses in the s[base] + v[lane offset] form (otherwise the loop is
+    // strength-reduced into per-array 64-bit vector addresses: +16 VGPRs and VALU adds per row)
+    const int64_t ro = (int64_t)__builtin_amdgcn_readfirstlane(row) * E;
+    const float* xr = x + ro;
+    const uint16_t* dyr = dy + ro;
+    const float* rr = dres + ro;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const unsigned c = lane + 64 * i;
+        if (c < (unsigned)nch) {
+            in.x[i] = *reinterpret_cast<const f32x4v*>(xr + 4u * c);
+            in.dy[i] = *reinterpret_cast<const u32x2v*>(dyr + 4u * c);
+            if (WITH_RES) in.r[i] = dres ? *reinterpret_cast<const f32x4v*>(rr + 4u * c) : f32x4v{0, 0, 0, 0};
+        }
+    }
+    in.mu = mean[row];
+    in.rs = rstd[row];
+    in.sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+}
+
+template <int MAXC, int PRE, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void ln_bwd_kernel(float* __restrict__ dx, uint16_t* __restrict__ dxs,
                                                      float* __restrict__ partial, const uint16_t* __restrict__ dy,
                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, const float* __restrict__ sscale,
                                                      int rows_per_sample, int M, int E) {
     __shared__ float red[4][MAXC * 256 + 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: row offsets then live in SGPRs and every access is base(s) + lane offset(v)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nch = E >> 2;
     f32x4v g[MAXC], ag[MAXC], ab[MAXC], as[MAXC];
 #pragma unroll
@@ -131,21 +168,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uin
         as[i] = f32x4v{0, 0, 0, 0};
     }
     const float invE = 1.f / (float)E;
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        const float* xr = x + (int64_t)row * E;
-        const uint16_t* dyr = dy + (int64_t)row * E;
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    LnRowIn<MAXC> nxt;
+    if (PRE == 2 && row < M)
+        ln_row_request<MAXC, true>(nxt, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+    for (; row < M; row += stride) {
+        LnRowIn<MAXC> in;
+        if (PRE == 2) {
+            in = nxt;
+            if (row + stride < M)
+                ln_row_request<MAXC, true>(nxt, row + stride, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+        } else {
+            ln_row_request<MAXC, PRE == 1>(in, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+        }
+        const float mu = in.mu, rs = in.rs;
         float xh[MAXC][4], d[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-                const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + 4 * c);
-                unpack_bf16x4(*reinterpret_cast<const u32x2v*>(dyr + 4 * c), d[i]);
+                unpack_bf16x4(in.dy[i], d[i]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[i][e] = (xv[e] - mu) * rs;
+                    xh[i][e] = (in.x[i][e] - mu) * rs;
                     ag[i][e] += d[i][e] * xh[i][e];
                     ab[i][e] += d[i][e];
                     const float dg = d[i][e] * g[i][e];
@@ -157,22 +204,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uin
         }
         s1 = wave_sum(s1) * invE;
         s2 = wave_sum(s2) * invE;
-        const float sc = sscale ? sscale[row / rows_per_sample] : 1.f;
+        const float sc = in.sc;
+        const int64_t ro = (int64_t)__builtin_amdgcn_readfirstlane(row) * E;
+        float* dxr = dx + ro;
+        uint16_t* dxsr = dxs + ro;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-                f32x4v r = dres ? *reinterpret_cast<const f32x4v*>(dres + (int64_t)row * E + 4 * c) : f32x4v{0, 0, 0, 0};
+            const unsigned c = lane + 64 * i;
+            if (c < (unsigned)nch) {
+                f32x4v r;
+                if (PRE == 0) r = dres ? *reinterpret_cast<const f32x4v*>(dres + ro + 4u * c) : f32x4v{0, 0, 0, 0};
+                else r = in.r[i];
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     r[e] += rs * (d[i][e] - s1 - xh[i][e] * s2);
                     o[e] = r[e] * sc;
                 }
-                *reinterpret_cast<f32x4v*>(dx + (int64_t)row * E + 4 * c) = r;
+                *reinterpret_cast<f32x4v*>(dxr + 4u * c) = r;
                 if (dxs) {
                     const u32x2v pk = pack_bf16x4(o);
-                    *reinterpret_cast<u32x2v*>(dxs + (int64_t)row * E + 4 * c) = pk;
+                    *reinterpret_cast<u32x2v*>(dxsr + 4u * c) = pk;
                     unpack_bf16x4(pk, o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) as[i][e] += o[e];
@@ -189,8 +241,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dx, uin
             for (int e = 0; e < 4; ++e)
                 red[wave][(i * 64 + lane) * 4 + e] = which == 0 ? ag[i][e] : (which == 1 ? ab[i][e] : as[i][e]);
         __syncthreads();
-        for (int c = threadIdx.x; c < E; c += 256)
-            partial[((int64_t)blockIdx.x * 3 + which) * E + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        float* prow = partial + ((int64_t)blockIdx.x * 3 + which) * E;
+#pragma nounroll
+        for (unsigned c = threadIdx.x; c < (unsigned)E; c += 256)
+            prow[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         __syncthreads();
     }
 }
@@ -492,7 +546,10 @@ int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, con
     if (((uintptr_t)dx | (uintptr_t)dx_scaled | (uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dres) % 16)
         return CREAM_ERR_BAD_ARG;
     // register footprint follows the row width: 2 chunks per lane cover E <= 512, 3 cover E <= 768
-    auto kern = E <= 512 ? ln_bwd_kernel<2> : (E <= 768 ? ln_bwd_kernel<3> : ln_bwd_kernel<LN_MAXC>);
+    // E <= 512: two rows in flight per wave (106 VGPRs, still 4 waves per SIMD = the grid's 4 workgroups per CU).  Alone
+    // on the chip all variants run at 4.6-4.8 TB/s (tools/probes/ln_probe.hip); next to the weight-gradient GEMMs of
+    // the side stream the deeper request queue is worth 1.0-1.2 % of the training step (same-box A/B, twice).
+    auto kern = E <= 512 ? ln_bwd_kernel<2, 2> : (E <= 768 ? ln_bwd_kernel<3, 0> : ln_bwd_kernel<LN_MAXC, 0>);
     hipLaunchKernelGGL(kern, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
                        (uint16_t*)dx_scaled, partial, (const uint16_t*)dy, x, mean, rstd, gamma, dres, sample_scale,
                        rows_per_sample, M, E);

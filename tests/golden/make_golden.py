@@ -382,6 +382,63 @@ def tinyclip_loss():
     save('tinyclip_soft_loss.npz', **out)
 
 
+MINIVIT_CASES = {
+    # the registered model (mini_deit_models.py:23-30): no class token, rpe on k, two repeats, head transforms
+    'mini_deit_tiny': dict(registered=True),
+    # the same machinery without head transforms, rpe on q, k, v, class token: the configuration the fused iRPE
+    # attention covers
+    'shared_qkv_cls': dict(registered=False, depth=4, repeated_times=2, use_transform=False, use_cls_token=True, rpe_on='qkv',
+                           skip=1, drop_path_rate=0.0),
+}
+
+
+def minivit_fill(model, seed):
+    fill_params(model, seed=seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            g = torch.Generator().manual_seed(zlib_seed(n) ^ seed)
+            if 'lookup_table' in n:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif 'norm' in n and n.endswith('weight'):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+
+
+def minivit():
+    """MiniViT/Mini-DeiT (weight-shared DeiT, per-repeat iRPE / norms / head transforms): logits and gradients of the
+    reference's own model classes on seeded weights and inputs (the RepeatedModuleList use)."""
+    from functools import partial
+    irpe, mvt, models, mini = refshim.load_minivit_models()
+    outs, meta = {}, {}
+    for tag, c in MINIVIT_CASES.items():
+        torch.manual_seed(0)
+        if c['registered']:
+            # = mini_deit_tiny_patch16_224() (mini_deit_models.py:9-30), whose lazy `from irpe import ...` needs the
+            # reference directory on sys.path at call time
+            cfg = irpe.get_rpe_config(ratio=1.9, method='product', mode='ctx', shared_head=True, skip=0, rpe_on='k')
+            model = models.deit_tiny_patch16_224(rpe_config=cfg, use_cls_token=False, repeated_times=2, use_transform=True)
+        else:
+            cfg = irpe.get_rpe_config(ratio=1.9, method='product', mode='ctx', shared_head=True, skip=c['skip'], rpe_on=c['rpe_on'])
+            model = mvt.VisionTransformer(patch_size=16, embed_dim=192, depth=c['depth'], num_heads=3, mlp_ratio=4, qkv_bias=True,
+                                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), rpe_config=cfg,
+                                          use_cls_token=c['use_cls_token'], repeated_times=c['repeated_times'],
+                                          use_transform=c['use_transform'], drop_path_rate=c['drop_path_rate'])
+        minivit_fill(model, seed=23)
+        model.eval()
+        g = torch.Generator().manual_seed(zlib_seed(tag))
+        x = torch.randn(2, 3, 224, 224, generator=g)
+        gy = torch.randn(2, 1000, generator=g)
+        logits = model(x)
+        (logits * gy).sum().backward()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        assert all(v is not None for v in grads.values())
+        meta[tag] = dict(keys=list(model.state_dict().keys()), n_params=sum(p.numel() for p in model.parameters()))
+        outs[f'{tag}|logits'] = logits
+        for k, v in grad_digest(grads).items():
+            outs[f'{tag}|{k}'] = v
+    json.dump(meta, open(os.path.join(HERE, 'minivit.json'), 'w'), indent=1)
+    save('minivit.npz', **outs)
+
+
 if __name__ == '__main__':
     assert refshim.have_reference(), "needs the reference checkout at /root/reference"
     which = sys.argv[1:] or ['autoformer', 'irpe']
@@ -397,3 +454,5 @@ if __name__ == '__main__':
         evolution()
     if 'tinyclip_loss' in which:
         tinyclip_loss()
+    if 'minivit' in which:
+        minivit()

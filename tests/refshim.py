@@ -18,6 +18,7 @@ import torch.nn as nn
 REFERENCE = "/root/reference"
 AUTOFORMER = os.path.join(REFERENCE, "AutoFormer")
 IRPE = os.path.join(REFERENCE, "iRPE", "DeiT-with-iRPE")
+MINIVIT = os.path.join(REFERENCE, "MiniViT", "Mini-DeiT")
 
 
 def have_reference():
@@ -222,4 +223,25 @@ def load_irpe_models():
             mods = [importlib.import_module(m) for m in ("irpe", "rpe_vision_transformer", "models", "rpe_models")]
     finally:
         sys.path.remove(IRPE)
+    return mods
+
+
+def load_minivit_models():
+    """-> (irpe, mini_vision_transformer, models, mini_deit_models) of MiniViT/Mini-DeiT, fallback rpe path."""
+    _install_easydict()
+    _install_timm_stub()
+    names = ("irpe", "mini_vision_transformer", "models", "mini_deit_models")
+    _purge(["rpe_ops", "rpe_index_cpp", "rpe_vision_transformer", "rpe_models"] + list(names))
+    import cream_amd.dropin as d
+    if d.PATH in sys.path:
+        sys.path.remove(d.PATH)
+    sys.path.insert(0, MINIVIT)
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mods = [importlib.import_module(m) for m in names]
+    finally:
+        sys.path.remove(MINIVIT)
+        _purge(names)
     return mods
