@@ -382,6 +382,67 @@ def tinyclip_loss():
     save('tinyclip_soft_loss.npz', **out)
 
 
+DETR_CASES = {
+    # --enc_rpe2d rpe-2.0-product-ctx-1-k (the DETR-with-iRPE README's recipe), padded images in the batch
+    'product_k_padmask': dict(kw=dict(ratio=2.0, method='product', mode='ctx', shared_head=True, skip=0, rpe_on='k'), hw=(10, 14),
+                              mask='pad'),
+    'euc_qkv_addmask': dict(kw=dict(ratio=1.9, method='euc', mode='ctx', shared_head=False, skip=0, rpe_on='qkv'), hw=(9, 5),
+                              mask='add'),
+    'quant_bias_qk': dict(kw=dict(ratio=1.9, method='quant', mode='bias', shared_head=True, skip=0, rpe_on='qk'), hw=(6, 11),
+                          mask=None),
+}
+
+
+def detr_inputs(tag, c, embed=256, batch=2):
+    h, w = c['hw']
+    L = h * w
+    g = torch.Generator().manual_seed(zlib_seed(tag))
+    src, pos, gy = (torch.randn(L, batch, embed, generator=g) for _ in range(3))
+    pad = add = None
+    if c['mask'] == 'pad':                      # the right part / bottom rows of image 1 are padding
+        m = torch.zeros(batch, h, w, dtype=torch.bool)
+        m[1, :, w - 3:] = True
+        m[1, h - 2:, :] = True
+        pad = m.flatten(1)
+    elif c['mask'] == 'add':
+        add = 0.5 * torch.randn(L, L, generator=g)
+    return src, pos, gy, pad, add
+
+
+def detr_fill(att, seed):
+    with torch.no_grad():
+        for n, p in att.named_parameters():
+            g = torch.Generator().manual_seed(zlib_seed(n) ^ seed)
+            p.copy_((0.3 if 'lookup_table' in n else (0.05 if p.dim() == 1 else p.shape[-1] ** -0.5)) * torch.randn(p.shape, generator=g))
+
+
+def detr():
+    """DETR-with-iRPE's encoder self-attention (models/rpe_attention/multi_head_attention.py): q = k = src + pos, v = src
+    (models/transformer.py encoder layer), rectangular maps, key padding / additive masks, head_dim 32."""
+    irpe, mha = refshim.load_detr_rpe_attention()
+    import contextlib
+    import io
+    outs = {}
+    for tag, c in DETR_CASES.items():
+        with contextlib.redirect_stdout(io.StringIO()):          # the constructor prints the bucket counts
+            att = mha.RPEMultiheadAttention(256, 8, dropout=0.0, rpe_config=irpe.get_rpe_config(**c['kw']))
+        detr_fill(att, seed=31)
+        src, pos, gy, pad, add = detr_inputs(tag, c)
+        src.requires_grad_()
+        pos.requires_grad_()
+        qk = src + pos
+        out, wts = att(qk, qk, src, key_padding_mask=pad, attn_mask=add, hw=c['hw'])
+        (out * gy).sum().backward()
+        for name, t in (('out', out), ('dsrc', src.grad), ('dpos', pos.grad)):          # strided sample + norm (file size)
+            outs[f'{tag}|{name}'] = t[::6, :, ::2]
+            outs[f'{tag}|{name}|norm'] = t.double().norm().reshape(1)
+        outs[f'{tag}|weights'] = wts[:, ::5, ::3]
+        for n, p in att.named_parameters():
+            outs[f'{tag}|grad|{n}'] = p.grad if ('lookup' in n or p.dim() == 1) else p.grad[::5, ::3]
+        outs[f'{tag}|keys'] = np.frombuffer(json.dumps(list(att.state_dict().keys())).encode(), dtype=np.uint8)
+    save('detr_rpe_attention.npz', **outs)
+
+
 MINIVIT_CASES = {
     # the registered model (mini_deit_models.py:23-30): no class token, rpe on k, two repeats, head transforms
     'mini_deit_tiny': dict(registered=True),
@@ -456,3 +517,5 @@ if __name__ == '__main__':
         tinyclip_loss()
     if 'minivit' in which:
         minivit()
+    if 'detr' in which:
+        detr()

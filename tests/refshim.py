@@ -19,6 +19,7 @@ REFERENCE = "/root/reference"
 AUTOFORMER = os.path.join(REFERENCE, "AutoFormer")
 IRPE = os.path.join(REFERENCE, "iRPE", "DeiT-with-iRPE")
 MINIVIT = os.path.join(REFERENCE, "MiniViT", "Mini-DeiT")
+DETR_RPE = os.path.join(REFERENCE, "iRPE", "DETR-with-iRPE", "models", "rpe_attention")
 
 
 def have_reference():
@@ -245,3 +246,23 @@ def load_minivit_models():
         sys.path.remove(MINIVIT)
         _purge(names)
     return mods
+
+
+def load_detr_rpe_attention():
+    """-> (irpe, multi_head_attention) of DETR-with-iRPE/models/rpe_attention, imported as a stand-alone package (the
+    parent `models/__init__.py` pulls the whole detector in), fallback rpe path."""
+    _install_easydict()
+    name = "_ref_detr_rpe_attention"
+    _purge([name, "rpe_ops", "rpe_index_cpp"])
+    import cream_amd.dropin as d
+    if d.PATH in sys.path:
+        sys.path.remove(d.PATH)
+    pkg = types.ModuleType(name)
+    pkg.__path__ = [DETR_RPE]
+    sys.modules[name] = pkg
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mha = importlib.import_module(name + ".multi_head_attention")
+        irpe = importlib.import_module(name + ".irpe")
+    return irpe, mha
