@@ -258,7 +258,8 @@ WGRAD_SIDE_STREAM = True
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
-        # (stream priorities were tried — side stream at 0 / main at -1 and the reverse: no change in step time)
+        # (stream priorities were tried — side stream at 0 / main at -1 and the reverse: no change in step time;
+        # a CU-masked side stream (hipExtStreamCreateWithCUMask, 64-128 CUs, whole XCDs or spread): 10.8 -> 16.2 ms)
         st = _side_streams[device] = torch.cuda.Stream(device=device)
     return st
 
