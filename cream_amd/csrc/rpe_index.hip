@@ -63,7 +63,11 @@ constexpr int WAVE = 64;
 // inside the row-per-wave kernel (DPP + alignbyte: slower), small row blocks in memory order (8-64
 // rows: slower than one large block per workgroup), 256/512-thread workgroups (slower).  A pure-store
 // ablation of this mapping tops out at ~4.4 TB/s against 6.9 TB/s of a framework fill of the same
-// buffer: the remaining gap is in how concurrent store streams land on DRAM pages, not in the gather.
+// buffer.  Round 2 (tools/probes/store_probe.hip, rpe_probe.hip): a pure 16-byte store stream with THIS mapping (one
+// 692 KB slab per 1024-thread workgroup) reaches 5.8 TB/s, so the mapping is not the limit; requesting the ids of the
+// next 1-4 vectors ahead of the store (software prefetch) changes nothing either.  What costs is the id stream itself:
+// 4 bytes of L2 traffic per output element for every plane -> rpe_gather_planes below.  This kernel remains the
+// fallback for rows too long for that kernel's per-thread vector budget.
 template <int BYTES>
 __global__ __launch_bounds__(1024) void rpe_gather_plane(
     typename raw_elem<BYTES>::type* __restrict__ y,
@@ -116,10 +120,11 @@ __global__ __launch_bounds__(1024) void rpe_gather_plane(
     int i = f / Lk, j = f - i * Lk;
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int32_t*>(idx), 0, (int)((int64_t)Lq * Lk * 4), 0x00020000);
+    constexpr int NW = V / 4 + (V < 4);                        // 16-byte id loads per output vector
     for (int q = tid; q < nvec; q += NT) {
         int32_t ids[V];
 #pragma unroll
-        for (int w = 0; w < V / 4 + (V < 4); ++w) {
+        for (int w = 0; w < NW; ++w) {
             const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (f + 4 * w) * 4, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -136,6 +141,128 @@ __global__ __launch_bounds__(1024) void rpe_gather_plane(
         i += stepq;
         j += stepr;
         if (j >= Lk) { j -= Lk; ++i; }
+    }
+}
+
+// Several planes per workgroup (the measured path).  The bucket ids depend on (i, j) only, yet the kernel above
+// fetches them once per PLANE: 4 bytes of L2 traffic per output element — as many bytes as the fp32 output itself and
+// twice the bf16 output — competing with the store stream for the same fabric.  Here a workgroup owns a block of query
+// rows for G planes of the same 16-byte alignment class (plane p + k * period: identical vector partition of the flat
+// output range), turns every id ONCE into the LDS address of its lookup value (row * nb + id, held in registers:
+// NV vectors x V elements per thread), and then for each plane only stages that plane's lookup rows (double-buffered,
+// one barrier per plane) and runs  V x ds_read + one aligned 16-byte store  per vector: no id traffic, no address
+// arithmetic in the per-plane loop.
+template <int BYTES, int NV>
+__global__ __launch_bounds__(1024) void rpe_gather_planes(
+    typename raw_elem<BYTES>::type* __restrict__ y,
+    const typename raw_elem<BYTES>::type* __restrict__ in,
+    const int32_t* __restrict__ idx,
+    int BH, int H, int Lq, int Lk, int nb,
+    int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+    int rows_per_block, int period, int G)
+{
+    using E = typename raw_elem<BYTES>::type;
+    constexpr int V = 16 / BYTES;
+    const int NT = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(Lq, r0 + rows_per_block);
+    const int cls = blockIdx.y % period, m0 = (blockIdx.y / period) * G;
+    const int p0 = cls + period * m0;                          // first plane of the group
+    if (r0 >= r1 || p0 >= BH) return;
+    const int total = (r1 - r0) * nb;
+    const int tstride = (rows_per_block * nb * BYTES + 15) / 16 * 16;          // bytes of one table buffer
+    const int64_t plane = (int64_t)Lq * Lk;
+
+    // lookup rows of one plane: requested into registers (NS per thread: the host keeps rows * nb <= NS * threads),
+    // written to the other LDS buffer after the gathers of the current plane — the round trip hides behind them
+    constexpr int NS = 4;
+    E stg[NS];
+    auto request = [&](int p) {
+        const int b = p / H, h = p - b * H;
+        const E* src = in + (int64_t)b * s0 + (int64_t)h * s1 + (int64_t)r0 * s2;
+        if (s3 == 1 && s2 == nb) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) { const int t = tid + u * NT; if (t < total) stg[u] = src[t]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int t = tid + u * NT;
+                if (t < total) { const int r = t / nb, c = t - r * nb; stg[u] = src[(int64_t)r * s2 + (int64_t)c * s3]; }
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        E* table = reinterpret_cast<E*>(smem + buf * tstride);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) { const int t = tid + u * NT; if (t < total) table[t] = stg[u]; }
+    };
+    request(p0);
+    commit(0);
+
+    // flat element range of this row block inside a plane and its 16-byte aligned interior (same for the whole group)
+    const int f0 = r0 * Lk, f1 = r1 * Lk;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(y + (int64_t)p0 * plane + f0) & 15) / BYTES);
+    const int fa = min(f1, f0 + ((V - mis) % V));
+    const int nvec = (f1 - fa) / V;
+    const int ft = fa + nvec * V;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(idx), 0, (int)((int64_t)Lq * Lk * 4), 0x00020000);
+    // LDS byte offsets (inside one table buffer) of the values of this thread's vectors
+    uint32_t toff[NV][V];
+    {
+        constexpr int NW = V / 4 + (V < 4);
+        const int stepq = (NT * V) / Lk, stepr = (NT * V) % Lk;
+        int f = fa + tid * V;
+        int i = f / Lk, j = f - i * Lk;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            int32_t ids[V];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (f + 4 * w) * 4, 0, 0);   // 0 past the end
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * w + e < V) ids[4 * w + e] = (int32_t)t4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int over = (j + e >= Lk) ? 1 : 0;        // the vector may run into the next query row
+                toff[k][e] = (uint32_t)(((i + over - r0) * nb + ids[e]) * BYTES);
+            }
+            f += NT * V;
+            i += stepq;
+            j += stepr;
+            if (j >= Lk) { j -= Lk; ++i; }
+        }
+    }
+    // the <= 2 (V - 1) edge elements of the block: ids kept as table indices too
+    const int nhead = fa - f0, ntail = f1 - ft;
+    int edge = -1, edge_f = 0;
+    if (tid < nhead) edge_f = f0 + tid;
+    else if (tid - nhead < ntail) edge_f = ft + (tid - nhead);
+    if (tid < nhead + ntail) edge = (edge_f / Lk - r0) * nb + idx[edge_f];
+
+    for (int g = 0; g < G; ++g) {
+        const int p = p0 + period * g;
+        if (p >= BH) break;
+        __syncthreads();                                       // table g staged; table g - 1 no longer read
+        const bool more = g + 1 < G && p + period < BH;
+        if (more) request(p + period);
+        const unsigned char* tb = smem + (g & 1) * tstride;
+        E* out = y + (int64_t)p * plane;
+        if (edge >= 0) out[edge_f] = reinterpret_cast<const E*>(tb)[edge];
+        E* ov = out + fa + tid * V;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (tid + k * NT < nvec) {
+                union { u32x4 vec; E e[V]; } pk;
+#pragma unroll
+                for (int e = 0; e < V; ++e) pk.e[e] = *reinterpret_cast<const E*>(tb + toff[k][e]);
+                *reinterpret_cast<u32x4*>(ov + (int64_t)k * NT * V) = pk.vec;     // 16-byte aligned
+            }
+        }
+        if (more) commit((g + 1) & 1);
     }
 }
 
@@ -455,6 +582,27 @@ int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int
         hipLaunchKernelGGL((rpe_gather_generic<BYTES>), dim3(grid), dim3(256), 0, st,
                            (E*)y, (const E*)in, idx, rows, H, Lq, Lk, s0, s1, s2, s3);
         return launch_status();
+    }
+    // measured path: several planes per workgroup (ids fetched once per group), tools/probes/rpe_probe.hip on config 4:
+    //   fp32  NV = 4, G = 2, 1024 threads  5.4 TB/s   (one plane per workgroup: 4.2-4.6)
+    //   bf16  NV = 4, G = 8,  768 threads  4.5 TB/s   (3.3)
+    {
+        constexpr int NV = 4, NS = 4;
+        const int thr = BYTES == 2 ? 768 : 1024, G = BYTES == 2 ? 8 : 2;
+        int64_t rows = std::min<int64_t>(Lq, (int64_t)NV * thr * V / Lk);      // NV vectors per thread cover the row block
+        rows = std::min<int64_t>(rows, (int64_t)NS * thr / nb);                 // NS staged lookup values per thread
+        rows = std::min<int64_t>(rows, 30720 / ((int64_t)nb * BYTES));          // two table buffers in 60 KB
+        if (rows >= 1) {
+            int nblk = ceil_div(Lq, rows);
+            rows = ceil_div(Lq, nblk);
+            int period = 1;                                     // planes p, p + period, ... share their 16-byte alignment
+            while (((int64_t)period * Lq * Lk * BYTES) % 16) ++period;
+            const int members = ceil_div(BH, period), groups = ceil_div(members, G);
+            const size_t lds = 2 * (((size_t)rows * nb * BYTES + 15) / 16 * 16);
+            hipLaunchKernelGGL((rpe_gather_planes<BYTES, NV>), dim3(nblk, period * groups), dim3(thr), lds, st, (E*)y, (const E*)in,
+                               idx, BH, H, Lq, Lk, nb, s0, s1, s2, s3, (int)rows, period, G);
+            return launch_status();
+        }
     }
     const int nthreads = 1024;
     int nblk = ceil_div(Lq, rpb);
