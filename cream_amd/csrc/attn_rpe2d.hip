@@ -980,31 +980,35 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
-    // persistent workgroup: (b, h) items blockIdx.x, + gridDim.x, ... (after the first round the workgroups of
-    // the CUs are out of step, so their prologue loads no longer hit HBM all at once)
-    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
-    __syncthreads();                                  // previous item done with the staged tiles and lse / delta
-    const int b = item / a.H, h = item - b * a.H;
-    const int64_t bh = (int64_t)b * a.H + h;
-    const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
-    const E* qp = reinterpret_cast<const E*>(a.q) + base;
-    const E* kpg = reinterpret_cast<const E*>(a.k) + base;
-    const E* vpg = reinterpret_cast<const E*>(a.v) + base;
+    // persistent workgroup: (b, h) items blockIdx.x, + gridDim.x, ...  The item-specific operands of the NEXT item (own
+    // K / V rows, first staged tile set, lse / delta) are requested into registers before the current item's epilogue
+    // (dK / dV and table-gradient stores), so an item starts with its prologue loads already landed: the prologue was
+    // 21 % of an item (phase stamps of tools/probes/attn_probe).
+    struct ItemPtrs {
+        const E *qp, *kpg, *vpg, *dop, *qep, *dep, *dltp, *spp;
+        int64_t bh;
+        int b, h;
+    };
     const int64_t orow = (int64_t)a.H * 64;
-    const E* dop = reinterpret_cast<const E*>(a.dout) + ((int64_t)b * N * a.H + h) * 64;
-    const E* qep = reinterpret_cast<const E*>(a.qe) + bh * NP * 32;
-    const E* dep = reinterpret_cast<const E*>(a.de) + bh * NP * 32;
-    const E* dltp = reinterpret_cast<const E*>(a.dlt) + bh * 64 * NP;
-    const E* spp = reinterpret_cast<const E*>(a.sp) + bh * 64 * NP;
+    auto item_ptrs = [&](int item) {
+        ItemPtrs P;
+        P.b = item / a.H;
+        P.h = item - P.b * a.H;
+        P.bh = (int64_t)P.b * a.H + P.h;
+        const int64_t base = (int64_t)P.b * a.sb + (int64_t)P.h * a.sh;
+        P.qp = reinterpret_cast<const E*>(a.q) + base;
+        P.kpg = reinterpret_cast<const E*>(a.k) + base;
+        P.vpg = reinterpret_cast<const E*>(a.v) + base;
+        P.dop = reinterpret_cast<const E*>(a.dout) + ((int64_t)P.b * N * a.H + P.h) * 64;
+        P.qep = reinterpret_cast<const E*>(a.qe) + P.bh * NP * 32;
+        P.dep = reinterpret_cast<const E*>(a.de) + P.bh * NP * 32;
+        P.dltp = reinterpret_cast<const E*>(a.dlt) + P.bh * 64 * NP;
+        P.spp = reinterpret_cast<const E*>(a.sp) + P.bh * 64 * NP;
+        return P;
+    };
     const bool active = wave < nt;
-
-    PROF_DECL
-    PROF_MARK();
     const int kj = wave * 32 + c32;
     const bool kok = active && kj < N;
-    F kb[S64], vb[S64], oh[S32];
-    load_row<T>(kb, kpg + (int64_t)min(kj, N - 1) * a.sn, g);
-    load_row<T>(vb, vpg + (int64_t)min(kj, N - 1) * a.sn, g);
 
     // staging is split over two groups of four waves (the workgroup always has 8 waves; waves
     // >= nt only stage): group 0 moves the Q tile (+ its transpose), the qe | de rows and the S'^T
@@ -1015,25 +1019,25 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     TileRegs<T, 64, 32> sdl;                                 // group 0: S'^T tile   group 1: dL'^T tile
     constexpr int EH = TileRegs<T, 32, 32>::CH;              // chunks of one 32 x 32 extension tile
     TileRegs<T, 32, 32> sqe;                                 // group 0 only: qe (first half of the group) | de
-    auto load_set = [&](int t) {
+    auto load_set = [&](const ItemPtrs& P, int t) {
         if (grp == 0) {
-            tile_load_g<T, 32, 64>(sq, qp, a.sn, t * 32, N, 0, gt);
-            tile_load_g<T, 64, 32>(sdl, spp, NP, 0, 64, t * 32, gt);
+            tile_load_g<T, 32, 64>(sq, P.qp, a.sn, t * 32, N, 0, gt);
+            tile_load_g<T, 64, 32>(sdl, P.spp, NP, 0, 64, t * 32, gt);
             if constexpr (EH == 128) {                       // bf16: 128 chunks each -> half a group per tile
                 const int c = gt & 127, row = c >> 2, cc = c & 3;
-                const E* src = (gt < 128 ? qep : dep) + (int64_t)(t * 32 + row) * 32 + cc * 8;
+                const E* src = (gt < 128 ? P.qep : P.dep) + (int64_t)(t * 32 + row) * 32 + cc * 8;
                 sqe.v[0] = *reinterpret_cast<const u32x4v*>(src);
             } else {                                         // fp32: 256 chunks each -> two per thread
-                tile_load_g<T, 32, 32>(sqe, qep, 32, t * 32, NP, 0, gt);
+                tile_load_g<T, 32, 32>(sqe, P.qep, 32, t * 32, NP, 0, gt);
             }
         } else {
-            tile_load_g<T, 32, 64>(sq, dop, orow, t * 32, N, 0, gt);
-            tile_load_g<T, 64, 32>(sdl, dltp, NP, 0, 64, t * 32, gt);
+            tile_load_g<T, 32, 64>(sq, P.dop, orow, t * 32, N, 0, gt);
+            tile_load_g<T, 64, 32>(sdl, P.dltp, NP, 0, 64, t * 32, gt);
         }
     };
     TileRegs<T, 32, 32> sde;                                 // fp32 only: de rows (group 0)
-    auto load_set_extra = [&](int t) {
-        if constexpr (EH != 128) { if (grp == 0) tile_load_g<T, 32, 32>(sde, dep, 32, t * 32, NP, 0, gt); }
+    auto load_set_extra = [&](const ItemPtrs& P, int t) {
+        if constexpr (EH != 128) { if (grp == 0) tile_load_g<T, 32, 32>(sde, P.dep, 32, t * 32, NP, 0, gt); }
     };
     auto store_set = [&](int i) {
         if (grp == 0) {
@@ -1052,18 +1056,39 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
             tile_store_g<T, 64, 32, true, false>(sdl, dlbuf(i), tpt, nullptr, 0, gt);
         }
     };
-    load_set(0);
-    load_set_extra(0);
-    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-        lse2[i] = i < N ? a.lse[bh * N + i] * LOG2E : INFINITY;           // P = 0 for padding queries
-        dlt_s[i] = i < N ? a.delta[bh * NP + i] * a.scale : 0.f;
-    }
+    // the one-hot slot operand of this lane's key: geometry only
+    F oh[S32];
     {
         const uint32_t km = key_mask(kj, G);
 #pragma unroll
         for (int ks = 0; ks < S32; ++ks) oh[ks] = TT::onehot_row(km, ks, g);
     }
     const float sc = a.scale * LOG2E;
+
+    // requests of an item's prologue operands (NP <= 256 < blockDim: one lse / delta value per thread)
+    F kb[S64], vb[S64];
+    float lse_r = INFINITY, dlt_r = 0.f;
+    auto request_item = [&](const ItemPtrs& P) {
+        load_row<T>(kb, P.kpg + (int64_t)min(kj, N - 1) * a.sn, g);
+        load_row<T>(vb, P.vpg + (int64_t)min(kj, N - 1) * a.sn, g);
+        load_set(P, 0);
+        load_set_extra(P, 0);
+        const int i = threadIdx.x;
+        lse_r = i < N ? a.lse[P.bh * N + i] * LOG2E : INFINITY;           // P = 0 for padding queries
+        dlt_r = i < N ? a.delta[P.bh * NP + i] * a.scale : 0.f;
+    };
+    int item = blockIdx.x;
+    if (item >= a.nitems) return;
+    ItemPtrs P = item_ptrs(item);
+    request_item(P);
+
+    for (;;) {
+    __syncthreads();                                  // previous item done with the staged tiles and lse / delta
+    const int b = P.b, h = P.h;
+    const int64_t bh = P.bh;
+    PROF_DECL
+    PROF_MARK();
+    if (threadIdx.x < NP) { lse2[threadIdx.x] = lse_r; dlt_s[threadIdx.x] = dlt_r; }
     store_set(0);
     __syncthreads();
     PROF_MARK();
@@ -1077,7 +1102,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         PROF_LOOP(t);
-        if (t + 1 < nt) { load_set(t + 1); load_set_extra(t + 1); }
+        if (t + 1 < nt) { load_set(P, t + 1); load_set_extra(P, t + 1); }
         if (active) {
             const E* qrow = qbuf(cur) + c32 * rp;
             const E* drow = dbuf(cur) + c32 * rp;
@@ -1146,6 +1171,13 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
         PROF_LOOP(t);
     }
     PROF_MARK();
+    // the next item's prologue operands travel while this item's results are stored
+    const int next = item + gridDim.x;
+    const bool more = next < a.nitems;
+    if (more) {
+        P = item_ptrs(next);
+        request_item(P);
+    }
     if (kok) {
         const int64_t off = (int64_t)b * a.dsb + (int64_t)kj * a.dsn + (int64_t)h * a.dsh;
         store_rows_64<T>(reinterpret_cast<E*>(a.dk) + off, dk, g);
@@ -1167,6 +1199,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     }
     PROF_MARK();
     PROF_FLUSH();
+    if (!more) break;
+    item = next;
     }   // items
 }
 

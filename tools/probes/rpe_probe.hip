@@ -95,7 +95,72 @@ void sweep(const char* tag) {
     hipFree(in); hipFree(y); hipFree(yref); hipFree(idx);
 }
 
-int main() {
+// ---- backward (scatter): tile width CT, tiles in flight PF, rows per workgroup ------------------------------------
+template <typename T, int CT, int PF>
+float run_scatter(T* gin, const T* gout, const int32_t* idx, int BH, int L, int nb, int wgs_per_cu, hipEvent_t e0, hipEvent_t e1) {
+    using ACC = typename cvt<T>::acc;
+    constexpr int V = 16 / (int)sizeof(T);
+    const size_t lds = (size_t)WAVE * (CT + V) * sizeof(T) + (size_t)nb * (WAVE + 1) * sizeof(ACC);
+    const int gx = (BH + WAVE - 1) / WAVE;
+    const int want_y = std::max(1, (256 * wgs_per_cu) / gx);
+    const int rpb = std::max(1, (L + want_y - 1) / want_y), gy = (L + rpb - 1) / rpb;
+    float sum = 0;
+    for (int it = 0; it < 7; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((rpe_scatter_planes<T, CT, PF, false>), dim3(gx, gy), dim3(WAVE), lds, 0, gin, gout, idx, BH, L, L, nb, rpb);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (it >= 2) sum += ms;
+    }
+    return sum / 5;
+}
+
+template <typename T>
+void sweep_bwd(const char* tag) {
+    const int B = 64, H = 12, L = 577, nb = 50, BH = B * H;
+    const size_t nin = (size_t)BH * L * nb, nout = (size_t)BH * L * L;
+    std::vector<T> hg(nout);
+    srand(9);
+    for (auto& v : hg) v = T((float)(rand() % 17 - 8) * 0.125f);
+    std::vector<int32_t> hidx((size_t)L * L);
+    for (auto& v : hidx) v = rand() % nb;
+    T *gout, *gin; int32_t* idx;
+    hipMalloc(&gout, nout * sizeof(T)); hipMalloc(&gin, nin * sizeof(T)); hipMalloc(&idx, hidx.size() * 4);
+    hipMemcpy(gout, hg.data(), nout * sizeof(T), hipMemcpyHostToDevice);
+    hipMemcpy(idx, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double bytes = (double)(nin + nout) * sizeof(T) + (double)L * L * 4;
+    std::vector<T> href(nin), hgot(nin);
+    bool have_ref = false;
+    auto report = [&](int ct, int pf, int w, float ms) {
+        hipMemcpy(hgot.data(), gin, nin * sizeof(T), hipMemcpyDeviceToHost);
+        if (!have_ref) { href = hgot; have_ref = true; }
+        const bool same = memcmp(href.data(), hgot.data(), nin * sizeof(T)) == 0;
+        printf("%s SCATTER CT=%3d PF=%d wgs/cu=%2d  %7.1f us  %.2f TB/s  %s\n", tag, ct, pf, w, ms * 1e3, bytes / (ms * 1e-3) / 1e12,
+               same ? "same" : "DIFFERENT");
+        hipMemset(gin, 0xff, nin * sizeof(T));
+    };
+    constexpr int C1 = 128 / (int)sizeof(T), C2 = (256 / (int)sizeof(T)) > 64 ? 64 : 256 / (int)sizeof(T);
+    for (int w : {8, 6, 12, 16}) {
+        report(C1, 2, w, run_scatter<T, C1, 2>(gin, gout, idx, BH, L, nb, w, e0, e1));
+        report(C1, 1, w, run_scatter<T, C1, 1>(gin, gout, idx, BH, L, nb, w, e0, e1));
+        report(C1, 3, w, run_scatter<T, C1, 3>(gin, gout, idx, BH, L, nb, w, e0, e1));
+        report(C1, 4, w, run_scatter<T, C1, 4>(gin, gout, idx, BH, L, nb, w, e0, e1));
+        if (C2 != C1) {
+            report(C2, 1, w, run_scatter<T, C2, 1>(gin, gout, idx, BH, L, nb, w, e0, e1));
+            report(C2, 2, w, run_scatter<T, C2, 2>(gin, gout, idx, BH, L, nb, w, e0, e1));
+            report(C2, 3, w, run_scatter<T, C2, 3>(gin, gout, idx, BH, L, nb, w, e0, e1));
+        }
+    }
+    hipFree(gout); hipFree(gin); hipFree(idx);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "bwd")) {
+        sweep_bwd<float>("fp32");
+        sweep_bwd<hip_bfloat16>("bf16");
+        return 0;
+    }
     sweep<4>("fp32");
     sweep<2>("bf16");
     return 0;
