@@ -21,6 +21,9 @@ Extra objects on the line:
                   in the line ("timing": "separate pass");
   roofline_step — whole-step algorithmic rate: 28.6 GFLOP per image (SURVEY 8d) x images/s / 2.5 PF;
   per_embed_dim — mean GPU ms per step by sampled embed dim (events between steps, no host sync);
+  host_unstalled — the same step at batch 4 (host-bound: same launches, ~30x less device work): what the host needs to
+                  enqueue a step when the launch queue is never full (`host_enqueue_ms_per_step` of the timed region
+                  includes waiting for queue slots whenever the device is the bottleneck);
   cpu_baseline  — the oracle (CPU fp32 restatement of the reference step, oracle/) timed on this box's
                   host cores on a bounded sample: best of several thread counts (rank 0, N=1 only),
                   CPU model stated; plus the iRPE pure-PyTorch path at config-4 shapes (B = 2).
@@ -61,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the tiny-batch pass that measures the unstalled host cost of a step")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-wgrad-stream", action="store_true", help="weight-gradient GEMMs on the main stream")
     ap.add_argument("--subnet", default=None, choices=["T", "S"],
@@ -322,6 +326,24 @@ def main():
     per_e = {str(e): dict(steps=len(v), gpu_ms_per_step=round(sum(v) / len(v), 3)) for e, v in sorted(per_e.items())}
     assert torch.isfinite(loss).item(), "loss is not finite"     # supernet_engine.py:87-89
 
+    # Host cost of a step WITHOUT back-pressure from the device: when the GPU is the bottleneck the launch queue fills
+    # and `t_issue` above includes the host waiting for queue slots.  The same code path at a tiny batch (same launches,
+    # same descriptors, ~30x less device work) is host-bound, so its time per step is what the host needs to enqueue one.
+    host_leg = None
+    if not a.no_host_leg:
+        hb = min(4, a.batch)
+        im4, tg4 = images[:hb].contiguous(), target[:hb].contiguous()
+        for _ in range(3):
+            trainer.step(im4, tg4)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            trainer.step(im4, tg4)
+        t_enq = time.perf_counter() - t0
+        sync()
+        host_leg = {"batch": hb, "steps": 20, "enqueue_ms_per_step": round(t_enq / 20 * 1e3, 3),
+                    "ms_per_step": round((time.perf_counter() - t0) / 20 * 1e3, 3)}
+
     # Kernel-level timing for the roofline entry: HIP events around the attention launches, on the
     # launch stream.  The timed region above enqueues each block with ONE native call
     # (csrc/block_seq.cpp), which leaves no place for host-side events, so the same kernels are
@@ -385,6 +407,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_issue / a.steps * 1e3, 3),
+            "host_unstalled": host_leg,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{what}, per-GPU batch {a.batch}, 224x224, AdamW, grad all-reduce RCCL",
