@@ -27,6 +27,7 @@ Extra objects on the line:
   cpu_baseline  — the oracle (CPU fp32 restatement of the reference step, oracle/) timed on this box's
                   host cores on a bounded sample: best of several thread counts (rank 0, N=1 only),
                   CPU model stated; plus the iRPE pure-PyTorch path at config-4 shapes (B = 2).
+  tinyclip_config5 — BASELINE config 5's distillation step on one device (student ViT-39M/16 + Text-19M, teacher ViT-B/16);
   irpe_config4  — BASELINE config 4 on the device: one RPEAttention layer (DeiT-B-384 + iRPE, L = 577) fwd+bwd
                   through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only).
 `--subnet T|S` benchmarks ONE fixed published sub-network instead of random sampling (BASELINE
@@ -256,6 +257,46 @@ def irpe_config4_leg(iters=10):
     return dict(workload="RPEAttention layer fwd+bwd, DeiT-B-384 iRPE product-ctx, B=64 H=12 L=577, bf16 autocast", **out)
 
 
+def tinyclip_config5_leg(batch=256, iters=10):
+    """BASELINE config 5 on ONE device: the affinity-mimicking distillation step of TinyCLIP — student
+    TinyCLIP-ViT-39M/16 + Text-19M, frozen teacher ViT-B/16, ClipSoftLoss, gradient clipping 5, AdamW — on synthetic
+    image / token batches, bf16 autocast; the image towers' attention on the fused kernels of csrc/irpe_attn.hip.  The
+    reference quotes this configuration on 8 GPUs at 1024 pairs per GPU; this is the per-GPU building block."""
+    from cream_amd import timing
+    from cream_amd.tinyclip import model as M
+    from cream_amd.tinyclip.distill import DistillStep
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    student = M.create_model("TinyCLIP-ViT-39M-16-Text-19M").to(dev)
+    teacher = M.create_model("ViT-B-16").to(dev)
+    opt = torch.optim.AdamW(student.parameters(), lr=1e-4, weight_decay=0.2, fused=True)
+    step = DistillStep(student, teacher, opt, logit_scale=50.0, norm_gradient_clip=5.0, amp_dtype=torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    images = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
+    texts = torch.randint(1, 49406, (batch, 77), device=dev, generator=g)
+    texts[:, 40] = 49407                                        # end-of-text
+    texts[:, 41:] = 0
+    for _ in range(3):
+        loss = step.step(images, texts)
+    torch.cuda.synchronize()
+    timing.reset()
+    timing.enable(True, only=("irpe_attn_fwd", "irpe_attn_bwd"))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        loss = step.step(images, texts)
+    b.record()
+    torch.cuda.synchronize()
+    timing.enable(False)
+    ks = timing.summary()
+    timing.reset()
+    ms = a.elapsed_time(b) / iters
+    assert torch.isfinite(loss).item()
+    return dict(workload="TinyCLIP distillation step: ViT-39M/16 + Text-19M student, ViT-B/16 teacher, ClipSoftLoss, bf16 autocast, 1 GPU",
+                batch=batch, ms_per_step=round(ms, 2), pairs_per_s=round(batch / ms * 1e3, 1), loss=round(float(loss), 4),
+                kernels={k: dict(launches_per_step=round(v["launches"] / iters, 1), avg_us=round(v["avg_ms"] * 1e3, 1)) for k, v in sorted(ks.items())})
+
+
 def main():
     a = parse()
     if a.cpu_baseline_only:
@@ -428,6 +469,12 @@ def main():
                 line["irpe_config4"] = irpe_config4_leg()
             except Exception as e:
                 sys.stderr.write(f"[bench] iRPE config-4 leg failed: {e}\n")
+            try:
+                del trainer, model, opt, reducer, images, target
+                torch.cuda.empty_cache()
+                line["tinyclip_config5"] = tinyclip_config5_leg()
+            except Exception as e:
+                sys.stderr.write(f"[bench] TinyCLIP config-5 leg failed: {e}\n")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -443,6 +443,74 @@ def detr():
     save('detr_rpe_attention.npz', **outs)
 
 
+TINYCLIP_CASES = {
+    # BASELINE config 5's student (model_configs/TinyCLIP-ViT-39M-16-Text-19M.json)
+    'vit39m16_text19m': dict(embed_dim=512, vision_cfg=dict(image_size=224, layers=12, width=512, patch_size=16),
+                             text_cfg=dict(context_length=77, vocab_size=49408, width=512, heads=8, layers=6), quick_gelu=False),
+    # OpenAI-style activation, 128-wide model with 64-wide heads, shorter context
+    'small_quickgelu': dict(embed_dim=64, vision_cfg=dict(image_size=64, layers=2, width=128, patch_size=16),
+                            text_cfg=dict(context_length=20, vocab_size=300, width=128, heads=2, layers=2), quick_gelu=True),
+}
+
+
+TINYCLIP_STRIDE = 4999
+
+
+def tinyclip_fill(model, seed):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            g = torch.Generator().manual_seed(zlib_seed(n) ^ seed)
+            if n.endswith('logit_scale'):
+                continue
+            if 'ln_' in n and n.endswith('weight'):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 1:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            elif 'embedding' in n:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p.shape[1] if p.dim() == 2 else p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * fan_in ** -0.5)
+
+
+def tinyclip_inputs(tag, c, batch=2):
+    g = torch.Generator().manual_seed(zlib_seed(tag))
+    size, ctx, vocab = c['vision_cfg']['image_size'], c['text_cfg']['context_length'], c['text_cfg']['vocab_size']
+    images = torch.randn(batch, 3, size, size, generator=g)
+    texts = torch.randint(1, vocab - 1, (batch, ctx), generator=g)
+    for b in range(batch):                          # the end-of-text token has the highest id; padding after it is 0
+        eot = int(torch.randint(3, ctx, (1,), generator=g))
+        texts[b, eot] = vocab - 1
+        texts[b, eot + 1:] = 0
+    gi = torch.randn(batch, c['embed_dim'], generator=g)
+    gt = torch.randn(batch, c['embed_dim'], generator=g)
+    return images, texts, gi, gt
+
+
+def tinyclip_model():
+    """TinyCLIP's CLIP class (open_clip/model.py) on seeded weights and inputs: normalised image / text features, logit
+    scale and the gradient of every parameter (the towers of BASELINE config 5)."""
+    m = refshim.load_tinyclip_model()
+    outs, meta = {}, {}
+    for tag, c in TINYCLIP_CASES.items():
+        torch.manual_seed(0)
+        model = m.CLIP(c['embed_dim'], dict(c['vision_cfg']), dict(c['text_cfg']), quick_gelu=c['quick_gelu'])
+        tinyclip_fill(model, seed=37)
+        images, texts, gi, gt = tinyclip_inputs(tag, c)
+        fi, ft, scale = model(images, texts, normalized=True)
+        ((fi * gi).sum() + (ft * gt).sum() + scale).backward()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        assert all(v is not None for v in grads.values())
+        meta[tag] = dict(keys=list(model.state_dict().keys()), n_params=sum(p.numel() for p in model.parameters()))
+        outs[f'{tag}|image_features'] = fi
+        outs[f'{tag}|text_features'] = ft
+        outs[f'{tag}|scale'] = scale.reshape(1)
+        for k, v in grad_digest(grads, stride=TINYCLIP_STRIDE).items():
+            outs[f'{tag}|{k}'] = v
+    json.dump(meta, open(os.path.join(HERE, 'tinyclip_model.json'), 'w'), indent=1)
+    save('tinyclip_model.npz', **outs)
+
+
 MINIVIT_CASES = {
     # the registered model (mini_deit_models.py:23-30): no class token, rpe on k, two repeats, head transforms
     'mini_deit_tiny': dict(registered=True),
@@ -519,3 +587,5 @@ if __name__ == '__main__':
         minivit()
     if 'detr' in which:
         detr()
+    if 'tinyclip_model' in which:
+        tinyclip_model()

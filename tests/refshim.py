@@ -20,6 +20,7 @@ AUTOFORMER = os.path.join(REFERENCE, "AutoFormer")
 IRPE = os.path.join(REFERENCE, "iRPE", "DeiT-with-iRPE")
 MINIVIT = os.path.join(REFERENCE, "MiniViT", "Mini-DeiT")
 DETR_RPE = os.path.join(REFERENCE, "iRPE", "DETR-with-iRPE", "models", "rpe_attention")
+OPEN_CLIP = os.path.join(REFERENCE, "TinyCLIP", "src", "open_clip")
 
 
 def have_reference():
@@ -266,3 +267,24 @@ def load_detr_rpe_attention():
         mha = importlib.import_module(name + ".multi_head_attention")
         irpe = importlib.import_module(name + ".irpe")
     return irpe, mha
+
+
+def load_tinyclip_model():
+    """-> TinyCLIP/src/open_clip/model.py imported as a stand-alone package module.  Its imports that are absent here
+    (torchvision for a frozen-BatchNorm helper of the ResNet tower, timm for the timm tower) get empty stand-ins: neither
+    is touched by the ViT towers."""
+    name = "_ref_open_clip"
+    _purge([name])
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.ops = types.ModuleType("torchvision.ops")
+        tv.ops.misc = types.ModuleType("torchvision.ops.misc")
+        tv.ops.misc.FrozenBatchNorm2d = type("FrozenBatchNorm2d", (nn.Module,), {})
+        sys.modules.update({"torchvision": tv, "torchvision.ops": tv.ops, "torchvision.ops.misc": tv.ops.misc})
+    pkg = types.ModuleType(name)
+    pkg.__path__ = [OPEN_CLIP]
+    sys.modules[name] = pkg
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return importlib.import_module(name + ".model")

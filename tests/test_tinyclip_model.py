@@ -1,0 +1,115 @@
+"""TinyCLIP's towers (cream_amd/tinyclip/model.py) against fixtures made by running the reference's own CLIP class
+(TinyCLIP/src/open_clip/model.py, tests/golden/make_golden.py `tinyclip_model`): state-dict keys, parameter count, normalised
+features, logit scale and the gradient of every parameter; then the distillation step built on them (cream_amd/tinyclip/
+distill.py).  CPU: fp32.  GPU: fp32, and bf16 autocast where the image tower must take the fused attention kernels."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from helpers import load_json, load_npz, max_rel  # noqa: E402
+from make_golden import TINYCLIP_CASES, TINYCLIP_STRIDE, tinyclip_fill, tinyclip_inputs  # noqa: E402
+
+
+def build(tag):
+    from cream_amd.tinyclip.model import CLIP
+    c = TINYCLIP_CASES[tag]
+    torch.manual_seed(0)
+    model = CLIP(c['embed_dim'], dict(c['vision_cfg']), dict(c['text_cfg']), quick_gelu=c['quick_gelu'])
+    tinyclip_fill(model, seed=37)
+    return model
+
+
+def run(model, tag, device, autocast=False):
+    images, texts, gi, gt = (t.to(device) for t in tinyclip_inputs(tag, TINYCLIP_CASES[tag]))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        fi, ft, scale = model(images, texts, normalized=True)
+    ((fi.float() * gi).sum() + (ft.float() * gt).sum() + scale).backward()
+    return fi, ft, scale, {k: p.grad for k, p in model.named_parameters()}
+
+
+def compare(tag, fi, ft, scale, grads, tol):
+    fix = load_npz("tinyclip_model.npz")
+    errs = {"image_features": max_rel(fi.detach().cpu().float(), fix[f"{tag}|image_features"]),
+            "text_features": max_rel(ft.detach().cpu().float(), fix[f"{tag}|text_features"]),
+            "scale": abs(float(scale.detach()) - float(fix[f"{tag}|scale"][0])) / float(fix[f"{tag}|scale"][0])}
+    for k, v in fix.items():
+        if k.startswith(tag + "|") and k.endswith("|norm"):
+            name = k[len(tag) + 1:-5]
+            ref = float(v[0])
+            g = grads[name].detach().cpu().double().flatten()
+            if ref < 1e-9:
+                assert float(g.norm()) < 1e-6, name
+                continue
+            errs[name + "|norm"] = abs(float(g.norm()) - ref) / ref
+            scale_ = ref / max(1.0, g.numel()) ** 0.5
+            sample = torch.from_numpy(fix[f"{tag}|{name}|sample"])
+            errs[name + "|sample"] = float((g[::TINYCLIP_STRIDE] - sample).abs().max() / scale_) / 10.0
+    bad = {k: e for k, e in errs.items() if not e <= tol}
+    assert not bad, f"{tag}: exceeds {tol}: " + ", ".join(f"{k}={e:.2e}" for k, e in sorted(bad.items(), key=lambda t: -t[1])[:8])
+    return max(errs.values())
+
+
+@pytest.mark.parametrize("tag", list(TINYCLIP_CASES))
+def test_towers_match_reference_on_cpu(tag):
+    model = build(tag)
+    meta = load_json("tinyclip_model.json")[tag]
+    assert list(model.state_dict().keys()) == meta["keys"]
+    assert sum(p.numel() for p in model.parameters()) == meta["n_params"]
+    worst = compare(tag, *run(model, tag, "cpu"), 2e-4)
+    print(f"[tinyclip cpu {tag}] worst {worst:.2e}")
+
+
+def test_named_configurations_have_the_published_sizes():
+    """TinyCLIP-ViT-39M-16-Text-19M: 39M image + 19M text parameters (the model's name); ViT-B/16: 86M + 63M... (OpenAI CLIP)."""
+    from cream_amd.tinyclip import model as M
+    s = M.create_model("TinyCLIP-ViT-39M-16-Text-19M")
+    ni, nt = M.n_params(s._image_encoder), M.n_params(s._text_encoder)
+    assert round(ni / 1e6) == 39 and round((nt - s._text_encoder.token_embedding.weight.numel()) / 1e6) == 19, (ni, nt)
+    assert list(s.state_dict())[0] == "_image_encoder.visual.class_embedding"
+
+
+def test_distill_step_decreases_the_soft_loss_on_cpu():
+    """A few steps of DistillStep on a tiny student / teacher pair: finite, decreasing, logit scale pinned as the flag says."""
+    import math
+    from cream_amd.tinyclip.distill import DistillStep
+    from cream_amd.tinyclip.model import CLIP
+    torch.manual_seed(3)
+    cfg = dict(vision_cfg=dict(image_size=32, layers=2, width=64, patch_size=16), text_cfg=dict(context_length=12, vocab_size=100, width=64, heads=1, layers=2))
+    student, teacher = CLIP(32, **cfg), CLIP(32, **cfg)
+    opt = torch.optim.AdamW(student.parameters(), lr=2e-3)
+    step = DistillStep(student, teacher, opt, logit_scale=50.0, amp_dtype=torch.float32)
+    images = torch.randn(8, 3, 32, 32)
+    texts = torch.randint(1, 99, (8, 12))
+    texts[:, -1] = 99
+    losses = [float(step.step(images, texts)) for _ in range(12)]
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert abs(float(student.logit_scale) - math.log(50.0)) < 1e-6
+    assert all(p.grad is None for p in teacher.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(TINYCLIP_CASES))
+def test_towers_match_reference_on_gpu_fp32(tag):
+    model = build(tag).to("cuda:0")
+    worst = compare(tag, *run(model, tag, "cuda:0"), 2e-3)
+    print(f"[tinyclip gpu fp32 {tag}] worst {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_image_tower_takes_the_fused_attention_under_autocast():
+    from cream_amd import timing
+    tag = "vit39m16_text19m"
+    model = build(tag).to("cuda:0")
+    timing.reset()
+    timing.enable(True)
+    out = run(model, tag, "cuda:0", autocast=True)
+    timing.enable(False)
+    s = timing.summary()
+    assert "irpe_attn_fwd" in s and "irpe_attn_bwd" in s, set(s)
+    # bf16 operands end to end through 12 + 6 layers; the worst entry is the token-embedding gradient, whose few non-zero
+    # rows are measured against the norm of a 25M-element, almost empty tensor (6e-2; features and tower weights < 2e-2)
+    worst = compare(tag, *out, 1e-1)
+    print(f"[tinyclip gpu bf16 {tag}] worst {worst:.2e}")
