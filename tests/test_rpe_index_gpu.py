@@ -27,6 +27,9 @@ SHAPES = [
     (70, 1, 4, 64, 3),        # > 64 planes (two scatter waves), Lk multiple of vector width
     (1, 130, 3, 1030, 9),     # long rows -> NCHUNK > 4 fallback for f32, planes not multiple of 64
     (2, 2, 6, 9, 300),        # nb > 128 -> generic gather; large bin array
+    (9, 1, 2, 25001, 6),      # rows longer than the multi-plane gather's per-thread vector budget -> one plane per workgroup;
+                              # 9 planes of one alignment class and an odd row length
+    (3, 7, 40, 196, 33),      # even Lk: every plane 16-byte aligned (period 1), groups of consecutive planes, last group partial
 ]
 
 
@@ -43,6 +46,22 @@ def test_fwd_bit_exact(shape, dt):
     raw = RAW[x.element_size()]
     want = O.fwd(x.view(raw).numpy(), index.numpy())
     np.testing.assert_array_equal(y.cpu().view(raw).numpy(), want)
+
+
+def test_fwd_general_strides_through_the_multi_plane_gather():
+    """Lookup rows with a non-unit innermost stride and padded rows (the staged-table path with the per-element index
+    arithmetic), planes spread over several alignment classes."""
+    from cream_amd import rpe_index as R
+    dev = _dev()
+    B, H, L, nb = 3, 5, 57, 11
+    torch.manual_seed(1)
+    base = torch.randn(B, H, L + 2, 2 * nb + 3)
+    view = base.to(dev)[:, :, 1:L + 1, 1:2 * nb + 1:2]
+    assert view.shape == (B, H, L, nb) and view.stride(3) == 2
+    index = torch.randint(0, nb, (L, L), dtype=torch.int32)
+    y = R.forward_gpu(view, index.to(dev))
+    want = base[:, :, 1:L + 1, 1:2 * nb + 1:2].contiguous()[:, :, torch.arange(L)[:, None], index.long()]
+    assert torch.equal(y.cpu(), want)
 
 
 def test_fwd_transposed_view_input():
