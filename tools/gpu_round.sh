@@ -14,10 +14,11 @@ fi
 timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-leg > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
+# QUICK=1: tests, bench line, kernel stats, the rpe_index HBM counters and config 2 only (the other records are unchanged)
 # counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
-for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+[ -z "$QUICK" ] && for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_|gemm_|ln_|adamw|grad_finalize' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
@@ -29,6 +30,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'rpe_gather|rpe_scatter' -d $OUT/${TAG}_rpepmc_$i -o pmc --output-format csv -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_rpepmc_$i.err
   echo "rpe pmc $i exit $?"
+  [ -n "$QUICK" ] && [ $i -ge 2 ] && break
   [ $i -ge 3 ] && timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_attn' -d $OUT/${TAG}_irpepmc_$i -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_irpepmc_$i.err
 done
 cd $REPO
@@ -38,12 +40,14 @@ timeout 300 python bench.py --supernet T --subnet T --steps 40 --warmup 10 --no-
 echo "config2 exit $?"; cat $OUT/${TAG}_bench_config2.json | cut -c1-400
 timeout 300 python tools/bench_rpe_index.py > $OUT/${TAG}_rpe_index_microbench.jsonl 2> $OUT/${TAG}_rpe_index_microbench.err
 echo "rpe microbench exit $?"; cut -c1-300 $OUT/${TAG}_rpe_index_microbench.jsonl
+if [ -z "$QUICK" ]; then
 timeout 300 python tools/bench_irpe_attention.py > $OUT/${TAG}_irpe_attention.jsonl 2> $OUT/${TAG}_irpe_attention.err
 echo "irpe attention exit $?"; cut -c1-300 $OUT/${TAG}_irpe_attention.jsonl
 timeout 300 python tools/bench_subnet_eval.py > $OUT/${TAG}_subnet_eval.json 2> $OUT/${TAG}_subnet_eval.err
 echo "subnet eval exit $?"; cut -c1-300 $OUT/${TAG}_subnet_eval.json
 timeout 300 python tools/host_profile.py > $OUT/${TAG}_host_profile.txt 2>&1
 echo "host profile exit $?"; head -12 $OUT/${TAG}_host_profile.txt
+fi
 find $OUT -name '*.csv' -path "*${TAG}*" | head -20
 # keep the merge small: drop raw traces, keep stats + counter csv
 find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" -delete

@@ -85,12 +85,9 @@ void sweep(const char* tag) {
         hipMemset(y, 0xff, nout * BYTES);
     };
     int nblk;
-    for (int thr : {1024, 768, 512}) for (int G : {1, 2, 3, 4, 8}) {
-        float ms = run_planes<BYTES, 2>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(2, G, thr, nblk, ms);
-        ms = run_planes<BYTES, 3>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(3, G, thr, nblk, ms);
-        ms = run_planes<BYTES, 4>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(4, G, thr, nblk, ms);
+    for (int thr : {1024, 768}) for (int G : {2, 4, 8}) {
+        float ms = run_planes<BYTES, 4>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(4, G, thr, nblk, ms);
         ms = run_planes<BYTES, 5>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(5, G, thr, nblk, ms);
-        ms = run_planes<BYTES, 6>(y, in, idx, BH, H, L, nb, G, thr, e0, e1, &nblk); report2(6, G, thr, nblk, ms);
     }
     hipFree(in); hipFree(y); hipFree(yref); hipFree(idx);
 }
