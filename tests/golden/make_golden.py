@@ -443,6 +443,24 @@ def detr():
     save('detr_rpe_attention.npz', **outs)
 
 
+RASAMPLER_CASES = [(1000, 1, 0, 0, True), (1000, 4, 3, 5, True), (777, 8, 2, 1, True), (513, 3, 1, 7, False), (256, 2, 1, 2, True),
+                   (300, 7, 6, 3, True), (5000, 8, 0, 11, True)]          # (dataset length, replicas, rank, epoch, shuffle)
+
+
+def rasampler():
+    """AutoFormer/lib/samplers.py RASampler: the index sequences of a few (length, replicas, rank, epoch) combinations."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_ref_samplers', os.path.join(refshim.AUTOFORMER, 'lib', 'samplers.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = []
+    for n, R, r, ep, sh in RASAMPLER_CASES:
+        s = mod.RASampler(range(n), num_replicas=R, rank=r, shuffle=sh)
+        s.set_epoch(ep)
+        out.append(dict(case=[n, R, r, ep, sh], len=len(s), indices=list(iter(s))))
+    json.dump(out, open(os.path.join(HERE, 'rasampler.json'), 'w'))
+
+
 TINYCLIP_CASES = {
     # BASELINE config 5's student (model_configs/TinyCLIP-ViT-39M-16-Text-19M.json)
     'vit39m16_text19m': dict(embed_dim=512, vision_cfg=dict(image_size=224, layers=12, width=512, patch_size=16),
@@ -589,3 +607,5 @@ if __name__ == '__main__':
         detr()
     if 'tinyclip_model' in which:
         tinyclip_model()
+    if 'rasampler' in which:
+        rasampler()

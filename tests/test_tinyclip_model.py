@@ -113,3 +113,78 @@ def test_image_tower_takes_the_fused_attention_under_autocast():
     # rows are measured against the norm of a 25M-element, almost empty tensor (6e-2; features and tower weights < 2e-2)
     worst = compare(tag, *out, 1e-1)
     print(f"[tinyclip gpu bf16 {tag}] worst {worst:.2e}")
+
+
+# ---- the distillation step across two ranks (gloo) == the same step on the global batch in one process ------------
+def _tiny_pair():
+    from cream_amd.tinyclip.model import CLIP
+    cfg = dict(vision_cfg=dict(image_size=32, layers=2, width=64, patch_size=16), text_cfg=dict(context_length=12, vocab_size=100, width=64, heads=1, layers=2))
+    torch.manual_seed(11)
+    return CLIP(32, **cfg), CLIP(32, **cfg)
+
+
+def _tiny_batch(n=8):
+    g = torch.Generator().manual_seed(13)
+    images = torch.randn(n, 3, 32, 32, generator=g)
+    texts = torch.randint(1, 99, (n, 12), generator=g)
+    texts[:, -1] = 99
+    return images, texts
+
+
+class _MeanReducer:
+    def __init__(self, params):
+        self.params = params
+
+    def finish(self):
+        import torch.distributed as dist
+        for p in self.params:
+            dist.all_reduce(p.grad)
+            p.grad /= dist.get_world_size()
+
+
+def _distill_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+    from cream_amd.tinyclip.distill import DistillStep
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    student, teacher = _tiny_pair()
+    opt = torch.optim.SGD(student.parameters(), lr=0.05)
+    step = DistillStep(student, teacher, opt, logit_scale=None, distillation_alpha=0.7, amp_dtype=torch.float32, rank=rank, world_size=world,
+                       reducer=_MeanReducer([p for p in student.parameters()]))
+    images, texts = _tiny_batch()
+    b = images.shape[0] // world
+    losses = [float(step.step(images[rank * b:(rank + 1) * b], texts[rank * b:(rank + 1) * b])) for _ in range(2)]
+    q.put((rank, losses, {k: v.detach().numpy().copy() for k, v in student.state_dict().items()}))     # (numpy: no shared-memory handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distill_step_world2_equals_the_global_batch_step():
+    import torch.multiprocessing as mp
+    from cream_amd.tinyclip.distill import DistillStep
+    student, teacher = _tiny_pair()
+    opt = torch.optim.SGD(student.parameters(), lr=0.05)
+    step = DistillStep(student, teacher, opt, logit_scale=None, distillation_alpha=0.7, amp_dtype=torch.float32)
+    images, texts = _tiny_batch()
+    ref_losses = [float(step.step(images, texts)) for _ in range(2)]
+    ref = student.state_dict()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_distill_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the global loss is the mean of the ranks' local losses; both ranks end with the single-process weights
+    for i in range(2):
+        assert abs((got[0][1][i] + got[1][1][i]) / 2 - ref_losses[i]) < 2e-5 * abs(ref_losses[i]), (got[0][1], got[1][1], ref_losses)
+    for rank in range(2):
+        for k, v in ref.items():
+            g = torch.from_numpy(got[rank][2][k])
+            assert torch.allclose(g, v, rtol=2e-4, atol=2e-6), (rank, k, float((g - v).abs().max()))
