@@ -9,8 +9,8 @@ import os
 import re
 import sys
 
-PAT = re.compile(r"(gemm_nt_kernel<[^>]*>|gemm_tn_kernel<\d+>|attn_rpe2d_\w+_kernel|ln_\w+_kernel|adamw_mirror_kernel|"
-                 r"grad_finalize_kernel|rpe_gather_plane<\d+>|rpe_scatter_planes|irpe_attn_\w+_kernel<[^>]*>|irpe_table_grad_kernel)")
+PAT = re.compile(r"(gemm_nt_kernel<[^>]*>|gemm_tn_kernel<[^>]*>|attn_rpe2d_\w+_kernel|ln_\w+_kernel|adamw_mirror_kernel|"
+                 r"grad_finalize_kernel|rpe_gather_planes?<[^>]*>|rpe_scatter_planes|irpe_attn_\w+_kernel<[^>]*>|irpe_table_grad_kernel)")
 EPI = {"0": "store", "1": "bias", "2": "bias+gelu (two outputs)", "3": "x gelu' + column sums"}
 FAMILY = {"gemm_nt": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() in ("0", "1"),
           "gemm_nt_gelu": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() == "2",
