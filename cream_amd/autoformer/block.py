@@ -771,7 +771,7 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
                                               *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
                                               reduce_tables=False)
     nb = tabs_p[0].shape[0]
-    for i, t in enumerate(tabs_p):                                     # dtab (B*H, 4, 32, 64)
+    for i, t in enumerate(tabs_p):                                     # dtab (workgroup partials, 4, 32, 64)
         jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
     dqkv2d = dqkv.view(M, 3 * Q)
     pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)                  # rows [q | k | v]; bias rides along

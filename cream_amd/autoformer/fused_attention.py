@@ -83,7 +83,8 @@ def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
 
 def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_tables=True):
     """-> (dqkv (B, N, 3, H, 64), dtab (4, 32, 64) fp32 = gradients of [tkv, tkh, tvv, tvh] rows;
-    with reduce_tables=False the per-(b,h) partials (B*H, 4, 32, 64) for cream_grad_finalize)."""
+    with reduce_tables=False the per-workgroup partials (cream_attn_rpe2d_dtab_parts(B, H), 4, 32, 64) for
+    cream_grad_finalize)."""
     B, N, _, H, D = qkv.shape
     gh, gw = grid_of(N, mr)
     NP = padded_len(N)
@@ -94,7 +95,7 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_
     qe = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
     de = torch.empty((B, H, NP, 32), dtype=qkv.dtype, device=qkv.device)
     delta = torch.empty((B, H, NP), dtype=torch.float32, device=qkv.device)
-    dtab = torch.empty((B * H, 4, 32, 64), dtype=torch.float32, device=qkv.device)
+    dtab = torch.empty((_lib.load().cream_attn_rpe2d_dtab_parts(B, H), 4, 32, 64), dtype=torch.float32, device=qkv.device)
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
     dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
@@ -110,7 +111,7 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_
             B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
     if not reduce_tables:
         return dqkv, dtab
-    return dqkv, dtab.sum(dim=0)                              # fixed-order reduction over (b, h)
+    return dqkv, dtab.sum(dim=0)                              # fixed-order reduction over the workgroups' partials
 
 
 class _FusedAttention(torch.autograd.Function):

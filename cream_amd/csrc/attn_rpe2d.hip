@@ -1077,6 +1077,13 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
         lse_r = i < N ? a.lse[P.bh * N + i] * LOG2E : INFINITY;           // P = 0 for padding queries
         dlt_r = i < N ? a.delta[P.bh * NP + i] * a.scale : 0.f;
     };
+    // table-gradient jobs of this wave: job = tab*2 + dt (tab 0/1 key tables v/h: X = Q, R = dL';
+    // tab 2/3 value tables: X = dO, R = S'), dT^T(64 d x 32 u) = X^T(d x q) . R(q x u).  The tables are shared by all
+    // (b, h): the accumulators live across the workgroup's items and ONE partial per workgroup leaves the kernel
+    // (256 x 32 KB instead of B*H x 32 KB written here and read back by the gradient finalisation).
+    const int job0 = wave, job1 = wave + nwaves;      // nwaves >= 4 -> at most two jobs per wave
+    f32x16 tacc[2] = {f32x16{}, f32x16{}};
+
     int item = blockIdx.x;
     if (item >= a.nitems) return;
     ItemPtrs P = item_ptrs(item);
@@ -1093,10 +1100,6 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     __syncthreads();
     PROF_MARK();
 
-    // table-gradient jobs of this wave: job = tab*2 + dt (tab 0/1 key tables v/h: X = Q, R = dL';
-    // tab 2/3 value tables: X = dO, R = S'), dT^T(64 d x 32 u) = X^T(d x q) . R(q x u)
-    const int job0 = wave, job1 = wave + nwaves;      // nwaves >= 4 -> at most two jobs per wave
-    f32x16 tacc[2] = {f32x16{}, f32x16{}};
 
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     for (int t = 0; t < nt; ++t) {
@@ -1184,24 +1187,24 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
         store_rows_64<T>(reinterpret_cast<E*>(a.dv) + off, dv, g);
     }
     PROF_MARK();
+    PROF_MARK();
+    PROF_FLUSH();
+    if (!more) break;
+    item = next;
+    }   // items
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int job = jj == 0 ? job0 : job1;
         if (job < 8) {
             // lane = bucket u (column), registers = d rows
             const int tab = job >> 1, dt = job & 1;
-            float* dst = a.dtab + ((bh * 4 + tab) * 32 + c32) * 64 + dt * 32;
+            float* dst = a.dtab + (((int64_t)blockIdx.x * 4 + tab) * 32 + c32) * 64 + dt * 32;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
                 *reinterpret_cast<f32x4v*>(dst + 8 * r4 + 4 * g) =
                     f32x4v{tacc[jj][4 * r4], tacc[jj][4 * r4 + 1], tacc[jj][4 * r4 + 2], tacc[jj][4 * r4 + 3]};
         }
     }
-    PROF_MARK();
-    PROF_FLUSH();
-    if (!more) break;
-    item = next;
-    }   // items
 }
 
 template <typename T, bool FAST>
@@ -1248,6 +1251,13 @@ bool geom_ok(int N, int gh, int gw, int mr, int nb) {
 extern "C" {
 
 int cream_attn_rpe2d_padded_len(int N) { return N <= 0 ? 0 : ((N + 31) / 32) * 32; }
+
+int cream_attn_rpe2d_dtab_parts(int B, int H)
+{
+    if (B <= 0 || H <= 0) return 0;
+    const int64_t items = (int64_t)B * H;
+    return (int)(items < fwd_persistent_grid() ? items : fwd_persistent_grid());
+}
 
 int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const void* k, const void* v,
                          int64_t sb, int64_t sn, int64_t sh, const float* tkv, const float* tkh,

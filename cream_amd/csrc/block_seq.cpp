@@ -262,7 +262,7 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     const int nb = 2 * d->mr + 2;
     float* tabs[4] = {G->tkv, G->tkh, G->tvv, G->tvh};
     for (int t = 0; t < 4; ++t)
-        job(tabs[t], G->ldt, at<float>(ws, L.dtab) + t * 32 * 64, d->B * d->H, 4 * 32 * 64, nb, 64, 0, 0);
+        job(tabs[t], G->ldt, at<float>(ws, L.dtab) + t * 32 * 64, cream_attn_rpe2d_dtab_parts(d->B, d->H), 4 * 32 * 64, nb, 64, 0, 0);
     job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, 0);
     job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     job(G->ln1_g, E, at<float>(ws, L.pl1), P, 3 * (int64_t)E, 1, E, 0, 0);

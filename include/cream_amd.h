@@ -84,6 +84,10 @@ int cream_rpe_index_bwd_host(void* gin, const void* gout, const int32_t* idx,
 /* Padded token count used by the side buffers below: N rounded up to a multiple of 32. */
 int cream_attn_rpe2d_padded_len(int N);
 
+/* Number of partial table-gradient blocks cream_attn_rpe2d_bwd writes for a (B, H) problem on the current device:
+ * one per persistent workgroup of its dK/dV kernel, min(B*H, compute units). */
+int cream_attn_rpe2d_dtab_parts(int B, int H);
+
 /* The attention core of AttentionSuper.forward between the qkv and proj GEMMs
  * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
  * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
@@ -115,9 +119,10 @@ int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp,
  * the index_put of RelativePosition2D_super's table lookup, multihead_super.py:64):
  *   dq, dk, dv : gradients, element (b, n, h, d) at ptr[b*dsb + n*dsn + h*dsh + d] (may alias
  *                one (B, N, 3, H, 64) buffer), same dtype as q
- *   dtab       : (B*H, 4, 32, 64) fp32, per-(b,h) gradients of [tkv, tkh, tvv, tvh] (rows
- *                >= 2*mr+2 are zero); the caller sums over the first axis — a fixed-order
- *                reduction instead of atomics
+ *   dtab       : (cream_attn_rpe2d_dtab_parts(B, H), 4, 32, 64) fp32, partial gradients of [tkv, tkh, tvv, tvh]
+ *                (rows >= 2*mr+2 are zero): the tables are shared by every (b, h), each persistent workgroup of the
+ *                dK/dV kernel accumulates over its items and writes one block; the caller sums over the first
+ *                axis — a fixed-order reduction instead of atomics
  *   dlt, qe, de, delta : scratch handed from the first to the second launch:
  *                dlt (B,H,64,NP) and qe, de (B,H,NP,32) in q's dtype, delta (B,H,NP) fp32
  *   dout, out  : (B, N, H, 64) contiguous, q's dtype;  lse, sp: as written by the forward
