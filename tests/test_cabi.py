@@ -136,3 +136,6 @@ def test_new_entry_points_validate_arguments_without_launching():
     assert lib.cream_adamw_step(0x1000, 0x1000, 2, 5, 1, 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1  # update needs step >= 1
     assert lib.cream_colsum128_slabs(25216) == 197 and lib.cream_colsum128_slabs(0) == 0
     assert lib.cream_ln_partials() > 0
+    # table-gradient partials of the attention backward: one per persistent workgroup, never more than the (b, h) items
+    assert lib.cream_attn_rpe2d_dtab_parts(0, 6) == 0 and lib.cream_attn_rpe2d_dtab_parts(2, 3) == 6
+    assert 1 <= lib.cream_attn_rpe2d_dtab_parts(128, 6) <= 768
