@@ -224,6 +224,9 @@ class CLIP(nn.Module):
         ft = self._text_encoder(text, normalized=normalized) if text is not None else None
         return fi, ft, self._logit_scale().exp()
 
+    def load_state_dict(self, state_dict, strict=True):                         # model.py:1049-1070
+        return super().load_state_dict(convert_to_new_checkpoint(state_dict), strict=strict)
+
     def lock_image_tower(self):                                                 # model.py:1015-1021
         for p in self._image_encoder.parameters():
             p.requires_grad = False
@@ -231,6 +234,36 @@ class CLIP(nn.Module):
     def lock_text_tower(self):
         for p in self._text_encoder.parameters():
             p.requires_grad = False
+
+
+def convert_to_new_checkpoint(state_dict):
+    """Any of the layouts TinyCLIP / OpenCLIP checkpoints come in -> the `_image_encoder. / _text_encoder. /
+    _logit_scale.` layout of this class (model.py:1115-1157 with `used_ddp=False`, plus the `.module` strip of
+    `CLIPBase.load_state_dict`, :1066-1070):
+      * the new layout saved from DDP-wrapped towers (`_image_encoder.module.visual...`): the `module` level is removed;
+      * the old single-module layout (`visual.*`, `logit_scale`, text keys at the root), optionally under `module.`."""
+    if '_logit_scale.module.logit_scale' in state_dict:
+        out = {}
+        for k, v in state_dict.items():
+            sp = k.split('.')
+            assert sp[1] == 'module', k
+            out['.'.join(sp[:1] + sp[2:])] = v
+        return out
+    if '_logit_scale.logit_scale' in state_dict:
+        return dict(state_dict)
+    if 'module.logit_scale' in state_dict:
+        state_dict = {k[len('module.'):]: v for k, v in state_dict.items()}
+    if 'logit_scale' not in state_dict:
+        return dict(state_dict)
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith('visual.'):
+            out['_image_encoder.' + k] = v
+        elif k == 'logit_scale':
+            out['_logit_scale.logit_scale'] = v
+        else:
+            out['_text_encoder.' + k] = v
+    return out
 
 
 # open_clip/model_configs/*.json of the configurations BASELINE config 5 names
@@ -258,4 +291,4 @@ def n_params(m):
 
 
 __all__ = ["CLIP", "ImageEncoder", "TextEncoder", "VisualTransformer", "Transformer", "ResidualAttentionBlock", "LayerNorm",
-           "QuickGELU", "MODEL_CONFIGS", "create_model", "n_params"]
+           "QuickGELU", "MODEL_CONFIGS", "create_model", "n_params", "convert_to_new_checkpoint"]

@@ -443,6 +443,33 @@ def detr():
     save('detr_rpe_attention.npz', **outs)
 
 
+def tinyclip_ckpt_layouts(keys):
+    """The layouts a CLIP checkpoint is found in, built from the new-layout key list."""
+    new = {k: i for i, k in enumerate(keys)}
+    ddp = {'.'.join(k.split('.')[:1] + ['module'] + k.split('.')[1:]): v for k, v in new.items()}
+    old = {}
+    for k, v in new.items():
+        head, rest = k.split('.', 1)
+        old[rest if head != '_logit_scale' else 'logit_scale'] = v
+    old_ddp = {'module.' + k: v for k, v in old.items()}
+    return dict(new=new, new_from_ddp=ddp, old=old, old_under_module=old_ddp)
+
+
+def tinyclip_ckpt():
+    """open_clip/model.py convert_to_new_checkpoint(used_ddp=False) + the `.module` strip of CLIPBase.load_state_dict on
+    the four layouts: resulting key -> value id."""
+    m = refshim.load_tinyclip_model()
+    c = TINYCLIP_CASES['small_quickgelu']
+    model = m.CLIP(c['embed_dim'], dict(c['vision_cfg']), dict(c['text_cfg']), quick_gelu=True)
+    keys = list(model.state_dict().keys())
+    out = {}
+    for name, sd in tinyclip_ckpt_layouts(keys).items():
+        conv = m.convert_to_new_checkpoint(dict(sd), False)
+        conv = {k.replace('.module', ''): v for k, v in conv.items()}                   # CLIPBase.load_state_dict :1066-1070
+        out[name] = conv
+    json.dump(dict(keys=keys, converted=out), open(os.path.join(HERE, 'tinyclip_ckpt.json'), 'w'))
+
+
 RASAMPLER_CASES = [(1000, 1, 0, 0, True), (1000, 4, 3, 5, True), (777, 8, 2, 1, True), (513, 3, 1, 7, False), (256, 2, 1, 2, True),
                    (300, 7, 6, 3, True), (5000, 8, 0, 11, True)]          # (dataset length, replicas, rank, epoch, shuffle)
 
@@ -609,3 +636,5 @@ if __name__ == '__main__':
         tinyclip_model()
     if 'rasampler' in which:
         rasampler()
+    if 'tinyclip_ckpt' in which:
+        tinyclip_ckpt()

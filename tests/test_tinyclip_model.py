@@ -188,3 +188,22 @@ def test_distill_step_world2_equals_the_global_batch_step():
         for k, v in ref.items():
             g = torch.from_numpy(got[rank][2][k])
             assert torch.allclose(g, v, rtol=2e-4, atol=2e-6), (rank, k, float((g - v).abs().max()))
+
+
+def test_checkpoint_layouts_convert_like_the_reference():
+    """New layout, new layout saved from DDP-wrapped towers, old single-module layout, old layout under `module.`:
+    every one lands on the keys (and tensors) the reference's convert_to_new_checkpoint + load_state_dict produce."""
+    from make_golden import tinyclip_ckpt_layouts
+    from cream_amd.tinyclip.model import CLIP, convert_to_new_checkpoint
+    rec = load_json("tinyclip_ckpt.json")
+    for name, sd in tinyclip_ckpt_layouts(rec["keys"]).items():
+        assert convert_to_new_checkpoint(sd) == rec["converted"][name], name
+    c = TINYCLIP_CASES["small_quickgelu"]
+    src = build("small_quickgelu")
+    old = {}
+    for k, v in src.state_dict().items():
+        head, rest = k.split(".", 1)
+        old["module." + (rest if head != "_logit_scale" else "logit_scale")] = v.clone()
+    dst = CLIP(c["embed_dim"], dict(c["vision_cfg"]), dict(c["text_cfg"]), quick_gelu=True)
+    dst.load_state_dict(old)
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
