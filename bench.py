@@ -14,19 +14,22 @@ then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks; r
 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      — the dominant hand-written kernel family of the step (by total time): algorithmic
-                  flops / HIP-event time on its launch stream (cream_amd.timing).  The timed region
-                  enqueues every block with ONE native call, so the events are taken in a SEPARATE
-                  op-by-op pass right after it (same kernels, shapes, process; one stream) — said so
-                  in the line ("timing": "separate pass");
+  roofline      — the dominant hand-written kernel family of the step BY IN-STEP TIME: algorithmic flops / HIP-event
+                  time, events recorded inside the native block calls (csrc/block_seq.cpp: cream_block_prof_*) on the
+                  stream each kernel is launched on, in a pass of the SAME two-stream native step right after the timed
+                  region (the timed region itself carries no events); `mfma_util` / `traffic` of the same kernels come
+                  from the committed rocprofv3 PMC passes under profiles/ (counters cannot be read in-process);
+  rpe_index_config4 — the rpe_index gather / scatter-add at BASELINE config 4 (B=64, H=12, L=577, 50 buckets), fp32 and
+                  bf16: algorithmic GB/s and fraction of the 8 TB/s HBM peak (HIP events, median of 20 launches);
   roofline_step — whole-step algorithmic rate: 28.6 GFLOP per image (SURVEY 8d) x images/s / 2.5 PF;
   per_embed_dim — mean GPU ms per step by sampled embed dim (events between steps, no host sync);
   host_unstalled — the same step at batch 4 (host-bound: same launches, ~30x less device work): what the host needs to
                   enqueue a step when the launch queue is never full (`host_enqueue_ms_per_step` of the timed region
                   includes waiting for queue slots whenever the device is the bottleneck);
-  cpu_baseline  — the oracle (CPU fp32 restatement of the reference step, oracle/) timed on this box's
-                  host cores on a bounded sample: best of several thread counts (rank 0, N=1 only),
-                  CPU model stated; plus the iRPE pure-PyTorch path at config-4 shapes (B = 2).
+  cpu_baseline  — kind "port": the oracle (CPU fp32 restatement of the reference step, oracle/autoformer_oracle.py)
+                  timed on this box's host cores on a bounded sample at batch 64: best of 16 / 64 / all hardware
+                  threads (rank 0, N=1 only), CPU model stated; plus one RPEAttention layer at config-4 shapes in
+                  the reference's own pure-PyTorch formulation (oracle/irpe_oracle.py: flat-index gather, irpe.py:646).
   tinyclip_config5 — BASELINE config 5's distillation step on one device (student ViT-39M/16 + Text-19M, teacher ViT-B/16);
   irpe_config4  — BASELINE config 4 on the device: one RPEAttention layer (DeiT-B-384 + iRPE, L = 577) fwd+bwd
                   through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only).
@@ -63,7 +66,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "bucketed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=28.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the tiny-batch pass that measures the unstalled host cost of a step")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -71,6 +74,7 @@ def parse():
     ap.add_argument("--subnet", default=None, choices=["T", "S"],
                     help="train ONE fixed published sub-network of that supernet (BASELINE config 2: T)")
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-irpe", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -95,27 +99,44 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_irpe_leg(seconds):
-    """The iRPE half of the path on the host: one RPEAttention layer (DeiT-base-384 geometry, H = 12,
-    L = 577, product-ctx 50 buckets, rpe on k) forward + backward at B = 2 through the pure-PyTorch
-    modules (the reference's own fallback formulation is the fair CPU baseline)."""
-    from cream_amd import irpe as I
-    from cream_amd.rpe_attention import RPEAttention
-    cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="k")
-    att = RPEAttention(768, num_heads=12, qkv_bias=True, rpe_config=cfg)
-    x = torch.randn(2, 577, 768, requires_grad=True)
-    att(x).sum().backward()
+def cpu_irpe_leg(seconds, threads=0):
+    """The iRPE half of the path on the host, kind "port": one RPEAttention layer (DeiT-base-384 geometry, C = 768, H = 12,
+    L = 577, product / contextual, 50 buckets, rpe on k) forward + backward at B = 2 in the reference's own PURE-PYTORCH
+    formulation — lookup = q W, gathered with the flat index i * nb + bucket[i, j] (irpe.py:573-583, :646-647), which is
+    what the reference runs on a host where its rpe_index_cpp extension is not built (oracle/irpe_oracle.py, pinned
+    against reference-made fixtures)."""
+    from oracle import irpe_oracle as IO
+    if threads > 0:
+        torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    C, H, L, B = 768, 12, 577, 2
+    ids, nb = IO.product_bucket_ids(24, 24, 1)
+    p = {"qkv.weight": torch.randn(3 * C, C) * C ** -0.5, "qkv.bias": torch.zeros(3 * C),
+         "rpe_k.lookup_table_weight": 0.02 * torch.randn(1, 64, nb), "proj.weight": torch.randn(C, C) * C ** -0.5,
+         "proj.bias": torch.zeros(C)}
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    x = torch.randn(B, L, C, requires_grad=True)
+
+    def once():
+        IO.rpe_attention_layer(p, x, H, ids, nb).sum().backward()
+        x.grad = None
+        for v in p.values():
+            v.grad = None
+
+    once()
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds and n < 20:
-        att(x).sum().backward()
+        once()
         n += 1
     dt = (time.perf_counter() - t0) / max(1, n)
-    return dict(ms_per_layer_fwd_bwd=round(dt * 1e3, 1), batch=2, sample=f"{n} RPEAttention fwd+bwd, B=2 H=12 L=577 fp32")
+    return dict(ms_per_layer_fwd_bwd=round(dt * 1e3, 1), batch=B, cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} RPEAttention fwd+bwd, B={B} H={H} L={L} fp32, reference's pure-PyTorch formulation (irpe.py:646 flat-index "
+                       "gather; oracle/irpe_oracle.py)")
 
 
-def cpu_baseline(size, seconds, threads=0):
+def cpu_baseline(size, seconds, threads=0, B=64):
     """Reference step restated on the CPU (oracle/autoformer_oracle.py), fp32, `threads` intra-op
-    threads (0 = torch's default = all cores), B=16, random sub-networks from the same draw
+    threads (0 = torch's default = all cores), batch B, random sub-networks from the same draw
     sequence, AdamW over the full supernet.  Bounded: warm-up 1 step, then steps until `seconds`."""
     import random
     from oracle import autoformer_oracle as AO
@@ -123,7 +144,6 @@ def cpu_baseline(size, seconds, threads=0):
     if threads > 0:
         torch.set_num_threads(threads)
     space = engine.SEARCH_SPACES[size]
-    B = 16
     torch.manual_seed(0)
     model = engine.build_supernet(size, drop_path_rate=0.0).float()      # parameter container
     params = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
@@ -146,14 +166,16 @@ def cpu_baseline(size, seconds, threads=0):
         if elapsed >= seconds or n >= 50:
             break
     return dict(value=round(n * B / elapsed, 2), unit="images/sec", cores=torch.get_num_threads(),
-                kind="port", sample=f"{n} AutoFormer-{size} supernet steps of batch {B} (fp32, oracle/autoformer_oracle.py)")
+                kind="port", sample=f"{n} AutoFormer-{size} supernet steps of batch {B} (fp32, oracle/autoformer_oracle.py: the "
+                                    "reference's dense formulation restated; NOT the reference's own code — timm is not vendored)")
 
 
 def cpu_baseline_best(size, seconds):
-    """Best of several intra-op thread counts (an oversubscribed pool at B = 16 was 3x slower than 8
-    threads in round 1), each in its own process, plus the iRPE leg; CPU model and counts stated."""
+    """Best of 16 / 64 / all hardware threads at batch 64 (an oversubscribed pool at batch 16 was 3x slower than 8 threads
+    in round 1; a larger batch gives the wide pools enough work), each in its own process, plus the iRPE leg; CPU model
+    and counts stated."""
     ncpu = os.cpu_count() or 1
-    counts = sorted({c for c in (8, 16, 32) if c <= ncpu}) or [ncpu]     # (all 256 cores: the B = 16 oracle step takes minutes)
+    counts = sorted({c for c in (16, 64, ncpu) if c <= ncpu}) or [ncpu]
     per = max(4.0, seconds / (len(counts) + 1))
     tried, best = {}, None
     for c in counts:
@@ -167,7 +189,7 @@ def cpu_baseline_best(size, seconds):
     best["threads_tried"] = tried
     best["cpu_model"] = cpu_model()
     best["host_cores"] = ncpu
-    irpe = cpu_baseline_subprocess(size, per, irpe=True)
+    irpe = cpu_baseline_subprocess(size, per, threads=min(64, ncpu), irpe=True)
     if irpe:
         best["irpe_config4_cpu"] = irpe
     return best
@@ -180,12 +202,12 @@ def cpu_baseline_subprocess(size, seconds, threads=0, irpe=False):
     the pool of a finished CPU run was still alive in the benchmark process)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--supernet", size,
-           "--cpu-seconds", str(seconds), "--cpu-threads", str(-1 if irpe else threads)]
+           "--cpu-seconds", str(seconds), "--cpu-threads", str(threads)] + (["--cpu-irpe"] if irpe else [])
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=seconds * 4 + 90)
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=seconds * 6 + 120)
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -208,6 +230,76 @@ def pmc_traffic(region):
     rec = json.load(open(files[-1]))
     val = rec.get("traffic_bytes_per_launch_by_timed_region", {}).get(region)
     return (val, os.path.relpath(files[-1], ROOT)) if val else (None, None)
+
+
+def pmc_kernels(pattern):
+    """{kernel name: {mfma_util, hbm_read_MB_corrected, hbm_write_MB, ...}} of the kernels whose name contains `pattern`, from the
+    newest committed profiles/*_kernels_pmc.json (rocprofv3 --pmc passes of this bench command, tools/summarize_pmc.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernels_pmc.json")))
+    if not files:
+        return None
+    rec = json.load(open(files[-1]))
+    out = {k: v for k, v in rec.get("kernels", {}).items() if pattern in k}
+    return dict(source=os.path.relpath(files[-1], ROOT), kernels=out) if out else None
+
+
+def native_prof_summary():
+    """Collect the in-step HIP-event records of csrc/block_seq.cpp -> {name: dict(launches, total_ms, avg_ms, flops, bytes)}."""
+    import ctypes
+    from cream_amd import _lib
+    lib = _lib.load()
+    n = lib.cream_block_prof_kinds()
+    ms, cnt, fl, by = (ctypes.c_double * n)(), (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    _lib.check(lib.cream_block_prof_collect(ms, cnt, fl, by), "cream_block_prof_collect")
+    out = {}
+    for k in range(n):
+        if cnt[k]:
+            out[lib.cream_block_prof_name(k).decode()] = dict(launches=int(cnt[k]), total_ms=ms[k], avg_ms=ms[k] / cnt[k],
+                                                              flops=fl[k], bytes=by[k])
+    return out
+
+
+def rpe_index_config4_leg(iters=20, warmup=3):
+    """north_star's first rocprof figure, measured live: the rpe_index gather (cream_rpe_index_fwd) and scatter-add
+    (cream_rpe_index_bwd) at BASELINE config 4 — DeiT-B-384 + iRPE: B = 64, H = 12, L = 577, 50 buckets — through the
+    Python operator (iRPE's transposed input view), fp32 and bf16.  Algorithmic bytes: lookup rows
+    B H L nb s + index L L 4 + output B H L L s; median of `iters` launches between HIP events on the launch stream."""
+    from cream_amd import rpe_index as R
+    dev = torch.device("cuda")
+    B, H, L, nb = 64, 12, 577, 50
+    index = torch.randint(0, nb, (L, L), dtype=torch.int32, device=dev)
+
+    def med(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return ts[len(ts) // 2]
+
+    out = {"workload": "rpe_index gather / scatter-add, B=64 H=12 Lq=Lk=577 nb=50 (DeiT-B-384 + iRPE product-ctx)", "peak_GBps": PEAK_HBM_GBS}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        s_ = torch.empty((), dtype=dt).element_size()
+        x = torch.randn(H, B, L, nb, device=dev).to(dt).transpose(0, 1)
+        g = torch.randn(B, H, L, L, device=dev).to(dt)
+        gin = torch.zeros(B, H, L, nb, device=dev, dtype=dt)
+        nbytes = B * H * L * nb * s_ + L * L * 4 + B * H * L * L * s_
+        f = med(lambda: R.forward_gpu(x, index))
+        b = med(lambda: R.backward_gpu(gin, g, index, accumulate=False))
+        out[name] = {"algorithmic_MB": round(nbytes / 1e6, 1),
+                     "gather": {"us": round(f * 1e3, 1), "GBps": round(nbytes / f / 1e6, 1), "frac": round(nbytes / f / 1e6 / PEAK_HBM_GBS, 4)},
+                     "scatter": {"us": round(b * 1e3, 1), "GBps": round(nbytes / b / 1e6, 1), "frac": round(nbytes / b / 1e6 / PEAK_HBM_GBS, 4)}}
+        del x, g, gin
+    pmc = pmc_kernels("rpe_")
+    if pmc:
+        out["pmc"] = pmc
+    return out
 
 
 def irpe_config4_leg(iters=10):
@@ -300,7 +392,7 @@ def tinyclip_config5_leg(batch=256, iters=10):
 def main():
     a = parse()
     if a.cpu_baseline_only:
-        res = cpu_irpe_leg(a.cpu_seconds) if a.cpu_threads < 0 else cpu_baseline(a.supernet, a.cpu_seconds, a.cpu_threads)
+        res = cpu_irpe_leg(a.cpu_seconds, a.cpu_threads) if a.cpu_irpe else cpu_baseline(a.supernet, a.cpu_seconds, a.cpu_threads)
         print(json.dumps(res), flush=True)
         return
     from cream_amd import comm, timing
@@ -385,28 +477,35 @@ def main():
         host_leg = {"batch": hb, "steps": 20, "enqueue_ms_per_step": round(t_enq / 20 * 1e3, 3),
                     "ms_per_step": round((time.perf_counter() - t0) / 20 * 1e3, 3)}
 
-    # Kernel-level timing for the roofline entry: HIP events around the attention launches, on the
-    # launch stream.  The timed region above enqueues each block with ONE native call
-    # (csrc/block_seq.cpp), which leaves no place for host-side events, so the same kernels are
-    # timed right after it in a short pass that drives them op by op (identical launches and
-    # shapes, same process, same sub-network distribution).
+    # Kernel-level timing for the roofline entry: HIP events recorded INSIDE the native block calls (csrc/block_seq.cpp,
+    # cream_block_prof_*), each pair on the stream its kernel is launched on, over a pass of the same two-stream native
+    # step right after the timed region — so durations include the contention between the weight-gradient GEMMs on the
+    # side stream and the main chain, as in the timed steps (the op-by-op single-stream pass of round 2 did not).
+    ksum = {}
     if not a.no_kernel_timing:                # every rank runs the pass (its steps contain collectives)
-        from cream_amd.autoformer import block as _blk
-        native, side = _blk.NATIVE_BLOCK, _blk.WGRAD_SIDE_STREAM
-        _blk.NATIVE_BLOCK = _blk.WGRAD_SIDE_STREAM = False     # one stream: nothing overlaps the timed kernels
-        timing.reset()
-        timing.enable(True, only=("attn_rpe2d_fwd", "attn_rpe2d_bwd", "rpe_index_fwd", "rpe_index_bwd", "gemm_nt",
-                                  "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad"))
+        from cream_amd import _lib
+        lib = _lib.load()
+        native_prof_summary()                 # (drop stale records)
         trainer.start_epoch(0)
-        for _ in range(max(4, min(a.steps, 12))):
+        lib.cream_block_prof_enable(1)
+        pm = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        nprof = max(4, min(a.steps, 12))
+        pm[0].record()
+        for _ in range(nprof):
             trainer.step(images, target)
+        pm[1].record()
         torch.cuda.synchronize()
-        timing.enable(False)
-        _blk.NATIVE_BLOCK, _blk.WGRAD_SIDE_STREAM = native, side
+        lib.cream_block_prof_enable(0)
+        ksum = native_prof_summary()
+        prof_ms_per_step = pm[0].elapsed_time(pm[1]) / nprof
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])       # proof that `world` ranks on distinct devices took part
+        devices = gathered
     dt = t.item()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -414,12 +513,11 @@ def main():
         cpu = cpu_baseline_best(a.supernet, a.cpu_seconds)            # after the GPU measurement, own processes
 
     if rank == 0:
-        ksum = timing.summary() if not a.no_kernel_timing else {}
         roof = None
         if ksum:
-            # dominant hand-written kernel by total time in the timed region
+            # dominant hand-written kernel family by total IN-STEP time (both streams live)
             name, st = max(ksum.items(), key=lambda kv: kv[1]["total_ms"])
-            if st["flops"] and not st["bytes"]:
+            if st["flops"]:
                 peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
                 ach = st["flops"] / (st["total_ms"] * 1e-3) / 1e12
                 roof = dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
@@ -433,11 +531,17 @@ def main():
                 roof["traffic_unit"] = "HBM bytes per launch (mean over the sampled sub-networks), rocprofv3 PMC pass: " + src
             roof["launches"] = st["launches"]
             roof["avg_us"] = round(st["avg_ms"] * 1e3, 2)
-            roof["timing"] = "separate pass: HIP events around every launch in an op-by-op run right after the timed region"
+            roof["timing"] = ("in-step: HIP events inside the native block calls, on each kernel's launch stream, two streams live; "
+                              f"{nprof} steps right after the timed region at {round(prof_ms_per_step, 3)} ms/step with the events in place")
             roof["kernels"] = {k: dict(launches=v["launches"], avg_us=round(v["avg_ms"] * 1e3, 2),
-                                       total_ms=round(v["total_ms"], 3),
-                                       tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["flops"] else None)
+                                       total_ms=round(v["total_ms"], 3), ms_per_step=round(v["total_ms"] / nprof, 3),
+                                       tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                                       GBps=round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
                                for k, v in sorted(ksum.items())}
+            qk = pmc_kernels("attn_rpe2d")
+            if qk and a.supernet == "S":
+                roof["qkt_mfma_util"] = dict(source=qk["source"], note="SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs), "
+                                             "rocprofv3 PMC pass of this command", kernels={k: v.get("mfma_util") for k, v in qk["kernels"].items()})
         ips = a.steps * a.batch * world / dt
         what = (f"AutoFormer-{a.subnet} published sub-network (experiments/subnet/AutoFormer-{a.subnet}.yaml) train step"
                 if a.subnet else f"AutoFormer-{a.supernet} supernet train step, random-path sampling (random.seed(epoch))")
@@ -454,6 +558,10 @@ def main():
             "config": {"workload": f"{what}, per-GPU batch {a.batch}, 224x224, AdamW, grad all-reduce RCCL",
                        "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "attention_impl": a.impl,
+                       "comm": {"world": world, "backend": (dist.get_backend() if dist.is_initialized() else "none"),
+                                "devices": devices, "grad_bytes_per_step_last": reducer.bytes_sent,
+                                "grad_bytes_full_buckets": int(reducer.arena.numel() * 4),
+                                "message": "active slices of the sampled sub-network per block bucket (csrc/slices.hip), side stream"},
                        "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp), no vendor GEMM library"},
             "roofline": roof,
             "roofline_step": ({"achieved": round(28.6e9 * ips / world / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -466,7 +574,14 @@ def main():
         }
         if world == 1 and a.supernet == "S" and not a.subnet and not a.no_kernel_timing and a.dtype == "bf16":
             try:                                   # after and outside the timed region; must not lose the line
+                line["rpe_index_config4"] = rpe_index_config4_leg()
+            except Exception as e:
+                sys.stderr.write(f"[bench] rpe_index config-4 leg failed: {e}\n")
+            try:
                 line["irpe_config4"] = irpe_config4_leg()
+                pm_ = pmc_kernels("irpe_attn")
+                if pm_:
+                    line["irpe_config4"]["qkt_mfma_util"] = dict(source=pm_["source"], kernels={k: v.get("mfma_util") for k, v in pm_["kernels"].items()})
             except Exception as e:
                 sys.stderr.write(f"[bench] iRPE config-4 leg failed: {e}\n")
             try:

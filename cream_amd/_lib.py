@@ -84,6 +84,11 @@ SIGNATURES = {
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
+    "cream_block_prof_enable": (_i, [_i]),
+    "cream_block_prof_kinds": (_i, []),
+    "cream_block_prof_name": (_c.c_char_p, [_i]),
+    "cream_block_prof_collect": (_i, [_vp, _vp, _vp, _vp]),
+    "cream_slices_copy": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "cream_block_fwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
     "cream_block_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cream_block_bwd_workspace": (_i64, [_vp, _vp, _vp, _vp]),
@@ -98,6 +103,11 @@ class GradJob(ctypes.Structure):
     _fields_ = [("dst", _vp), ("src", _vp), ("ld", _i64), ("pstride", _i64),
                 ("nparts", _c.c_int32), ("rows", _c.c_int32), ("cols", _c.c_int32),
                 ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("reserved", _c.c_int32)]
+
+class SliceJob(ctypes.Structure):
+    """struct cream_slice_job of include/cream_amd.h."""
+    _fields_ = [("full", _vp), ("ld", _i64), ("packed_off", _i64), ("rows", _c.c_int32), ("cols", _c.c_int32)]
+
 
 class BlockDesc(ctypes.Structure):
     """struct cream_block_desc of include/cream_amd.h."""

@@ -424,6 +424,7 @@ class BlockOperands:
         self.key = self._key()
         self.versions = None
         self._table = None
+        _register(self)
 
     def _key(self):
         return tuple(m.weight.data_ptr() for m in self.mods)
@@ -456,6 +457,32 @@ class BlockOperands:
 
 _OPS_KEY = '_cream_operands'
 
+# Every live operand set, so that an optimizer the library does not know can invalidate them: fused optimizers
+# (torch.optim.AdamW / SGD with fused=True) and writes through `.data` leave `Tensor._version` unchanged, so the version
+# test of `stale()` alone would keep the block GEMMs on the initial weights forever.  engine.NativeAdamW rewrites the
+# copies itself and is skipped.
+import weakref as _weakref
+
+_ALL_OPERANDS = _weakref.WeakSet()
+_optimizer_hook = None
+
+
+def _register(ops):
+    global _optimizer_hook
+    _ALL_OPERANDS.add(ops)
+    if _optimizer_hook is None:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+
+        def after_any_optimizer_step(opt, args, kwargs):
+            if getattr(opt, '_cream_rewrites_operands', False):
+                return
+            mine = {p.data_ptr() for g in opt.param_groups for p in g['params']}
+            for ops in list(_ALL_OPERANDS):
+                if any(k in mine for k in ops._key()):
+                    ops.versions = None                      # stale: re-derived on the next use
+
+        _optimizer_hook = register_optimizer_step_post_hook(after_any_optimizer_step)
+
 
 class PatchOperands:
     """bf16 operand copy of the patch-embedding weight viewed as (E_super, C*ph*pw) and of its bias — the
@@ -471,6 +498,7 @@ class PatchOperands:
         self.key = self._key()
         self.versions = None
         self._table = None
+        _register(self)
 
     def _key(self):
         return (self.mod.weight.data_ptr(),)
@@ -605,6 +633,14 @@ def stem_supported(model, x):
     if not (patch_embed_supported(pe, x) and x.dtype == torch.float32 and pe.patch_size[1] % 8 == 0 and E % 4 == 0):
         return False
     if pos is not None and (pos.shape[0] != 1 or pos.shape[-1] % 4 or pos.dtype != torch.float32):
+        return False
+    # PatchembedSuper.forward's own assertion (embedding_super.py:28-31) and the geometry the kernels index with raw
+    # pointers: anything else takes the composed path, which asserts
+    H, W = x.shape[-2:]
+    ph, pw = pe.patch_size
+    if (H, W) != tuple(pe.img_size) or H % ph or W % pw:
+        return False
+    if pos is not None and pos.shape[1] != (H // ph) * (W // pw) + 1:
         return False
     return not (model.training and (model.sample_dropout or 0.0) > 0.0)
 

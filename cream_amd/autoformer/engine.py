@@ -80,6 +80,11 @@ class NativeAdamW(torch.optim.Optimizer):
     the bf16 operand copies (and their transposes) the block GEMMs read.  State layout = torch's
     (`exp_avg`, `exp_avg_sq`, `step` per parameter), so checkpoints move between the two.
 
+    Two documented differences from torch.optim.AdamW: ONE global step counter (torch counts per parameter and skips
+    parameters whose grad is None) — blocks beyond every sampled depth so far therefore see bias correction and weight
+    decay from step 1 here, as they do under the reference's torch 1.7 once they were active (SURVEY 8e);
+    `load_state_dict` takes max(step) and creates zero moments for parameters the file has no state for.
+
     Every parameter must have a `.grad` tensor when `step()` runs (the trainer zero-fills instead of
     setting None — SURVEY 8e: under the reference's torch 1.7 every tensor that was active once keeps
     receiving weight decay and moment decay); the device-resident job table is rebuilt only if a
@@ -88,6 +93,7 @@ class NativeAdamW(torch.optim.Optimizer):
     def __init__(self, model, param_groups, lr, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0))
         self.model = model
+        self._cream_rewrites_operands = True     # (block._register: no invalidation needed after this optimizer's step)
         self._steps = 0
         self._table = None
         self._grads = ()
@@ -100,6 +106,12 @@ class NativeAdamW(torch.optim.Optimizer):
 
     def _build(self):
         wd = {p: g['weight_decay'] for g in self.param_groups for p in g['params']}
+        for p in wd:                             # a torch.optim.AdamW checkpoint holds no state for never-active parameters
+            st = self.state[p]
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if k not in st or st[k].device != p.device:
+                    st[k] = (torch.zeros_like(p, memory_format=torch.contiguous_format) if k not in st
+                             else st[k].to(p.device).contiguous())
         states = {p: (st['exp_avg'], st['exp_avg_sq']) for p, st in self.state.items()}
         for p in wd:
             if p.grad is None:
@@ -128,11 +140,20 @@ class NativeAdamW(torch.optim.Optimizer):
         self._table = _block.JobTable(jobs, next(iter(wd)).device)
         self._plist = tuple(wd)
         self._grads = tuple(p.grad for p in wd)
+        self._ptrs = self._pointer_key()
+
+    def _pointer_key(self):
+        """Raw pointers baked into the device job table: model.to(), `p.data = ...`, re-created moments or an added
+        parameter group move them without touching the gradient objects."""
+        return tuple((p.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
+                     if 'exp_avg' in self.state[p] else (p.data_ptr(), 0, 0)
+                     for g in self.param_groups for p in g['params'])
 
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
-        if self._table is None or any(p.grad is not g for p, g in zip(self._plist, self._grads)):
+        if (self._table is None or any(p.grad is not g for p, g in zip(self._plist, self._grads))
+                or self._ptrs != self._pointer_key()):
             self._build()
         g0 = self.param_groups[0]
         lr = g0['lr']

@@ -163,7 +163,7 @@ class EvolutionSearcher:
     def load_checkpoint(self, path):
         if not os.path.exists(path):
             return False
-        info = torch.load(path, weights_only=False)        # our own file: tuples and dicts of python scalars
+        info = torch.load(path, weights_only=True)         # tuples / dicts / lists of python scalars: the safe unpickler reads them
         self.memory, self.candidates, self.vis_dict = info['memory'], info['candidates'], info['vis_dict']
         self.keep_top_k, self.epoch = info['keep_top_k'], info['epoch']
         self.top_accuracies = info.get('top_accuracies', [])

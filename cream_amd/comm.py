@@ -16,6 +16,10 @@ for the CPU tests).  Design points, MI355X-first rather than DDP-reducer-first:
     so the set of parameters that receive gradients is known up front: blocks beyond the
     sampled depth are not "unused parameters" to be discovered, their buckets are simply
     not sent (their gradients stay exactly zero on every rank).  No dead bytes on xGMI.
+  * ACTIVE-SLICE messages: a sampled sub-network only writes W.grad[:out, :in] of every super weight, and the
+    configuration is the same on every rank — so a bucket's message is the contiguous gather of those slices
+    (one HIP launch to pack, one to scatter the result back: csrc/slices.hip), not the full super bucket:
+    supernet-S sends 52-139 MB per step depending on the sampled widths instead of always 139 MB (SURVEY 8e);
   * averaging = one AVG all-reduce where the backend has it (RCCL), else SUM followed by an
     in-place 1/world scale (gloo) — DDP semantics; lr is already scaled by the world size,
     supernet_train.py:294;
@@ -29,6 +33,36 @@ import torch
 import torch.distributed as dist
 
 
+def autoformer_active_slice(name, p, config):
+    """(rows, cols) of the part of parameter `name` (viewed as (numel / last dim, last dim); the patch-embedding
+    convolution as (out, C*ph*pw)) that a sub-network with `config` can write — the slicing rules of
+    Linear_super.py:71-81, qkv_super.py:72-83 (rows 3 i + j, i < Q = rows [0, 3 Q)), layernorm_super.py:26-37,
+    embedding_super.py:33-40 and supernet_transformer.py:147-172.  Unknown names: the whole tensor."""
+    E = config["embed_dim"][0]
+    last = p.shape[-1] if p.dim() > 1 else p.numel()
+    full = (p.numel() // last, last)
+    parts = name.split(".")
+    if parts[0] == "blocks":
+        i = int(parts[1])
+        if i >= config["layer_num"]:
+            return (0, 0)
+        Q = 64 * config["num_heads"][i]
+        F_ = int(E * config["mlp_ratio"][i])
+        leaf = ".".join(parts[2:])
+        rule = {"attn.qkv.weight": (3 * Q, E), "attn.qkv.bias": (1, 3 * Q), "attn.proj.weight": (E, Q),
+                "attn.proj.bias": (1, E), "fc1.weight": (F_, E), "fc1.bias": (1, F_), "fc2.weight": (E, F_),
+                "fc2.bias": (1, E), "attn_layer_norm.weight": (1, E), "attn_layer_norm.bias": (1, E),
+                "ffn_layer_norm.weight": (1, E), "ffn_layer_norm.bias": (1, E)}.get(leaf)
+        return rule if rule is not None else full
+    if name == "patch_embed_super.proj.weight":
+        return (E, p.numel() // p.shape[0])
+    if name in ("patch_embed_super.proj.bias", "norm.weight", "norm.bias", "cls_token"):
+        return (1, E)
+    if name in ("pos_embed", "head.weight"):
+        return (full[0], E)
+    return full
+
+
 class GradReducer:
     """mode 'allreduce' (default): one all-reduce per bucket.  mode 'rs_ag': reduce-scatter + all-gather
     per bucket — on the xGMI full mesh (7 point-to-point links per GPU) each phase moves 1/world of the
@@ -36,9 +70,13 @@ class GradReducer:
     link per step for supernet-S instead of ~244 MB over one); buckets are padded to a multiple of the
     world size inside the arena.  Same API, same results (fixed reduction order per shard)."""
 
-    def __init__(self, model, process_group=None, bucket_of=None, world=None, mode="allreduce"):
+    def __init__(self, model, process_group=None, bucket_of=None, world=None, mode="allreduce", slice_of=autoformer_active_slice):
         assert mode in ("allreduce", "rs_ag")
         self.mode = mode
+        self.slice_of = slice_of              # None: always send whole buckets
+        self.stage = None                     # staging arena of the packed messages (allocated on first use)
+        self._slice_tables = {}
+        self.msg = {}
         self.model = model
         self.pg = process_group
         # `world` overrides the group size (tests drive the bucket logic with a stubbed collective)
@@ -68,6 +106,7 @@ class GradReducer:
             self.padded[b] = (sizes[b] + quantum - 1) // quantum * quantum
             total += self.padded[b]
         self.arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.starts, self.quantum = starts, quantum
         self.flat_padded = {}
         for b, mem in self.members.items():
             buf = self.arena[starts[b]:starts[b] + sizes[b]]
@@ -90,6 +129,10 @@ class GradReducer:
                 with torch.no_grad():
                     for t in list(model.parameters()) + list(model.buffers()):
                         dist.broadcast(t.data, src=0, group=self.pg)
+                # the broadcast wrote through .data (no version bump): bf16 operand copies made by a forward that
+                # ran BEFORE the reducer existed would stay on the pre-broadcast weights of ranks != 0
+                from .autoformer import block as _blk
+                _blk.refresh_operands(model, force=True)
                 self.use_avg = dist.get_backend(self.pg) == "nccl"
             # hooks hold the reducer WEAKLY: a discarded reducer must not keep firing (or stay alive)
             ref = weakref.ref(self)
@@ -141,6 +184,12 @@ class GradReducer:
         """Zero-fill (not None, see engine.SupernetTrainer) — one memset for all buckets."""
         self.arena.zero_()
 
+    def owns_grads(self):
+        """True while every parameter's .grad is still the view into the arena handed out at construction (an
+        optimizer.zero_grad(set_to_none=True) or a `p.grad = ...` assignment breaks the aliasing silently)."""
+        lo, hi = self.arena.data_ptr(), self.arena.data_ptr() + self.arena.numel() * 4
+        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for _, p in self.params)
+
     def prepare(self, config=None):
         """Call after zero_grad and before forward.  `config` is the sampled architecture
         (same on all ranks); blocks >= layer_num will not produce gradients."""
@@ -154,6 +203,61 @@ class GradReducer:
                 continue
             self.active.add(b)
             self.pending[b] = len(mem)
+        self.msg = {}
+        if config is not None and self.slice_of is not None and self.world > 1:
+            for b in self.active:
+                self.msg[b] = self._slice_plan(b, config)
+
+    # ------------------------------------------------------------------ active-slice messages
+    def _slice_plan(self, b, config):
+        """-> (message view into the staging arena, pack / unpack plan) of bucket b for this configuration; cached per
+        (bucket, slice signature) — the S search space has 27 signatures per block."""
+        sig = tuple(self.slice_of(n, p, config) for n, p in self.members[b])
+        key = (b, sig)
+        plan = self._slice_tables.get(key)
+        if plan is None:
+            if self.stage is None:
+                self.stage = torch.zeros_like(self.arena)
+            off, views, jobs, max_rows = 0, [], [], 0
+            for (n, p), (rows, cols) in zip(self.members[b], sig):
+                if rows * cols == 0:
+                    continue
+                last = p.shape[-1] if p.dim() > 1 else p.numel()
+                if n == "patch_embed_super.proj.weight":
+                    last = p.numel() // p.shape[0]
+                g2d = p.grad.view(-1, last)
+                assert rows <= g2d.shape[0] and cols <= last, (n, rows, cols, tuple(p.shape))
+                views.append((g2d, rows, cols, off))
+                jobs.append((g2d.data_ptr(), last, off, rows, cols))
+                max_rows = max(max_rows, rows)
+                off += rows * cols
+            padded = (off + self.quantum - 1) // self.quantum * self.quantum
+            msg = self.stage[self.starts[b]:self.starts[b] + (padded if self.mode == "rs_ag" else off)]
+            table = None
+            if self.on_gpu:
+                from . import _lib
+                arr = (_lib.SliceJob * len(jobs))()
+                base = self.stage.data_ptr() + self.starts[b] * 4
+                for j, (ptr, ld, o, r, c) in zip(arr, jobs):
+                    j.full, j.ld, j.packed_off, j.rows, j.cols = ptr, ld, o, r, c
+                table = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(jobs), max_rows, base)
+            plan = self._slice_tables[key] = (msg, views, table, off)
+        return plan
+
+    def _copy_slices(self, plan, to_packed):
+        msg, views, table, _ = plan
+        if table is not None:
+            from . import _lib
+            tab, n, max_rows, base = table
+            _lib.check(_lib.load().cream_slices_copy(tab.data_ptr(), n, base, max_rows, 1 if to_packed else 0,
+                                                     torch.cuda.current_stream(self.device).cuda_stream), "cream_slices_copy")
+            return
+        for g2d, rows, cols, off in views:               # host tensors (gloo tests): plain views
+            m = msg[off:off + rows * cols].view(rows, cols)
+            if to_packed:
+                m.copy_(g2d[:rows, :cols])
+            else:
+                g2d[:rows, :cols].copy_(m)
 
     def _hook(self, p):
         b = self.bucket_index.get(id(p))
@@ -182,28 +286,33 @@ class GradReducer:
         dist.all_gather_into_tensor(buf, mine.clone(), group=self.pg)
 
     def _launch(self, b):
-        buf = self.flat[b]
-        self.bytes_sent += buf.numel() * 4
-        if self.mode == "rs_ag":
-            full = self.flat_padded[b]
-            if self.on_gpu:
-                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self.comm_stream):
-                    self._reduce_scatter_gather(full)
-            else:
-                self._reduce_scatter_gather(full)
-            return
+        plan = self.msg.get(b)
+        buf = plan[0] if plan is not None else (self.flat_padded[b] if self.mode == "rs_ag" else self.flat[b])
+        self.bytes_sent += (plan[3] if plan is not None else self.flat[b].numel()) * 4
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                if self.use_avg:
-                    dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)      # one pass over the bucket
+                if plan is not None:
+                    self._copy_slices(plan, True)
+                if self.mode == "rs_ag":
+                    self._reduce_scatter_gather(buf)
+                elif self.use_avg:
+                    dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)      # one pass over the message
                 else:
                     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
                     buf.mul_(1.0 / self.world)
-        else:
-            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self.works.append((w, buf))
+                if plan is not None:
+                    self._copy_slices(plan, False)
+            return
+        if plan is not None:
+            self._copy_slices(plan, True)
+        if self.mode == "rs_ag":
+            self._reduce_scatter_gather(buf)
+            if plan is not None:
+                self._copy_slices(plan, False)
+            return
+        w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.works.append((w, buf, plan))
 
     def finish(self):
         """Call after backward, before the optimizer step."""
@@ -218,9 +327,11 @@ class GradReducer:
         if self.on_gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         else:
-            for w, buf in self.works:
+            for w, buf, plan in self.works:
                 w.wait()
                 buf.mul_(1.0 / self.world)
+                if plan is not None:
+                    self._copy_slices(plan, False)
         self.works = []
 
 

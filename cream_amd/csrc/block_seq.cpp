@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <vector>
 
 #include "cream_amd.h"
 
@@ -133,6 +134,49 @@ bool fork(hipStream_t main, hipStream_t side) {
 
 #define TRY(call) do { const int rc_ = (call); if (rc_ != CREAM_OK) return rc_; } while (0)
 
+// ---- optional in-step kernel timing -------------------------------------------------------------
+// HIP events around every launch of cream_block_fwd / cream_block_bwd, each pair recorded on the
+// stream the kernel is launched on (main or side) — so the durations are those of the REAL step: both
+// streams live, the weight-gradient GEMMs contending with the main chain.  bench.py reads them for the
+// roofline entry.  Off by default (one relaxed load per launch).
+enum ProfKind { K_LN_FWD = 0, K_GEMM_NT, K_GEMM_NT_GELU, K_GEMM_NT_MUL, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD,
+                K_GRAD_FINALIZE, K_COUNT };
+const char* const kProfNames[K_COUNT] = {"ln_fwd", "gemm_nt", "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad", "attn_rpe2d_fwd",
+                                         "attn_rpe2d_bwd", "ln_bwd", "grad_finalize"};
+struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_free;
+hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct ProfScope {
+    ProfRec r{};
+    hipStream_t st;
+    bool on;
+    ProfScope(int kind, hipStream_t s, double flops, double bytes) : st(s), on(g_prof_on) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        r.kind = kind; r.flops = flops; r.bytes = bytes;
+        r.a = prof_event(); r.b = prof_event();
+        on = r.a && r.b && hipEventRecord(r.a, st) == hipSuccess;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (hipEventRecord(r.b, st) == hipSuccess) g_prof_recs.push_back(r);
+    }
+};
+#define PTRY(kind, st, flops, bytes, call) do { ProfScope ps_((kind), (hipStream_t)(st), (double)(flops), (double)(bytes)); TRY(call); } while (0)
+double attn_flops(const cream_block_desc* d) {      // algorithmic forward flops of the attention core
+    const double N = d->N;
+    return (double)d->B * d->H * (4.0 * N * N * 64 + 4.0 * N * 64 * 60);
+}
+
 template <typename T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off); }
 template <typename T> const T* at(const void* base, int64_t off) {
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off);
@@ -162,30 +206,30 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     const float* xin = x_in;
     // LN1 — with a pending residual branch of the previous block: x = x_in + s_prev * pend_f first
     if (pend_f) {
-        TRY(cream_add_ln_fwd(at<float>(ws, L.xsum), at<void>(ws, L.a), at<float>(ws, L.mean1), at<float>(ws, L.rstd1), x_in, pend_f,
+        PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.xsum), at<void>(ws, L.a), at<float>(ws, L.mean1), at<float>(ws, L.rstd1), x_in, pend_f,
                              pend_scale, N, d->ln1_g, d->ln1_b, M, E, d->eps1, stream));
         xin = at<float>(ws, L.xsum);
     } else {
-        TRY(cream_ln_fwd(at<void>(ws, L.a), at<float>(ws, L.mean1), at<float>(ws, L.rstd1), x_in, d->ln1_g, d->ln1_b, M, E, d->eps1,
+        PTRY(K_LN_FWD, stream, 0, (double)M * E * 6, cream_ln_fwd(at<void>(ws, L.a), at<float>(ws, L.mean1), at<float>(ws, L.rstd1), x_in, d->ln1_g, d->ln1_b, M, E, d->eps1,
                          stream));
     }
     // qkv: rows [q | k | v] = the first Q rows of the three de-interleaved parts, bias = plain prefix
     // (qkv_super.py:72-83)
-    TRY(cream_linear_fwd_seg(at<void>(ws, L.qkv), at<void>(ws, L.a), d->wqkv, d->bqkv, M, 3 * Q, E, d->ld_qkv, Q, d->seg_qkv,
+    PTRY(K_GEMM_NT, stream, 2.0 * M * 3 * Q * E, 0, cream_linear_fwd_seg(at<void>(ws, L.qkv), at<void>(ws, L.a), d->wqkv, d->bqkv, M, 3 * Q, E, d->ld_qkv, Q, d->seg_qkv,
                              stream));
     const uint16_t* qkv = at<uint16_t>(ws, L.qkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
-    TRY(cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
+    PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
                              d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
                              CREAM_BF16, stream));
-    TRY(cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
+    PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
     // x1 = x + s1 * p ; c = LN2(x1)
-    TRY(cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
+    PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
                          at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
-    TRY(cream_linear_gelu_fwd_pad(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
+    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
                                   d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
-    TRY(cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
+    PTRY(K_GEMM_NT, stream, 2.0 * M * E * F, 0, cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
 }
 
@@ -213,32 +257,32 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
 
     // ---- MLP branch ----------------------------------------------------------------------------
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // df, g complete on main
-    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
+    PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
-    TRY(cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+    PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
                                  main));
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
+    PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
+    PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
-    TRY(cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
+    PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
-    TRY(cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
+    PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+    PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
-    TRY(cream_attn_rpe2d_bwd(dqkv, dqkv + Q, dqkv + 2 * Q, sb, sn, 64, at<float>(ws, L.dtab), at<void>(ws, L.dlt), at<void>(ws, L.qe),
+    PTRY(K_ATTN_BWD, main, 2.5 * attn_flops(d), 0, cream_attn_rpe2d_bwd(dqkv, dqkv + Q, dqkv + 2 * Q, sb, sn, 64, at<float>(ws, L.dtab), at<void>(ws, L.dlt), at<void>(ws, L.qe),
                              at<void>(ws, L.de), at<float>(ws, L.delta), at<void>(ws, L.dout), at<void>(fws, FL.o),
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
     // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
-    TRY(cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
-    TRY(cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
-    TRY(cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
+    PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
+    PTRY(K_GEMM_NT, main, 2.0 * M * 3 * Q * E, 0, cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
+    PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
                      at<float>(fws, FL.mean1), at<float>(fws, FL.rstd1), d->ln1_g, at<float>(ws, L.dx1), prev_scale, N, M, E, main));
 
     // ---- gradient finalisation: every parameter of the block in one launch, on the side stream ----
@@ -267,7 +311,39 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     job(G->ln1_g, E, at<float>(ws, L.pl1), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
-    return cream_grad_finalize(J, n, side);
+    PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));
+    return CREAM_OK;
+}
+
+int cream_block_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_on = on != 0;
+    return CREAM_OK;
+}
+
+int cream_block_prof_kinds(void) { return K_COUNT; }
+
+const char* cream_block_prof_name(int kind) { return kind >= 0 && kind < K_COUNT ? kProfNames[kind] : ""; }
+
+int cream_block_prof_collect(double* total_ms, int64_t* launches, double* flops, double* bytes)
+{
+    if (!total_ms || !launches || !flops || !bytes) return CREAM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    for (int k = 0; k < K_COUNT; ++k) { total_ms[k] = 0; launches[k] = 0; flops[k] = 0; bytes[k] = 0; }
+    int rc = CREAM_OK;
+    for (const ProfRec& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            total_ms[r.kind] += ms; launches[r.kind] += 1; flops[r.kind] += r.flops; bytes[r.kind] += r.bytes;
+        } else {
+            rc = CREAM_ERR_LAUNCH;
+        }
+        g_prof_free.push_back(r.a);
+        g_prof_free.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return rc;
 }
 
 }  // extern "C"

@@ -68,10 +68,17 @@ class DistillStep:
         return total
 
     def step(self, images, texts):
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            # the reducer owns the gradients (views into its flat arena): zero-fill them in place and arm the buckets —
+            # zero_grad(set_to_none=True) would detach every p.grad from the arena and no collective would ever run
+            self.reducer.zero_grad()
+            self.reducer.prepare(None)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss(images, texts)
         loss.backward()
         if self.reducer is not None:
+            assert self.reducer.owns_grads(), "a parameter gradient no longer aliases the reducer's arena"
             self.reducer.finish()
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip, norm_type=2.0)

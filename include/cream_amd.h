@@ -381,6 +381,22 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- active-slice gradient messages (data-parallel exchange) ------------------------------------
+ * DistributedDataParallel (AutoFormer/supernet_train.py:286-289) all-reduces the FULL gradient of every
+ * super weight; a sampled sub-network only writes W.grad[:rows, :cols] (Linear_super.py:71-81,
+ * qkv_super.py:72-83) and every rank samples the same one (supernet_engine.py:36).  cream_slices_copy
+ * gathers the active slices of one bucket into a contiguous fp32 message (to_packed != 0) or scatters
+ * the reduced message back (to_packed == 0): slice i = full[r * ld + c], r < rows, c < cols, stored
+ * row-major at packed + packed_off.  The job table lives in DEVICE memory (built once per bucket and
+ * configuration); max_rows = the largest `rows` of the table (sizes the grid). */
+typedef struct cream_slice_job {
+    float* full;
+    int64_t ld;
+    int64_t packed_off;
+    int32_t rows, cols;
+} cream_slice_job;
+int cream_slices_copy(const cream_slice_job* jobs_dev, int njobs, float* packed, int max_rows, int to_packed, void* stream);
+
 /* ---- one transformer block, sequenced natively ---------------------------------------------
  * TransformerEncoderLayer.forward (AutoFormer/model/supernet_transformer.py:251-287) and its
  * autograd backward as ONE call per direction: the kernels are the ones declared above, enqueued
@@ -438,6 +454,19 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const
                     void* ws, const float* dx2, const void* df, const float* pb2, int pb2_parts,
                     int64_t pb2_pstride, const float* dp1, const float* prev_scale, int want_prev,
                     void* stream, void* side_stream);
+
+
+/* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
+ * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).
+ * While enabled, every launch of cream_block_fwd / cream_block_bwd is bracketed by a pair of HIP events
+ * recorded on the stream it is launched on (main or side), so durations are those of the real two-stream
+ * step.  cream_block_prof_collect waits for the recorded events and returns, per kernel family
+ * (cream_block_prof_kinds() of them, names from cream_block_prof_name), the summed duration in ms, the
+ * launch count and the summed ALGORITHMIC flops / bytes; it empties the record list. */
+int cream_block_prof_enable(int on);
+int cream_block_prof_kinds(void);
+const char* cream_block_prof_name(int kind);
+int cream_block_prof_collect(double* total_ms, int64_t* launches, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }  /* extern "C" */

@@ -178,3 +178,57 @@ def test_subnet_evaluation_native_path_matches_module_path():
     assert res[True]["config"] == res[False]["config"] and res[True]["params"] == res[False]["params"]
     assert abs(res[True]["loss"] - res[False]["loss"]) < 2e-2 * abs(res[False]["loss"])
     assert res[True]["loss"] == res[True]["loss"]
+
+
+# measured on the MI355X (round 3, profiles/r03_parity.txt): whole AutoFormer-S step, depth 13, E = 384, B = 128, native
+# bf16 throughput path against the fp32 CPU oracle — bounds = 2x the worst measured value of each class.
+STEP128_TOL = dict(logits=2e-2, loss=4e-3, weights=4e-2, small=5e-2)
+
+
+def test_whole_step_at_bench_size_matches_oracle():
+    """The benchmarked workload itself: AutoFormer-S supernet, one sampled sub-network of depth 13 (E = 384, mixed heads
+    and MLP ratios), B = 128, 224^2 — the native bf16 path (block stack = one autograd node, every block one native call
+    per direction, weight-gradient GEMMs on the side stream, native stem / tail) against ONE step of
+    oracle.autoformer_oracle.train_step (the reference's dense fp32 formulation on the CPU): logits, loss and EVERY
+    parameter gradient (max-abs error / max-abs reference per tensor; exact zeros outside the sampled slices)."""
+    from cream_amd.autoformer import engine
+    from oracle import autoformer_oracle as AO
+    dev = _dev()
+    m = engine.build_supernet("S", drop_path_rate=0.0)
+    fill_params(m, seed=7)
+    cfg = dict(layer_num=13, embed_dim=[384] * 13, num_heads=[6, 5, 7, 6, 6, 5, 7, 7, 5, 6, 6, 7, 5],
+               mlp_ratio=[3.5, 3.0, 4.0, 3.5, 3.0, 4.0, 3.5, 3.5, 3.0, 4.0, 4.0, 3.0, 3.5])
+    images, target = make_batch(128, seed=9)
+    sd = {k: v.detach().clone() for k, v in m.named_parameters()}
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    loss_ref, grads_ref = AO.train_step(sd, cfg, images, target)
+    with torch.no_grad():
+        logits_ref = AO.forward(sd, cfg, images)
+    m = m.to(dev)
+    m.set_sample_config(cfg)
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(images.to(dev))
+        loss = engine.soft_target_cross_entropy(logits, target.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    errs = dict(logits=max_rel(logits.detach().float().cpu(), logits_ref),
+                loss=abs(float(loss) - float(loss_ref)) / abs(float(loss_ref)))
+    worst = dict(weights=(0.0, ""), small=(0.0, ""))
+    for k, p in m.named_parameters():
+        ref = grads_ref[k]
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().cpu()
+        if float(ref.abs().max()) == 0.0:                         # blocks.13.*: beyond the sampled depth
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        e = max_rel(got, ref)
+        cls = "weights" if p.dim() == 2 and min(p.shape) >= 64 else "small"
+        if e > worst[cls][0]:
+            worst[cls] = (e, k)
+    errs["weights"], errs["small"] = worst["weights"][0], worst["small"][0]
+    print("[whole step S d13 B128 bf16 native vs fp32 oracle]", {k: f"{v:.2e}" for k, v in errs.items()},
+          "worst tensors:", worst["weights"][1], "/", worst["small"][1])
+    g = m.blocks[1].attn.qkv.weight.grad                          # H = 5: rows beyond 3 * 320 and columns beyond E stay zero
+    assert torch.count_nonzero(g[3 * 320:]) == 0 and torch.count_nonzero(g[:, 384:]) == 0
+    for k, tol in STEP128_TOL.items():
+        assert errs[k] < tol, (k, errs[k], worst)

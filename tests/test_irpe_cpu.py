@@ -244,3 +244,44 @@ def test_reference_rpe_attention_through_the_patched_caller():
             sys.path.remove(refshim.IRPE)
         for k in [k for k in sys.modules if k in ("irpe", "rpe_vision_transformer", "rpe_index_cpp") or k.startswith("rpe_ops")]:
             del sys.modules[k]
+
+
+def test_irpe_oracle_is_pinned():
+    """oracle/irpe_oracle.py (the reference's pure-PyTorch RPEAttention formulation, used as the CPU baseline of bench.py's
+    config-4 leg) against reference-made fixtures: the product bucket tables (full 14x14, sampled rows + checksum of
+    24x24) and an RPEAttention forward / backward with rpe on q, k and v."""
+    from oracle import irpe_oracle as IO
+    z = load_npz("irpe_buckets.npz")
+    meta = {m["key"]: m for m in load_json("irpe_buckets.json")}
+    ids, nb = IO.product_bucket_ids(14, 14, 1)
+    assert nb == meta["product_1.9_14x14_s1"]["num_buckets"] and np.array_equal(ids, z["product_1.9_14x14_s1"])
+    ids577, nb577 = IO.product_bucket_ids(24, 24, 1)
+    assert nb577 == 50 and int(ids577.sum()) == meta["product_1.9_24x24_s1"]["sum"] == 8019121
+    assert np.array_equal(ids577[::16], z["product_1.9_24x24_s1|rows16"])
+    ids70, nb70 = IO.product_bucket_ids(7, 10, 0)
+    assert nb70 == 49 and np.array_equal(ids70, z["product_1.9_7x10_s0"])
+    ids145, _ = IO.product_bucket_ids(12, 12, 1, ratio=3.0)
+    assert np.array_equal(ids145, z["product_3.0_12x12_s1"])
+
+    fix = load_npz("irpe_attention.npz")
+    att = torch.nn.ModuleDict(dict(qkv=torch.nn.Linear(192, 576), proj=torch.nn.Linear(192, 192)))
+    params = {"qkv.weight": None, "qkv.bias": None, "rpe_q.lookup_table_weight": (1, 64, 50), "rpe_k.lookup_table_weight": (1, 64, 50),
+              "rpe_v.lookup_table_weight": (1, 50, 64), "proj.weight": None, "proj.bias": None}
+    # the parameter names (and their order) of the reference's RPEAttention: fill_params keys its seeds on them
+    holder = {}
+    for name, shape in params.items():
+        holder[name] = dict(att.named_parameters())[name].detach().clone() if shape is None else torch.zeros(shape)
+    fill_params(holder, seed=19)
+    for n in holder:
+        if "lookup_table" in n:
+            holder[n] = 0.3 * torch.randn(holder[n].shape, generator=torch.Generator().manual_seed(len(n)))
+    holder = {k: v.requires_grad_() for k, v in holder.items()}
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 197, 192, generator=g, requires_grad=True)
+    gy = torch.randn(2, 197, 192, generator=g)
+    y = IO.rpe_attention_layer(holder, x, 3, ids, nb)
+    y.backward(gy)
+    assert max_rel(y.detach(), fix["y"]) < 1e-5 and max_rel(x.grad, fix["dx"]) < 1e-5
+    for k, v in fix.items():
+        if k.startswith("full|"):
+            assert max_rel(holder[k[5:]].grad, v) < 1e-5, k

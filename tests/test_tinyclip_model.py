@@ -131,31 +131,25 @@ def _tiny_batch(n=8):
     return images, texts
 
 
-class _MeanReducer:
-    def __init__(self, params):
-        self.params = params
-
-    def finish(self):
-        import torch.distributed as dist
-        for p in self.params:
-            dist.all_reduce(p.grad)
-            p.grad /= dist.get_world_size()
-
-
 def _distill_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     torch.set_num_threads(2)
+    from cream_amd.comm import GradReducer
     from cream_amd.tinyclip.distill import DistillStep
     dist.init_process_group("gloo", rank=rank, world_size=world)
     student, teacher = _tiny_pair()
     opt = torch.optim.SGD(student.parameters(), lr=0.05)
+    # the REAL reducer (flat arena, per-bucket hooks): DistillStep must zero-fill and arm it every step — with
+    # zero_grad(set_to_none=True) the gradients leave the arena, no collective runs and the ranks diverge
+    reducer = GradReducer(student, bucket_of=lambda name: name.split(".")[0])
     step = DistillStep(student, teacher, opt, logit_scale=None, distillation_alpha=0.7, amp_dtype=torch.float32, rank=rank, world_size=world,
-                       reducer=_MeanReducer([p for p in student.parameters()]))
+                       reducer=reducer)
     images, texts = _tiny_batch()
     b = images.shape[0] // world
     losses = [float(step.step(images[rank * b:(rank + 1) * b], texts[rank * b:(rank + 1) * b])) for _ in range(2)]
+    assert reducer.owns_grads() and reducer.bytes_sent > 0
     q.put((rank, losses, {k: v.detach().numpy().copy() for k, v in student.state_dict().items()}))     # (numpy: no shared-memory handles)
     dist.barrier()
     dist.destroy_process_group()
