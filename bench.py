@@ -175,7 +175,9 @@ def cpu_baseline_best(size, seconds):
     in round 1; a larger batch gives the wide pools enough work), each in its own process, plus the iRPE leg; CPU model
     and counts stated."""
     ncpu = os.cpu_count() or 1
-    counts = sorted({c for c in (16, 64, ncpu) if c <= ncpu}) or [ncpu]
+    # all 256 hardware threads of the GPU box: > 160 s for two steps of batch 64 (gpurun_out/r03a_bench.err) — the oracle's
+    # small GEMMs do not scale past one CCD group; 64 threads are already 2x slower than 16
+    counts = sorted({c for c in (16, 32, 64) if c <= ncpu}) or [ncpu]
     per = max(4.0, seconds / (len(counts) + 1))
     tried, best = {}, None
     for c in counts:
@@ -187,6 +189,7 @@ def cpu_baseline_best(size, seconds):
     if best is None:
         return None
     best["threads_tried"] = tried
+    best["threads_note"] = "all 256 hardware threads: more than 160 s for two batch-64 steps (round-3 run), excluded from the sweep"
     best["cpu_model"] = cpu_model()
     best["host_cores"] = ncpu
     irpe = cpu_baseline_subprocess(size, per, threads=min(64, ncpu), irpe=True)

@@ -68,14 +68,22 @@ def test_step_fp32_within_1e3_of_reference(size, batch, impl):
         assert torch.count_nonzero(tg[1]) == 0 and torch.count_nonzero(tg[29]) == 0
 
 
+# bounds = 2x measured on the MI355X (profiles/r03_parity.txt); B = 2 and supernet-T: few tokens, so single bf16 roundings
+# show (the B = 128 whole-step test below is the statistically meaningful one)
+BF16_T_TOL = dict(logits=3e-2, loss=1e-2, grads=8e-2)
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 def test_step_bf16_autocast_documented_tolerance(impl):
     fix, cfg, m, logits, loss, grads = _step("T", 2, impl, amp=True)
-    assert max_rel(logits.detach().float().cpu(), fix["logits"]) < 3e-2
-    assert abs(float(loss) - float(fix["loss"][0])) / float(fix["loss"][0]) < 1e-2
-    for k, v in fix.items():
-        if k.startswith("full|"):
-            assert max_rel(grads[k[5:]].float().cpu(), v) < 8e-2, k
+    el = max_rel(logits.detach().float().cpu(), fix["logits"])
+    eloss = abs(float(loss) - float(fix["loss"][0])) / float(fix["loss"][0])
+    eg = {k[5:]: max_rel(grads[k[5:]].float().cpu(), v) for k, v in fix.items() if k.startswith("full|")}
+    worst = max(eg, key=eg.get)
+    print(f"[T step B=2 bf16 {impl}] logits {el:.2e} loss {eloss:.2e} worst full-gradient {eg[worst]:.2e} ({worst})")
+    assert el < BF16_T_TOL["logits"] and eloss < BF16_T_TOL["loss"]
+    for k, e in eg.items():
+        assert e < BF16_T_TOL["grads"], (k, e)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -181,8 +189,9 @@ def test_subnet_evaluation_native_path_matches_module_path():
 
 
 # measured on the MI355X (round 3, profiles/r03_parity.txt): whole AutoFormer-S step, depth 13, E = 384, B = 128, native
-# bf16 throughput path against the fp32 CPU oracle — bounds = 2x the worst measured value of each class.
-STEP128_TOL = dict(logits=2e-2, loss=4e-3, weights=4e-2, small=5e-2)
+# bf16 throughput path against the fp32 CPU oracle: logits 7.5e-3, loss 4.2e-5, projection / embedding weights 8.1e-3
+# (worst: head.weight), small tensors 1.03e-2 (worst: blocks.1.ffn_layer_norm.weight) — bounds = 2x measured (loss: 2.5x).
+STEP128_TOL = dict(logits=1.5e-2, loss=1e-4, weights=1.7e-2, small=2.1e-2)
 
 
 def test_whole_step_at_bench_size_matches_oracle():

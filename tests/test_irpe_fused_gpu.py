@@ -183,9 +183,11 @@ def test_fused_irpe_attention_at_config4_matches_restatement(rpe_on):
         report[rounded] = errs
     print(f"[fused irpe config 4, rpe on {rpe_on}] vs restatement with bf16 lookups:", {k: f"{v:.2e}" for k, v in report[True].items()})
     print(f"[fused irpe config 4, rpe on {rpe_on}] vs pure fp32 restatement:       ", {k: f"{v:.2e}" for k, v in report[False].items()})
-    # 2x measured at this shape (first GPU run of this test, profiles/r03_parity.txt)
-    bound = dict(y=1.0e-2, dq=1.3e-2, dk=1.3e-2, dv=1.3e-2, dWq=1.3e-2, dWk=1.3e-2, dWv=1.3e-2)
-    for k, v in report[True].items():
-        assert v < bound[k], (k, v, report)
-    for k, v in report[False].items():
-        assert v < 2 * bound[k], (k, v, report)
+    # measured on the MI355X (profiles/r03_parity.txt): rpe on k: y 3.5e-3, dq 5.9e-3, dk 3.4e-3, dv 4.3e-3, dWk 3.6e-3;
+    # rpe on q, k, v: y 5.8e-3, dq 8.2e-3, dk 4.9e-3, dv 4.2e-3, dWq 2.6e-3, dWk 3.6e-3, dWv 1.8e-3 — the same against the
+    # pure fp32 restatement as against the one with bf16 lookups (the kernel's rounding of the lookups is not what bounds
+    # the error), so BOTH are held to the same bounds = 2x the worst measured value of each quantity
+    bound = dict(y=1.2e-2, dq=1.7e-2, dk=1.0e-2, dv=9e-3, dWq=7.5e-3, dWk=7.5e-3, dWv=7.5e-3)
+    for rounded in (True, False):
+        for k, v in report[rounded].items():
+            assert v < bound[k], (k, v, rounded, report)

@@ -60,8 +60,8 @@ def test_soft_loss_on_the_device_matches_reference_values(amp):
         eg = max(np.abs(gi - di).max() / np.abs(di).max(), np.abs(gt - dt).max() / np.abs(dt).max())
         el = np.abs(got - want).max() / np.abs(want).max()
         print(f"[ClipSoftLoss on device, amp={amp}, avg={avg}] loss rel err {el:.2e}, feature-gradient rel err {eg:.2e}")
-        if amp:      # logits = 50 x cosine in bf16 (8 mantissa bits on values up to 50): measured 1.2e-2 / 3.1e-2; bounds 2x
-            assert el < 2.5e-2 and eg < 6e-2
+        if amp:      # logits = 50 x cosine in bf16 (8 mantissa bits on values up to 50): measured 3.4e-3 / 1.08e-2; bounds 2x
+            assert el < 7e-3 and eg < 2.2e-2
         else:
             assert el < 1e-5 and eg < 1e-4
 
