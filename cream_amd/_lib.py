@@ -84,6 +84,11 @@ SIGNATURES = {
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
+    "cream_linear_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
+    "cream_linear_f32_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
+    "cream_linear_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
+    "cream_ln_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cream_ln_f32_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_block_prof_enable": (_i, [_i]),
     "cream_block_prof_kinds": (_i, []),
     "cream_block_prof_name": (_c.c_char_p, [_i]),

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import attention_op
+from . import attention_op, native_fp32
 
 
 def _trunc_normal_(t, std):
@@ -116,9 +116,17 @@ class _SampledLinearBase(nn.Linear):
         return self.samples
 
     def forward(self, x):
+        if x.is_cuda and native_fp32.usable(x, self.weight, self.bias):
+            # fp32 parity mode on the device: the framework's own exact-fp32 matrix-core GEMMs on the super weight in place
+            seg, step = self._native_row_map()
+            y = native_fp32.linear(x, self.weight, self.bias, self.sample_out_dim, self.sample_in_dim, seg, step)
+            return y * self.sample_scale if self.scale else y
         self.sample_parameters()
         y = F.linear(x, self.samples['weight'], self.samples['bias'])
         return y * self.sample_scale if self.scale else y
+
+    def _native_row_map(self):
+        return 0, 0
 
     def calc_sampled_param_num(self):
         assert 'weight' in self.samples
@@ -157,6 +165,10 @@ class qkv_super(_SampledLinearBase):
     def __init__(self, super_in_dim, super_out_dim, bias=True, uniform_=None, non_linear='linear', scale=False):
         super().__init__(super_in_dim, super_out_dim, bias=bias, scale=scale)
         # (the reference leaves nn.Linear's default init here: qkv_super.py:24)
+
+    def _native_row_map(self):
+        # output n of [q | k | v] = super row 3 (n % Q) + n / Q  (qkv_super.py:75)
+        return self.sample_out_dim // 3, 3
 
     def _slice_weight(self):
         n3 = self.sample_out_dim
@@ -198,6 +210,8 @@ class LayerNormSuper(nn.LayerNorm):
         self.samples.stale = True
 
     def forward(self, x):
+        if x.is_cuda and self.sample_embed_dim % 4 == 0 and native_fp32.usable(x, self.weight, self.bias):
+            return native_fp32.layer_norm(x, self.weight, self.bias, self.sample_embed_dim, self.eps)
         self.sample_parameters()
         return F.layer_norm(x, (self.sample_embed_dim,), weight=self.samples['weight'],
                             bias=self.samples['bias'], eps=self.eps)
@@ -248,7 +262,10 @@ class PatchembedSuper(nn.Module):
             if _block.patch_embed_supported(self, x):        # own GEMMs (csrc/gemm_mfma.hpp), bf16 autocast
                 return _block.patch_embed(self, x)
         patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
-        y = F.linear(patches, self.sampled_weight.reshape(self.sample_embed_dim, -1), self.sampled_bias)
+        if x.is_cuda and native_fp32.usable(x, self.proj.weight, self.proj.bias):
+            y = native_fp32.linear(patches, self.proj.weight, self.proj.bias, self.sample_embed_dim, C * ph * pw)
+        else:
+            y = F.linear(patches, self.sampled_weight.reshape(self.sample_embed_dim, -1), self.sampled_bias)
         return y * self.sampled_scale if self.scale else y
 
     def calc_sampled_param_num(self):

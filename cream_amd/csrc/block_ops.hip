@@ -49,11 +49,36 @@ __device__ __forceinline__ u32x2v pack_bf16x4(const float (&f)[4]) {
 
 constexpr int LN_MAXC = 5;          // float4 chunks per lane: E <= 64 * 4 * 5 = 1280
 
+// The LayerNorm kernels exist in two instantiations of ONE code path: 16-bit side (uint16_t = bf16 bits: the GEMM-operand
+// side of the throughput mode) and fp32 side (float: the parity mode, fp32 in and out like the reference's
+// layernorm_super.py:33-37 outside autocast).  Only the pack / unpack of the 4-element chunks differs.
+template <typename T> struct Io4;
+template <> struct Io4<uint16_t> {
+    using raw = u32x2v;
+    static __device__ __forceinline__ raw zero() { return u32x2v{0, 0}; }
+    static __device__ __forceinline__ raw load(const uint16_t* p) { return *reinterpret_cast<const u32x2v*>(p); }
+    static __device__ __forceinline__ void unpack(raw v, float (&f)[4]) { unpack_bf16x4(v, f); }
+    // stores the rounded values and returns them (callers that sum what they wrote need the rounding)
+    static __device__ __forceinline__ void store(uint16_t* p, float (&f)[4]) {
+        const u32x2v pk = pack_bf16x4(f);
+        *reinterpret_cast<u32x2v*>(p) = pk;
+        unpack_bf16x4(pk, f);
+    }
+};
+template <> struct Io4<float> {
+    using raw = f32x4v;
+    static __device__ __forceinline__ raw zero() { return f32x4v{0, 0, 0, 0}; }
+    static __device__ __forceinline__ raw load(const float* p) { return *reinterpret_cast<const f32x4v*>(p); }
+    static __device__ __forceinline__ void unpack(raw v, float (&f)[4]) { f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+    static __device__ __forceinline__ void store(float* p, float (&f)[4]) { *reinterpret_cast<f32x4v*>(p) = f32x4v{f[0], f[1], f[2], f[3]}; }
+};
+
 // ---- LayerNorm forward: one wave per row ------------------------------------------------
 // With a branch output `res` (bf16) the kernel first forms the new residual stream
 // x1 = x + s_b * res (written to `xsum`, fp32) and normalises that: the residual add and the
 // next LayerNorm of the block in one pass.
-__global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, float* __restrict__ mean,
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(TY* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int M, int E, float eps, float* __restrict__ xsum,
@@ -91,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
     }
     const float rs = rsqrtf(wave_sum(q) / (float)E + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    uint16_t* yr = y + (int64_t)row * E;
+    TY* yr = y + (int64_t)row * E;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -101,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
-            *reinterpret_cast<u32x2v*>(yr + 4 * c) = pack_bf16x4(o);
+            Io4<TY>::store(yr + 4 * c, o);
         }
     }
 }
@@ -114,16 +139,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(uint16_t* __restrict__ y, f
 // PRE: 0 = loads as they are needed (x, dy; then dres after the row reductions); 1 = all three row operands requested
 // before the reductions; 2 = as 1, and the NEXT row's operands are requested before this row's reductions (two rows
 // in flight per wave).  Same arithmetic in the same order in all three.
-template <int MAXC>
+template <int MAXC, typename TD = uint16_t>
 struct LnRowIn {
     f32x4v x[MAXC], r[MAXC];
-    u32x2v dy[MAXC];
+    typename Io4<TD>::raw dy[MAXC];
     float mu, rs, sc;
 };
 
-template <int MAXC, bool WITH_RES>
-__device__ __forceinline__ void ln_row_request(LnRowIn<MAXC>& in, int row, int lane, int nch, int E,
-                                               const uint16_t* __restrict__ dy, const float* __restrict__ x,
+template <int MAXC, bool WITH_RES, typename TD = uint16_t>
+__device__ __forceinline__ void ln_row_request(LnRowIn<MAXC, TD>& in, int row, int lane, int nch, int E,
+                                               const TD* __restrict__ dy, const float* __restrict__ x,
                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                const float* __restrict__ dres, const float* __restrict__ sscale,
                                                int rows_per_sample) {
@@ -131,14 +156,14 @@ __device__ __forceinline__ void ln_row_request(LnRowIn<MAXC>& in, int row, int l
     // strength-reduced into per-array 64-bit vector addresses: +16 VGPRs and VALU adds per row)
     const int64_t ro = (int64_t)__builtin_amdgcn_readfirstlane(row) * E;
     const float* xr = x + ro;
-    const uint16_t* dyr = dy + ro;
+    const TD* dyr = dy + ro;
     const float* rr = dres + ro;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const unsigned c = lane + 64 * i;
         if (c < (unsigned)nch) {
             in.x[i] = *reinterpret_cast<const f32x4v*>(xr + 4u * c);
-            in.dy[i] = *reinterpret_cast<const u32x2v*>(dyr + 4u * c);
+            in.dy[i] = Io4<TD>::load(dyr + 4u * c);
             if (WITH_RES) in.r[i] = dres ? *reinterpret_cast<const f32x4v*>(rr + 4u * c) : f32x4v{0, 0, 0, 0};
         }
     }
@@ -147,9 +172,9 @@ __device__ __forceinline__ void ln_row_request(LnRowIn<MAXC>& in, int row, int l
     in.sc = sscale ? sscale[row / rows_per_sample] : 1.f;
 }
 
-template <int MAXC, int PRE, int WPE = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void ln_bwd_kernel(float* __restrict__ dx, uint16_t* __restrict__ dxs,
-                                                     float* __restrict__ partial, const uint16_t* __restrict__ dy,
+template <int MAXC, int PRE, int WPE = 1, typename TD = uint16_t>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void ln_bwd_kernel(float* __restrict__ dx, TD* __restrict__ dxs,
+                                                     float* __restrict__ partial, const TD* __restrict__ dy,
                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, const float* __restrict__ sscale,
@@ -170,17 +195,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     const float invE = 1.f / (float)E;
     const int stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
-    LnRowIn<MAXC> nxt;
+    LnRowIn<MAXC, TD> nxt;
     if (PRE == 2 && row < M)
-        ln_row_request<MAXC, true>(nxt, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+        ln_row_request<MAXC, true, TD>(nxt, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
     for (; row < M; row += stride) {
-        LnRowIn<MAXC> in;
+        LnRowIn<MAXC, TD> in;
         if (PRE == 2) {
             in = nxt;
             if (row + stride < M)
-                ln_row_request<MAXC, true>(nxt, row + stride, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+                ln_row_request<MAXC, true, TD>(nxt, row + stride, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
         } else {
-            ln_row_request<MAXC, PRE == 1>(in, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
+            ln_row_request<MAXC, PRE == 1, TD>(in, row, lane, nch, E, dy, x, mean, rstd, dres, sscale, rows_per_sample);
         }
         const float mu = in.mu, rs = in.rs;
         float xh[MAXC][4], d[MAXC][4];
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-                unpack_bf16x4(in.dy[i], d[i]);
+                Io4<TD>::unpack(in.dy[i], d[i]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[i][e] = (in.x[i][e] - mu) * rs;
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
         const float sc = in.sc;
         const int64_t ro = (int64_t)__builtin_amdgcn_readfirstlane(row) * E;
         float* dxr = dx + ro;
-        uint16_t* dxsr = dxs + ro;
+        TD* dxsr = dxs + ro;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const unsigned c = lane + 64 * i;
@@ -223,9 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
                 }
                 *reinterpret_cast<f32x4v*>(dxr + 4u * c) = r;
                 if (dxs) {
-                    const u32x2v pk = pack_bf16x4(o);
-                    *reinterpret_cast<u32x2v*>(dxsr + 4u * c) = pk;
-                    unpack_bf16x4(pk, o);
+                    Io4<TD>::store(dxsr + 4u * c, o);                  // (o now holds the values as written)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) as[i][e] += o[e];
                 }
@@ -516,8 +539,34 @@ int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float*
     if (!y || !mean || !rstd || !x || !gamma || !beta) return CREAM_ERR_BAD_ARG;
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16) return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
                        x, gamma, beta, M, E, eps, (float*)nullptr, (const uint16_t*)nullptr, (const float*)nullptr, 1);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_ln_f32_fwd(float* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
+                     int M, int E, float eps, void* stream)
+{
+    if (M < 0 || E <= 0) return CREAM_ERR_BAD_ARG;
+    if (M == 0) return CREAM_OK;
+    if (!y || !mean || !rstd || !x || !gamma || !beta) return CREAM_ERR_BAD_ARG;
+    if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
+    if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, mean, rstd,
+                       x, gamma, beta, M, E, eps, (float*)nullptr, (const uint16_t*)nullptr, (const float*)nullptr, 1);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_ln_f32_bwd(float* dx, float* partial, const float* dy, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, int M, int E, void* stream)
+{
+    if (M <= 0 || E <= 0) return CREAM_ERR_BAD_ARG;
+    if (!dx || !partial || !dy || !x || !mean || !rstd || !gamma) return CREAM_ERR_BAD_ARG;
+    if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
+    if (((uintptr_t)dx | (uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma) % 16) return CREAM_ERR_BAD_ARG;
+    auto kern = E <= 512 ? ln_bwd_kernel<2, 0, 1, float> : (E <= 768 ? ln_bwd_kernel<3, 0, 1, float> : ln_bwd_kernel<LN_MAXC, 0, 1, float>);
+    hipLaunchKernelGGL(kern, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx, (float*)nullptr, partial, dy, x,
+                       mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, 1, M, E);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -531,7 +580,7 @@ int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)xsum | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16 || (uintptr_t)res % 8)
         return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
                        x, gamma, beta, M, E, eps, xsum, (const uint16_t*)res, sample_scale, rows_per_sample);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }

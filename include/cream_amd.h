@@ -381,6 +381,31 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- fp32-I/O instantiations (parity mode) -------------------------------------------------------
+ * The same operators with fp32 tensors on both sides, for the "within 1e-3 of the reference PyTorch-CPU
+ * forward / backward" bar: exact-fp32 matrix-core products (v_mfma_f32_32x32x2_f32; gfx950 has no TF32)
+ * and the fp32 instantiation of the LayerNorm kernels.
+ *
+ * cream_linear_f32_fwd   y (M x N) = x (M x K, row stride ldx) . W[wmap(n), :K]^T + bias[:N]
+ *                        = LinearSuper.forward / qkv_super.forward (Linear_super.py:38-54, :71-81; qkv_super.py:72-83)
+ * cream_linear_f32_dgrad dx (M x K) = dy (M x N) . W[wmap(n), :K]
+ * cream_linear_f32_wgrad dW[wmap(n), :K] = dy^T . x  (rows of dw, stride lddw; other rows untouched);
+ *                        dbias (N) = column sums of dy in ascending row order, or NULL
+ * wmap(r) = (r % seg) * step + r / seg for seg > 0 (qkv super weight: seg = Q, step = 3 — rows 3 i + j,
+ * qkv_super.py:75), identity for seg == 0.  w: fp32 super weight, row stride ldw.
+ * cream_ln_f32_fwd / _bwd = LayerNormSuper.forward (layernorm_super.py:33-37) and its autograd backward:
+ * partial (cream_ln_partials() x 3 x E): planes 0 / 1 = per-slab dgamma / dbeta sums (plane 2 zero). */
+int cream_linear_f32_fwd(float* y, const float* x, const float* w, const float* bias, int M, int N, int K, int64_t ldx,
+                         int64_t ldw, int seg, int step, void* stream);
+int cream_linear_f32_dgrad(float* dx, const float* dy, const float* w, int M, int N, int K, int64_t ldw, int seg, int step,
+                           void* stream);
+int cream_linear_f32_wgrad(float* dw, float* dbias, const float* dy, const float* x, int M, int N, int K, int64_t ldx,
+                           int64_t lddw, int seg, int step, void* stream);
+int cream_ln_f32_fwd(float* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
+                     int M, int E, float eps, void* stream);
+int cream_ln_f32_bwd(float* dx, float* partial, const float* dy, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, int M, int E, void* stream);
+
 /* ---- active-slice gradient messages (data-parallel exchange) ------------------------------------
  * DistributedDataParallel (AutoFormer/supernet_train.py:286-289) all-reduces the FULL gradient of every
  * super weight; a sampled sub-network only writes W.grad[:rows, :cols] (Linear_super.py:71-81,

@@ -55,9 +55,28 @@ def _step(size, batch, impl, amp):
 
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("size,batch", [("T", 2), ("S", 1)])
-def test_step_fp32_within_1e3_of_reference(size, batch, impl):
+def test_step_fp32_within_1e3_of_reference(size, batch, impl, monkeypatch):
+    """BASELINE's bar on the framework's OWN kernels: every projection (qkv / proj / fc1 / fc2 / patch embedding / head),
+    forward, dgrad and wgrad, runs on csrc/gemm_f32.hip (exact-fp32 matrix cores), every LayerNorm on the fp32 instantiation
+    of csrc/block_ops.hip, attention on the fp32 instantiation of csrc/attn_rpe2d.hip — a vendor GEMM or the framework's
+    layer_norm reaching a device tensor fails the test."""
+    import torch.nn.functional as F
+    from cream_amd.autoformer import modules, native_fp32
+
+    def no_library(name, fn):
+        def guard(x, *a, **k):
+            assert not x.is_cuda, f"{name} reached a device tensor: the fp32 parity step must run on the own kernels"
+            return fn(x, *a, **k)
+        return guard
+    monkeypatch.setattr(modules.F, "linear", no_library("F.linear", F.linear))
+    monkeypatch.setattr(modules.F, "layer_norm", no_library("F.layer_norm", F.layer_norm))
+    before = dict(native_fp32.CALLS)
     fix, cfg, m, logits, loss, grads = _step(size, batch, impl, amp=False)
+    depth = cfg["layer_num"]
+    assert native_fp32.CALLS["linear"] - before["linear"] == 4 * depth + 2          # + patch embedding + head
+    assert native_fp32.CALLS["layer_norm"] - before["layer_norm"] == 2 * depth + 1
     worst = check_against_fixture(fix, logits, loss, grads, tol=1e-3)
+    print(f"[fp32 step {size} B={batch} {impl} on the own fp32 kernels] worst rel err vs the reference-made fixture {worst:.2e}")
     assert worst < 1e-3
     E = cfg["embed_dim"][0]
     g = m.blocks[0].attn.qkv.weight.grad
@@ -68,9 +87,9 @@ def test_step_fp32_within_1e3_of_reference(size, batch, impl):
         assert torch.count_nonzero(tg[1]) == 0 and torch.count_nonzero(tg[29]) == 0
 
 
-# bounds = 2x measured on the MI355X (profiles/r03_parity.txt); B = 2 and supernet-T: few tokens, so single bf16 roundings
-# show (the B = 128 whole-step test below is the statistically meaningful one)
-BF16_T_TOL = dict(logits=3e-2, loss=1e-2, grads=8e-2)
+# bounds = 2x measured on the MI355X (profiles/r03_parity.txt: logits 5.7e-3, loss 2.6e-4, worst full gradient 8.2e-3 — a
+# position table of the last block); round 2 held this test to 3e-2 / 1e-2 / 8e-2
+BF16_T_TOL = dict(logits=1.2e-2, loss=6e-4, grads=1.7e-2)
 
 
 @pytest.mark.parametrize("impl", IMPLS)

@@ -443,7 +443,11 @@ def test_reducer_bucket_protocol_with_fused_blocks(monkeypatch):
         tr.forward_backward(x, t)
         torch.cuda.synchronize()
         ptrs = {red.flat[b].data_ptr(): b for b in red.flat}
+        ptrs.update({plan[0].data_ptr(): b for b, plan in red.msg.items()})    # active-slice messages (staging arena)
+        assert set(red.msg) == {"block00", "block01", "stem", "tail"}
         sent = [ptrs[c[0]] for c in calls]
+        # a message holds exactly the elements this configuration can write (E = 320, H = 5 / 6, ratio 3 / 4)
+        assert sum(c[1] for c in calls) * 4 == red.bytes_sent < sum(red.flat[b].numel() for b in red.active) * 4
         assert sorted(sent) == ["block00", "block01", "stem", "tail"]          # block02 is beyond the depth
         assert all(c[2] > 0 for c in calls), "a bucket was sent before its gradients were written"
         # reverse layer order, stem last: communication overlaps the rest of backward
@@ -455,6 +459,7 @@ def test_reducer_bucket_protocol_with_fused_blocks(monkeypatch):
             blk.fused = False                                                 # module path: autograd hooks
         tr.forward_backward(x, t)
         torch.cuda.synchronize()
+        ptrs.update({plan[0].data_ptr(): b for b, plan in red.msg.items()})
         assert sorted(ptrs[c[0]] for c in calls) == ["block00", "block01", "stem", "tail"]
         assert _rel(m.blocks[0].fc1.weight.grad, g1) < 3e-2                   # (2x sum) / 2 either way
     finally:
@@ -604,3 +609,54 @@ def test_hidden_width_not_multiple_of_8_runs_padded_on_the_native_path():
     assert float(prm["blocks.0.fc1.weight"].grad[756:].abs().max()) == 0.0
     assert float(prm["blocks.0.fc2.weight"].grad[:, 756:].abs().max()) == 0.0
     assert float(prm["blocks.0.fc1.bias"].grad[756:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,qkv", [(394, 576, 216, True), (197, 1000, 384, False), (25216, 1152, 384, True), (333, 100, 52, False),
+                                       (25216, 448, 1792, False)])
+def test_fp32_linear_kernels_match_fp64(M, N, K, qkv):
+    """csrc/gemm_f32.hip (forward, dgrad, wgrad + bias column sums on v_mfma_f32_32x32x2_f32, the super weight read in place
+    through the qkv row map) against the same products in fp64: <= 2e-6 of the largest magnitude for contractions up to
+    ~2k terms; the weight / bias gradients at M = 25,216 are ONE sequential fp32 chain over 25,216 tokens per element
+    (rounding grows like sqrt(terms) x 6e-8: measured 6.1e-6, bound 2e-5).  Gradients exactly zero outside the active slice."""
+    from cream_amd.autoformer import native_fp32
+    torch.manual_seed(M + N)
+    Ns, Ks = (N + 96 if not qkv else N + 3 * 64), K + 40                    # super extents beyond the sampled ones
+    w = (torch.randn(Ns, Ks, device=DEV) * K ** -0.5).requires_grad_()
+    b = torch.randn(Ns, device=DEV).requires_grad_()
+    x = torch.randn(M, K, device=DEV).requires_grad_()
+    gy = torch.randn(M, N, device=DEV)
+    seg, step = (N // 3, 3) if qkv else (0, 0)
+    y = native_fp32.linear(x, w, b, N, K, seg, step)
+    dx, dw, db = torch.autograd.grad(y, [x, w, b], gy)
+    rows = torch.arange(N, device=DEV)
+    rows = (rows % seg) * step + rows // seg if qkv else rows
+    wd, xd, gd = w.detach().double()[rows][:, :K], x.detach().double(), gy.double()
+    errs = dict(y=_rel(y.double(), xd @ wd.T + b.detach().double()[:N]), dx=_rel(dx.double(), gd @ wd),
+                dw=_rel(dw.double()[rows][:, :K], gd.T @ xd), db=_rel(db.double()[:N], gd.sum(0)))
+    print(f"[fp32 own GEMM M={M} N={N} K={K} qkv={qkv}]", {k: f"{v:.1e}" for k, v in errs.items()})
+    tol = dict(y=2e-6, dx=2e-6 if N < 1500 else 4e-6, dw=2e-6 if M < 2000 else 2e-5, db=2e-6 if M < 2000 else 2e-5)
+    assert all(errs[k] < tol[k] for k in errs), errs
+    mask = torch.ones_like(dw, dtype=torch.bool)
+    mask[rows[:, None], torch.arange(K, device=DEV)[None, :]] = False
+    assert torch.count_nonzero(dw[mask]) == 0 and torch.count_nonzero(db[N:]) == 0
+
+
+@pytest.mark.parametrize("M,E,Es", [(394, 216, 256), (25216, 384, 448), (197, 448, 448)])
+def test_fp32_layernorm_kernels_match_fp64(M, E, Es):
+    """The fp32 instantiation of the LayerNorm kernels (csrc/block_ops.hip, Io4<float>) against fp64."""
+    from cream_amd.autoformer import native_fp32
+    torch.manual_seed(E)
+    g = (1 + 0.1 * torch.randn(Es, device=DEV)).requires_grad_()
+    b = (0.1 * torch.randn(Es, device=DEV)).requires_grad_()
+    x = (torch.randn(M, E, device=DEV) * 2 + 0.5).requires_grad_()
+    gy = torch.randn(M, E, device=DEV)
+    y = native_fp32.layer_norm(x, g, b, E, 1e-5)
+    dx, dg, db = torch.autograd.grad(y, [x, g, b], gy)
+    xd = x.detach().double().requires_grad_()
+    gd, bd = g.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xd, (E,), gd[:E], bd[:E], 1e-5)
+    rdx, rdg, rdb = torch.autograd.grad(yr, [xd, gd, bd], gy.double())
+    errs = dict(y=_rel(y.double(), yr), dx=_rel(dx.double(), rdx), dg=_rel(dg.double(), rdg), db=_rel(db.double(), rdb))
+    print(f"[fp32 own LayerNorm M={M} E={E}]", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 5e-6 for v in errs.values()), errs
+    assert torch.count_nonzero(dg[E:]) == 0 and torch.count_nonzero(db[E:]) == 0
