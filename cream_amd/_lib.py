@@ -84,6 +84,10 @@ SIGNATURES = {
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
+    "cream_wgrad_group_slots": (_i, []),
+    "cream_wgrad_group_workspace": (_i64, []),
+    "cream_wgrad_group_max_tiles": (_i, []),
+    "cream_wgrad_group": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cream_linear_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
     "cream_linear_f32_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
     "cream_linear_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
@@ -148,7 +152,14 @@ class BlockGrads(ctypes.Structure):
     """struct cream_block_grads of include/cream_amd.h."""
     _fields_ = ([(n, _vp) for n in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2", "ln1_g", "ln1_b", "ln2_g",
                                     "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
-                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2", "ldt")])
+                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2", "ldt")] +
+                [("wgrad_slabs", _vp), ("wgrad_counters", _vp)])
+
+
+class WgradProblem(ctypes.Structure):
+    """struct cream_wgrad_problem of include/cream_amd.h."""
+    _fields_ = [("dy", _vp), ("x", _vp), ("ldy", _i64), ("ldx", _i64), ("dw", _vp), ("ld_dw", _i64), ("dbias", _vp),
+                ("N", _c.c_int32), ("K", _c.c_int32), ("interleave", _c.c_int32), ("reserved", _c.c_int32)]
 
 
 _lib = None

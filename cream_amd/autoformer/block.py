@@ -283,18 +283,64 @@ def wgrad_parts_async(dy, x, want_bias=False):
     return out, bout
 
 
+# Weight gradients of a block: False (default) = one split-K launch per projection + cream_grad_finalize; True = ONE
+# stream-K launch with the reduction in the kernel (cream_wgrad_group).  Same-box A/B of the S supernet step, twice:
+# 10.92 ms (False) vs 11.58 ms (True) although the grouped launch needs 25 % less side-stream time standalone — its
+# workgroups live ~200 us and hold half of every SIMD's registers, which costs the main chain more.
+WGRAD_GROUPED = False
+_wgrad_ws = {}
+
+
+def wgrad_workspace(device):
+    """(slabs, counters) of cream_wgrad_group for `device`: one allocation per device for the life of the process —
+    the grouped launches of all blocks are ordered on the side stream (or the main stream without it), and every launch
+    leaves the counters zero."""
+    ent = _wgrad_ws.get(device)
+    if ent is None:
+        lib = _lib.load()
+        with torch.cuda.device(device):
+            slabs = torch.empty(lib.cream_wgrad_group_workspace(), dtype=torch.uint8, device=device)
+            counters = torch.zeros(lib.cream_wgrad_group_max_tiles(), dtype=torch.int32, device=device)
+        ent = _wgrad_ws[device] = (slabs, counters)
+    return ent
+
+
+def wgrad_group(problems):
+    """All weight gradients of a block in ONE launch on the current stream (cream_wgrad_group): `problems` = list of
+    (dy (M, N) bf16, x (M, K) bf16, weight parameter, bias parameter or None, interleave) — adds dy^T x into the active
+    slice of weight.grad (rows through the qkv interleave) and the column sums of dy into bias.grad[:N]."""
+    lib = _lib.load()
+    dev = problems[0][0].device
+    slabs, counters = wgrad_workspace(dev)
+    arr = (_lib.WgradProblem * len(problems))()
+    M = problems[0][0].shape[0]
+    flops = 0
+    for q, (dy, x, w, b, inter) in zip(arr, problems):
+        gw = _ensure_grad(w)
+        q.dy, q.x, q.ldy, q.ldx = dy.data_ptr(), x.data_ptr(), dy.stride(0), x.stride(0)
+        q.dw, q.ld_dw = gw.data_ptr(), gw.stride(0)
+        q.dbias = _ensure_grad(b).data_ptr() if b is not None else 0
+        q.N, q.K, q.interleave = dy.shape[1], x.shape[1], inter
+        flops += 2 * M * dy.shape[1] * x.shape[1]
+    with timing.region("gemm_tn_wgrad", flops=flops):
+        _lib.check(lib.cream_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(problems), M, _p(slabs), _p(counters), _stream()),
+                   "cream_wgrad_group")
+
+
 def join_side_stream(device):
     if WGRAD_SIDE_STREAM:
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def finalize_on_side_stream(jobs, blk, tensors):
-    """Gradient finalisation of a block (and the announcement of its gradients to the reducer) on
-    the side stream, behind the block's weight-gradient GEMMs: the main stream goes straight on to
-    the previous block.  `tensors`: everything the side stream reads — they were allocated on the
-    main stream, so the allocator is told not to recycle them before the side stream is done."""
+def finalize_on_side_stream(jobs, blk, tensors, wgrads=None):
+    """The block's weight gradients (`wgrads`: ONE grouped launch, see wgrad_group), the finalisation of its small
+    gradients and the announcement of its gradients to the reducer, on the side stream: the main stream goes straight
+    on to the previous block.  `tensors`: everything the side stream reads — they were allocated on the main stream, so
+    the allocator is told not to recycle them before the side stream is done."""
     dev = tensors[0].device
     if not WGRAD_SIDE_STREAM:
+        if wgrads:
+            wgrad_group(wgrads)
         jobs.launch()
         _notify(blk)
         return
@@ -302,6 +348,8 @@ def finalize_on_side_stream(jobs, blk, tensors):
     side = _side_stream(dev)
     side.wait_event(main.record_event())
     with torch.cuda.stream(side):
+        if wgrads:
+            wgrad_group(wgrads)
         jobs.launch()
         _notify(blk)
     for t in tensors:
@@ -782,12 +830,18 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
 
     jobs = GradJobs()
     # ---- MLP branch -----------------------------------------------------------------------
-    pw2, _ = wgrad_parts_async(df, g)
-    jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
+    grouped = WGRAD_GROUPED
+    extra = []
+    if not grouped:
+        pw2, _ = wgrad_parts_async(df, g)
+        jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
+        extra.append(pw2)
     jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
     dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)           # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
-    pw1, _ = wgrad_parts_async(dh, c)
-    jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
+    if not grouped:
+        pw1, _ = wgrad_parts_async(dh, c)
+        jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
+        extra.append(pw1)
     jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
     dc = linear_dgrad(dh, w1_t, F_, E)
     # dx1 = dx2 + dLN2(dc); dp = s1 * dx1 is the gradient of the proj output, and its column sums
@@ -799,8 +853,10 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
 
     # ---- attention branch ---------------------------------------------------------------------
-    pwp, _ = wgrad_parts_async(dp, o.view(M, Q))
-    jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
+    if not grouped:
+        pwp, _ = wgrad_parts_async(dp, o.view(M, Q))
+        jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
+        extra.append(pwp)
     do = linear_dgrad(dp, wproj_t, E, Q)
     tabs_p = _tables(at)
     dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
@@ -810,15 +866,19 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     for i, t in enumerate(tabs_p):                                     # dtab (workgroup partials, 4, 32, 64)
         jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
     dqkv2d = dqkv.view(M, 3 * Q)
-    pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)                  # rows [q | k | v]; bias rides along
-    jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
-    jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
+    if not grouped:
+        pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)              # rows [q | k | v]; bias rides along
+        jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
+        jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
+        extra += [pwq, pbq]
     da = linear_dgrad_seg(dqkv2d, wqkv_t, 3 * Q, E, Q)
     dx, df_prev, pl1 = ln_bwd_raw(da, x, mean1, rstd1, ln1.weight[:E], dx1, prev_scale, N, want_prev)
     jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
     jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
-    finalize_on_side_stream(jobs, blk, [df, g, pw2, pb2[0], dh, c, pw1, pb1, pl2, dp, o, pwp, dtab, dqkv, a, pwq, pbq,
-                                        pl1])
+    # grouped mode: the four weight gradients (+ the qkv bias gradient: column sums of dqkv, rows [q | k | v]) in one launch
+    wgrads = [(df, g, blk.fc2.weight, None, 0), (dh, c, blk.fc1.weight, None, 0), (dp, o.view(M, Q), at.proj.weight, None, 0),
+              (dqkv2d, a, at.qkv.weight, at.qkv.bias, Q)] if grouped else None
+    finalize_on_side_stream(jobs, blk, [df, g, pb2[0], dh, c, pb1, pl2, dp, o, dtab, dqkv, a, pl1] + extra, wgrads)
     return dx, df_prev, (pl1, P, 3 * E, 2 * E)
 
 
@@ -888,7 +948,7 @@ def _block_grads(blk):
     at = blk.attn
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
     ent = blk.__dict__.get(_GRADS_KEY)
-    if ent is not None and all(p.grad is g for p, g in ent[1]):
+    if ent is not None and ent[2] == WGRAD_GROUPED and all(p.grad is g for p, g in ent[1]):
         return ent[0]
     params = _block_params(blk) + (ln1.weight, ln1.bias, ln2.weight, ln2.bias) + _tables(at)
     gr = [_ensure_grad(p) for p in params]
@@ -898,7 +958,10 @@ def _block_grads(blk):
     g.ln1_g, g.ln1_b, g.ln2_g, g.ln2_b = (t.data_ptr() for t in gr[8:12])
     g.tkv, g.tkh, g.tvv, g.tvh = (t.data_ptr() for t in gr[12:16])
     g.ldt = gr[12].stride(0)
-    blk.__dict__[_GRADS_KEY] = (g, list(zip(params, gr)))
+    if WGRAD_GROUPED:                          # (NULL pointers = split-K launches + cream_grad_finalize)
+        slabs, counters = wgrad_workspace(gr[0].device)
+        g.wgrad_slabs, g.wgrad_counters = slabs.data_ptr(), counters.data_ptr()
+    blk.__dict__[_GRADS_KEY] = (g, list(zip(params, gr)), WGRAD_GROUPED)
     return g
 
 

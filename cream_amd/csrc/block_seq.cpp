@@ -252,24 +252,30 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     const FwdLayout FL = fwd_layout(D);
     const BwdLayout L = bwd_layout(D);
     const int M = (int)D.M, E = (int)D.E, Q = (int)D.Q, F = (int)D.F, N = (int)D.N, P = (int)D.P, slabs = (int)D.slabs;
-    const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
     hipStream_t main = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : main;
 
     // ---- MLP branch ----------------------------------------------------------------------------
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // df, g complete on main
-    PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
     PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
                                  main));
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
+    // Two ways to the weight gradients (measured in one call on one box, twice: 10.92 vs 11.58 ms per step):
+    //   grouped == false (default): one split-K launch per projection as soon as its operands exist, partials added by
+    //       cream_grad_finalize — short workgroups that interleave with the main chain;
+    //   grouped == true (the caller hands over slabs + counters): ONE stream-K launch per block with the reduction in the
+    //       kernel (cream_wgrad_group) — 25 % less side-stream time standalone, but its long-lived workgroups hold half of
+    //       every SIMD's registers for ~200 us and the main chain behind them loses more than the side stream gains.
+    const bool grouped = G->wgrad_slabs && G->wgrad_counters;
+    const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
+    if (!grouped) {
+        if (!fork(main, side)) return CREAM_ERR_LAUNCH;
+        PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
+    }
     PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
     PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
@@ -278,9 +284,21 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
                              at<void>(ws, L.de), at<float>(ws, L.delta), at<void>(ws, L.dout), at<void>(fws, FL.o),
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
+    // ---- all four weight gradients (+ the qkv bias gradient: column sums of dqkv) in ONE launch on the side stream: their
+    // operands are complete on the main stream here; the launch overlaps this block's last passes and the next block's chain
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-    // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
-    PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
+    if (!grouped) {
+        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
+    } else {
+        cream_wgrad_problem W[4] = {
+            {df, at<void>(fws, FL.g), E, F, G->w2, G->ld_w2, nullptr, E, F, 0, 0},
+            {at<void>(ws, L.dh), at<void>(fws, FL.c), F, E, G->w1, G->ld_w1, nullptr, F, E, 0, 0},
+            {at<void>(ws, L.dp), at<void>(fws, FL.o), E, Q, G->wproj, G->ld_proj, nullptr, E, Q, 0, 0},
+            {dqkv, at<void>(fws, FL.a), 3 * Q, E, G->wqkv, G->ld_qkv, G->bqkv, 3 * Q, E, Q, 0}};
+        PTRY(K_GEMM_TN, side, 2.0 * M * ((double)E * F * 2 + (double)E * Q + 3.0 * Q * E), 0,
+             cream_wgrad_group(W, 4, M, G->wgrad_slabs, G->wgrad_counters, side));
+    }
     PTRY(K_GEMM_NT, main, 2.0 * M * 3 * Q * E, 0, cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
                      at<float>(fws, FL.mean1), at<float>(fws, FL.rstd1), d->ln1_g, at<float>(ws, L.dx1), prev_scale, N, M, E, main));
@@ -295,20 +313,22 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         J[n].cols = cols; J[n].interleave = interleave; J[n].src_bf16 = bf16; J[n].reserved = 0;
         ++n;
     };
-    job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, 0);
+    if (!grouped) {
+        job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, 0);
+        job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, 0);
+        job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, 0);
+        job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, 0);
+        job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
+    }
     job(G->b2, E, pb2, pb2_parts, pb2_pstride, 1, E, 0, 0);
-    job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, 0);
     job(G->b1, F, at<void>(ws, L.pb1), slabs, F, 1, F, 0, 0);
     job(G->ln2_g, E, at<float>(ws, L.pl2), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln2_b, E, at<float>(ws, L.pl2) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->bproj, E, at<float>(ws, L.pl2) + 2 * E, P, 3 * (int64_t)E, 1, E, 0, 0);
-    job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, 0);
     const int nb = 2 * d->mr + 2;
     float* tabs[4] = {G->tkv, G->tkh, G->tvv, G->tvh};
     for (int t = 0; t < 4; ++t)
         job(tabs[t], G->ldt, at<float>(ws, L.dtab) + t * 32 * 64, cream_attn_rpe2d_dtab_parts(d->B, d->H), 4 * 32 * 64, nb, 64, 0, 0);
-    job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, 0);
-    job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     job(G->ln1_g, E, at<float>(ws, L.pl1), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));

@@ -184,4 +184,41 @@ int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, co
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+/* ---- all weight gradients of a block in one launch (stream-K ranges, in-kernel fixed-order reduction) ---- */
+int cream_wgrad_group_slots(void) { return 2 * num_cus() / 8 * 8; }          /* ranges = workgroups per launch: 2 per CU */
+
+int64_t cream_wgrad_group_workspace(void) { return (int64_t)2 * cream_wgrad_group_slots() * TN_SLAB * 4; }
+
+int cream_wgrad_group_max_tiles(void) { return 4096; }
+
+int cream_wgrad_group(const cream_wgrad_problem* probs, int nprobs, int M, void* slabs, int32_t* counters, void* stream)
+{
+    if (!probs || nprobs <= 0 || nprobs > 4 || M <= 0 || !slabs || !counters || !aligned16(slabs)) return CREAM_ERR_BAD_ARG;
+    TnGroupParams g{};
+    g.np = nprobs; g.M = M; g.tsteps = (M + 63) / 64;
+    int T = 0;
+    for (int i = 0; i < nprobs; ++i) {
+        const cream_wgrad_problem& q = probs[i];
+        if (q.N <= 0 || q.K <= 0 || q.N % 8 || q.K % 8 || !q.dy || !q.x || !q.dw || q.ldy < q.N || q.ldx < q.K || q.ld_dw < q.K ||
+            q.ld_dw % 4 || q.interleave < 0 || (q.interleave > 0 && q.N != 3 * q.interleave))
+            return CREAM_ERR_BAD_ARG;
+        if (!aligned16(q.dy) || !aligned16(q.x) || !aligned16(q.dw) || q.ldy % 8 || q.ldx % 8) return CREAM_ERR_BAD_ARG;
+        TnProblem& P = g.prob[i];
+        P.dY = (const uint16_t*)q.dy; P.X = (const uint16_t*)q.x; P.ldy = q.ldy; P.ldx = q.ldx;
+        P.dst = q.dw; P.ld_dst = q.ld_dw; P.dst_bias = q.dbias; P.N = q.N; P.K = q.K; P.interleave = q.interleave;
+        P.tile0 = T; P.ntk = (q.K + 127) / 128; P.ntn = (q.N + 127) / 128;
+        P.colmajor = q.K > q.N;                               // X (M x K) is the larger operand: keep its sharers together
+        T += P.ntn * P.ntk;
+    }
+    if (T > cream_wgrad_group_max_tiles()) return CREAM_ERR_TOO_LARGE;
+    g.T = T;
+    g.slabs = (float*)slabs; g.counters = counters;
+    const int64_t U = (int64_t)T * g.tsteps;
+    const int slots = cream_wgrad_group_slots();
+    if ((U + 1) * slots >= ((int64_t)1 << 31)) return CREAM_ERR_TOO_LARGE;     // the kernel's range arithmetic is 32-bit
+    const int grid = U < slots ? (int)U : slots;
+    hipLaunchKernelGGL(gemm_tn_group_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 }  // extern "C"

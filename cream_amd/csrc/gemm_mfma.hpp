@@ -432,29 +432,26 @@ __device__ __forceinline__ bf16x4 tr16(const uint16_t* p) {
         reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p)));
 }
 
-// BM tokens per step, NST LDS stages (NST - 1 steps of loads in flight across the per-step barrier, counted vmcnt)
-template <int OCC, int BM = 64, int NST = 2>
-__global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
+// One 128 x 128 tile of dW over the token steps [s_lo, s_hi): the loop of both TN kernels.
+// BM tokens per step, NST LDS stages (NST - 1 steps of loads in flight across the per-step barrier, counted vmcnt).
+struct TnTile {
+    const uint16_t* dY; const uint16_t* X;
+    int64_t ldy, ldx;
+    int M, N, K, n0, k0;
+};
+
+template <int BM = 64, int NST = 2>
+__device__ __forceinline__ void tn_accumulate(const TnTile& t, int s_lo, int s_hi, bool want_bias, f32x16 (&acc)[2][2],
+                                              f32x16 (&bacc)[2], uint16_t* lds, int tid)
 {
     constexpr int BT = 128;                                     // output tile edge
     constexpr int STAGE = 2 * BM * BT;                          // bf16 elements per stage ([dY | X] tiles)
     constexpr int NPIECE = 2 * BM / 4 / 4;                      // 1-KB pieces (4 rows of 256 B) per wave and stage
     constexpr int PPO = BM / 4;                                 // pieces per operand tile
     static_assert(BM % 16 == 0 && NPIECE >= 2 && NST >= 2 && NST <= 4, "steps");
-    __shared__ __attribute__((aligned(1024))) uint16_t lds[NST * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
-    const int ntk = (p.K + BT - 1) / BT, ntn = (p.N + BT - 1) / BT;
-    // XCD-aware order: all tiles of one split run on ONE XCD (they re-read the same 64-token rows of dY
-    // and X every step: one HBM fetch, the rest from that XCD's L2 — without the remap neighbouring
-    // tiles sit on different XCDs and every operand row is fetched ntn / ntk times)
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid % (ntk * ntn), split = bid / (ntk * ntn);
-    const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
-    const int tsteps = (p.M + BM - 1) / BM;
-    const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
-    const bool want_bias = p.bias_parts && k0 == 0;
 
     // sources: piece j of a stage = rows 4j..4j+3 of [dY tile (pieces 0..15) | X tile (16..31)]
     const uint16_t* src[NPIECE];
@@ -464,16 +461,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
         const int piece = wave + 4 * i, r = (piece % PPO) * 4 + (lane >> 4);    // token row inside the step
         const int c = (lane & 15) ^ ((r & 3) << 2);                             // source chunk of this LDS position
         rowin[i] = r;
-        if (piece < PPO) src[i] = p.dY + min(n0 + c * 8, p.N - 8);              // N, K % 8 == 0: whole chunks
-        else src[i] = p.X + min(k0 + c * 8, p.K - 8);
+        if (piece < PPO) src[i] = t.dY + min(t.n0 + c * 8, t.N - 8);            // N, K % 8 == 0: whole chunks
+        else src[i] = t.X + min(t.k0 + c * 8, t.K - 8);
     }
     auto issue = [&](int step, int buf) {
         const int m0 = step * BM;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
             const bool isY = i < NPIECE / 2;                                      // pieces wave + 4 i < PPO
-            const int m = min(m0 + rowin[i], p.M - 1);
-            const uint16_t* s = src[i] + (int64_t)m * (isY ? p.ldy : p.ldx);
+            const int m = min(m0 + rowin[i], t.M - 1);
+            const uint16_t* s = src[i] + (int64_t)m * (isY ? t.ldy : t.ldx);
             __builtin_amdgcn_global_load_lds(
                 s, reinterpret_cast<__attribute__((address_space(3))) void*>(
                        reinterpret_cast<uintptr_t>(lds + buf * STAGE + (wave + 4 * i) * 4 * BT)), 16, 0, 0);
@@ -490,14 +487,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
         const bf16x4 lo = tr16(tile_ + off), hi = tr16(tile_ + off + 4 * BT);
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-
-    f32x16 acc[2][2], bacc[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        bacc[a] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    }
     const bf16x8 ones = bf16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     // one 64-token step from stage `buf`: fragments double buffered in registers (the transpose reads of
@@ -540,7 +529,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     using Yes = std::integral_constant<bool, true>;
     // the loop exists twice (with / without the bias MFMAs) so that no branch sits between the MFMAs;
     // the token tail (rows beyond M: only the very last step of the last split) is handled after it
-    const bool tail = s_hi > s_lo && s_hi * BM > p.M;
+    const bool tail = s_hi > s_lo && s_hi * BM > t.M;
     const int s_full = tail ? s_hi - 1 : s_hi;
     constexpr int D = NST - 1;
     auto run = [&](auto with_bias) {
@@ -563,7 +552,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             uint16_t* Yt = lds + buf * STAGE;                   // zero the token rows beyond M in both tiles
-            const int valid = p.M - s_full * BM;
+            const int valid = t.M - s_full * BM;
             for (int i = tid; i < 2 * BM * BT / 8; i += 256) {
                 const int r = (i / 16) & (BM - 1);
                 if (r >= valid) *reinterpret_cast<u32x4v*>(Yt + i * 8) = u32x4v{0, 0, 0, 0};
@@ -573,6 +562,39 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
         }
     };
     if (want_bias && wk == 0) run(Yes{}); else run(No{});
+}
+
+__device__ __forceinline__ void tn_zero(f32x16 (&acc)[2][2], f32x16 (&bacc)[2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        bacc[a] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+template <int OCC, int BM = 64, int NST = 2>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
+{
+    constexpr int BT = 128;
+    __shared__ __attribute__((aligned(1024))) uint16_t lds[NST * 2 * BM * BT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int ntk = (p.K + BT - 1) / BT, ntn = (p.N + BT - 1) / BT;
+    // XCD-aware order: all tiles of one split run on ONE XCD (they re-read the same 64-token rows of dY
+    // and X every step: one HBM fetch, the rest from that XCD's L2 — without the remap neighbouring
+    // tiles sit on different XCDs and every operand row is fetched ntn / ntk times)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % (ntk * ntn), split = bid / (ntk * ntn);
+    const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
+    const int tsteps = (p.M + BM - 1) / BM;
+    const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
+    const bool want_bias = p.bias_parts && k0 == 0;
+    f32x16 acc[2][2], bacc[2];
+    tn_zero(acc, bacc);
+    const TnTile t{p.dY, p.X, p.ldy, p.ldx, p.M, p.N, p.K, n0, k0};
+    tn_accumulate<BM, NST>(t, s_lo, s_hi, want_bias, acc, bacc, lds, threadIdx.x);
     // ---- partial tile: D[n][k], lane = column k (l & 31), registers = rows n -------------------------
     const int g = lane >> 5, c32 = lane & 31;
     float* out = p.parts + (int64_t)split * p.N * p.K;
@@ -595,6 +617,192 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
                 const int n = n0 + wn * 64 + a * 32 + acc_row(r, g);
                 if (n < p.N) p.bias_parts[(int64_t)split * p.N + n] = bacc[a][r];
             }
+    }
+}
+
+// =================================================================================================
+// Grouped TN kernel — ALL weight gradients of a transformer block in one launch, reduced in the kernel.
+//
+// Up to 4 problems dW_i(N_i x K_i) = dY_i^T . X_i over the same M tokens (qkv, proj, fc1, fc2 of
+// supernet_transformer.py:251-287).  Their 128 x 128 output tiles are laid end to end and the (tile, 64-token step)
+// space is cut into gridDim.x EQUAL contiguous ranges (stream-K): every workgroup does the same number of steps
+// whatever the mix of shapes (the per-GEMM split-K of gemm_tn_kernel needed 8-16 splits per tile to fill the chip:
+// 4 x 22 MB of fp32 partials written per block and 129 MB read back by cream_grad_finalize; here a tile has
+// ~gridDim.x / tiles contributors — 3 to 5 for the supernet-S shapes).
+// A range that covers a whole tile adds it straight into the gradient.  Partial ranges write an fp32 slab
+// (at most two per workgroup: the one that starts the range, the one that ends it), publish it with the agent-scope
+// release / ticket protocol of cdna_hip_programming.md (plain stores -> every wave drains vmcnt -> barrier -> one
+// lane: release fence, drained, relaxed ticket fetch_add), and the workgroup that draws the LAST ticket of a tile
+// (acquire fence by one lane, barrier) adds the slabs of all contributors IN RANGE ORDER — a fixed summation order
+// whatever the arrival order, bit-reproducible, no atomics on data — into dW[rowmap(n)][k] (the q / k / v row
+// interleave of qkv_super.py:75) and, for the first k-tile of a problem with a bias, the column sums of dY into db.
+// Nobody waits on anybody: no spinning, no deadlock.  The last arriver resets the tile's counter for the next launch.
+struct TnProblem {
+    const uint16_t* dY; const uint16_t* X;
+    int64_t ldy, ldx;
+    float* dst; int64_t ld_dst;
+    float* dst_bias;          // (N) += column sums of dY, or nullptr
+    int N, K;
+    int interleave;           // > 0: dst row of output n = 3 * (n % interleave) + n / interleave
+    int tile0, ntk, ntn;      // first tile of this problem in the launch-wide tile order; k-tiles per tile row, tile rows
+    int colmajor;             // tile order inside the problem: 0 = tile rows (share dY) adjacent, 1 = tile columns (share X) adjacent
+};
+struct TnGroupParams {
+    TnProblem prob[4];
+    int np, M, tsteps, T;     // problems, tokens, ceil(M / 64), tiles in total
+    float* slabs;             // [2 * gridDim.x][TN_SLAB] fp32
+    int32_t* counters;        // [T], zero before the first launch
+};
+constexpr int TN_SLAB = 128 * 128 + 128;                        // tile + its bias row
+
+// range w of G over U units: [U w / G, U (w + 1) / G).  32-bit: the launcher guarantees U * G < 2^31
+__device__ __forceinline__ int tn_range_lo(int U, int w, int G) { return (int)((unsigned)U * (unsigned)w / (unsigned)G); }
+
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, OCC))) void gemm_tn_group_kernel(const TnGroupParams g)
+{
+    constexpr int BT = 128, BM = 64, NST = 2;
+    __shared__ __attribute__((aligned(1024))) uint16_t lds[NST * 2 * BM * BT];
+    const int G = gridDim.x, w = xcd_remap(blockIdx.x, G);     // neighbouring ranges (same tile row, same tokens) share an XCD's L2
+    const int U = g.T * g.tsteps;
+    int lo = tn_range_lo(U, w, G);
+    const int lo0 = lo, hi = tn_range_lo(U, w + 1, G);
+    while (lo < hi) {
+        // the lane index is made opaque per range: everything derived from it (fragment offsets, source pointers, epilogue
+        // addresses) is recomputed per range instead of being hoisted out of this loop and kept live across the MFMA loops
+        // (measured at compile time: 256 VGPRs + scratch with the hoisting, 162 without — and with it no other kernel's
+        // wave fits next to two of these on a SIMD)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wn = wave >> 1, wk = wave & 1;
+        const int gq = lane >> 5, c32 = lane & 31;
+        const int tile = lo / g.tsteps, s_lo = lo - tile * g.tsteps;
+        const int s_hi = min(g.tsteps, s_lo + (hi - lo));
+        // the tile's problem (constant indices: the descriptors stay in scalar registers, no private copy of the arguments)
+        TnProblem P = g.prob[0];
+        if (g.np > 1 && tile >= g.prob[1].tile0) P = g.prob[1];
+        if (g.np > 2 && tile >= g.prob[2].tile0) P = g.prob[2];
+        if (g.np > 3 && tile >= g.prob[3].tile0) P = g.prob[3];
+        // neighbouring tiles (= neighbouring workgroups on one XCD, marching through the tokens in step) share the LARGER operand
+        const int lt = tile - P.tile0;
+        const int n0 = (P.colmajor ? lt % P.ntn : lt / P.ntk) * BT, k0 = (P.colmajor ? lt / P.ntn : lt % P.ntk) * BT;
+        const bool want_bias = P.dst_bias && k0 == 0;
+        f32x16 acc[2][2], bacc[2];
+        tn_zero(acc, bacc);
+        const TnTile t{P.dY, P.X, P.ldy, P.ldx, g.M, P.N, P.K, n0, k0};
+        tn_accumulate<BM, NST>(t, s_lo, s_hi, want_bias, acc, bacc, lds, tid);
+        // ---- the accumulators leave through LDS (the stages are idle): [128 n][128 k] fp32 = exactly the 64 KB of the two
+        //      stages, so that every global access below is a 16-byte row chunk: thread = (rows r0 + 8 i, columns c4 .. c4 + 3)
+        float* ct = reinterpret_cast<float*>(lds);
+        __syncthreads();                                                       // every wave is done reading the stages
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(wn * 64 + a * 32 + acc_row(r, gq)) * BT + wk * 64 + b * 32 + c32] = acc[a][b][r];
+        const bool whole = s_lo == 0 && s_hi == g.tsteps;
+        float* slab = g.slabs + ((int64_t)2 * w + (lo == lo0 ? 0 : 1)) * TN_SLAB;   // slab 0 starts this workgroup's range, slab 1 ends it
+        if (want_bias && wk == 0 && c32 == 0) {                                 // the bias row: 32 values per (wave, half)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = wn * 64 + a * 32 + acc_row(r, gq);
+                    if (whole) { if (n0 + nl < P.N) P.dst_bias[n0 + nl] += bacc[a][r]; }
+                    else __hip_atomic_store(slab + BT * BT + nl, bacc[a][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
+                }
+        }
+        __syncthreads();
+        const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+        const bool kok = k0 + c4 < P.K;                                        // K % 8 == 0: a 4-chunk is all in or all out
+        auto add_rows = [&](int i, const f32x4v& v) {                          // dW[rowmap(n)][k0 + c4 ..] += v
+            const int n = n0 + r0 + 8 * i;
+            if (kok && n < P.N) {
+                const int rr = P.interleave > 0 ? 3 * (n % P.interleave) + n / P.interleave : n;
+                float* d = P.dst + (int64_t)rr * P.ld_dst + k0 + c4;
+                f32x4v o = *reinterpret_cast<f32x4v*>(d);
+                o += v;
+                *reinterpret_cast<f32x4v*>(d) = o;
+            }
+        };
+        if (whole) {
+            // ---- the only contributor of this tile: add into the gradient in place
+#pragma unroll
+            for (int i = 0; i < 16; ++i) add_rows(i, *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4));
+        } else {
+            // ---- partial range: publish the slab WRITE-THROUGH (sc1 16-byte stores: no release fence, no L2 write-back of
+            //      everybody's dirty lines), every wave drains its stores, barrier, one lane draws the tile's ticket
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4);
+                float* dst = slab + (r0 + 8 * i) * BT + c4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                   // (also: everyone is done reading ct)
+            // contributors of this tile: the workgroups whose ranges intersect [tile * tsteps, (tile + 1) * tsteps)
+            const int t_lo = tile * g.tsteps, t_hi = t_lo + g.tsteps;
+            const int w_first = (int)((((unsigned)t_lo + 1u) * (unsigned)G - 1u) / (unsigned)U);
+            const int w_last = (int)(((unsigned)t_hi * (unsigned)G - 1u) / (unsigned)U);
+            const int nc = w_last - w_first + 1;
+            // their slab addresses (0 = empty range), once, into LDS
+            uint64_t* tab = reinterpret_cast<uint64_t*>(lds) + 8;
+            int* flag = reinterpret_cast<int*>(lds);
+            int mine = 0;
+            for (int c = tid; c < nc; c += 256) {
+                const int wc = w_first + c, clo = tn_range_lo(U, wc, G), chi = tn_range_lo(U, wc + 1, G);
+                const bool live = chi > clo;
+                tab[c] = live ? reinterpret_cast<uint64_t>(g.slabs + ((int64_t)2 * wc + (clo >= t_lo ? 0 : 1)) * TN_SLAB) : 0;
+                mine += live;
+            }
+            if (tid == 0) flag[1] = 0;
+            __syncthreads();
+            if (mine) atomicAdd(&flag[1], mine);                               // LDS: number of live contributors
+            __syncthreads();
+            if (tid == 0) {
+                const int n = flag[1];
+                const int ticket = __hip_atomic_fetch_add(&g.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = ticket == n - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale lines: plain loads below
+                    g.counters[tile] = 0;                                      // ready for the next launch (stream order)
+                }
+                flag[0] = last;
+            }
+            __syncthreads();
+            if (flag[0] != 0) {
+                // ---- last arriver: add the slabs of ALL contributors in range order (fixed summation order), eight loads
+                //      in flight per row (the reads come from other CUs' write-through stores: HBM / Infinity Cache latency)
+#pragma nounroll
+                for (int i = 0; i < 16; ++i) {
+                    f32x4v sum = f32x4v{0, 0, 0, 0};
+                    const int off = (r0 + 8 * i) * BT + c4;
+                    for (int cb = 0; cb < nc; cb += 8) {
+                        f32x4v v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint64_t a = cb + j < nc ? tab[cb + j] : 0;
+                            v[j] = a ? *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(a) + off) : f32x4v{0, 0, 0, 0};
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sum += v[j];
+                    }
+                    add_rows(i, sum);
+                }
+                if (want_bias && tid < BT && n0 + tid < P.N) {
+                    float bsum = 0.f;
+                    for (int c = 0; c < nc; ++c)
+                        if (tab[c]) bsum += reinterpret_cast<const float*>(tab[c])[BT * BT + tid];
+                    P.dst_bias[n0 + tid] += bsum;
+                }
+            }
+        }
+        lo += s_hi - s_lo;
+        if (lo < hi) __syncthreads();                                          // next range restages the LDS
     }
 }
 

@@ -381,6 +381,28 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- all weight gradients of a transformer block in ONE launch --------------------------------
+ * dW_i[rowmap(n)][k] += sum_m dy_i[m][n] x_i[m][k]  and  dbias_i[n] += sum_m dy_i[m][n]   for up to 4 projections
+ * over the same M tokens — what autograd derives for LinearSuper / qkv_super (Linear_super.py:71-81,
+ * qkv_super.py:72-83: interleave = Q maps output n of [q | k | v] to super row 3 (n % Q) + n / Q).
+ * The (128 x 128 tile, 64-token step) space of all problems is cut into cream_wgrad_group_slots() equal ranges
+ * (stream-K); partial ranges meet through fp32 slabs in `slabs` (cream_wgrad_group_workspace() bytes, contents
+ * irrelevant between launches) and are added by the last-arriving workgroup of each tile in range order — fixed
+ * summation order, no atomics on data, bit-reproducible.  `counters`: >= cream_wgrad_group_max_tiles() int32,
+ * ZERO before the first launch; every launch leaves them zero.  Launches sharing slabs / counters must be
+ * stream-ordered.  dy / x bf16 (row strides ldy / ldx elements), dw fp32 (row stride ld_dw), N, K % 8 == 0. */
+typedef struct cream_wgrad_problem {
+    const void* dy; const void* x;
+    int64_t ldy, ldx;
+    float* dw; int64_t ld_dw;
+    float* dbias;                 /* (N) or NULL */
+    int32_t N, K, interleave, reserved;
+} cream_wgrad_problem;
+int cream_wgrad_group_slots(void);
+int64_t cream_wgrad_group_workspace(void);
+int cream_wgrad_group_max_tiles(void);
+int cream_wgrad_group(const cream_wgrad_problem* probs, int nprobs, int M, void* slabs, int32_t* counters, void* stream);
+
 /* ---- fp32-I/O instantiations (parity mode) -------------------------------------------------------
  * The same operators with fp32 tensors on both sides, for the "within 1e-3 of the reference PyTorch-CPU
  * forward / backward" bar: exact-fp32 matrix-core products (v_mfma_f32_32x32x2_f32; gfx950 has no TF32)
@@ -454,6 +476,10 @@ typedef struct cream_block_grads {
     float *wqkv, *bqkv, *wproj, *bproj, *w1, *b1, *w2, *b2;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *tkv, *tkh, *tvv, *tvh;
     int64_t ld_qkv, ld_proj, ld_w1, ld_w2, ldt;
+    /* both NULL (default): one split-K launch per projection + cream_grad_finalize; both set: the block's weight gradients
+     * in ONE cream_wgrad_group launch (workspace / counters as that function wants them, shared by all blocks of a device) */
+    void* wgrad_slabs;
+    int32_t* wgrad_counters;
 } cream_block_grads;
 
 /* Bytes of the forward workspace (kept by the caller for the backward); *off_x = block input after

@@ -660,3 +660,93 @@ def test_fp32_layernorm_kernels_match_fp64(M, E, Es):
     print(f"[fp32 own LayerNorm M={M} E={E}]", {k: f"{v:.1e}" for k, v in errs.items()})
     assert all(v < 5e-6 for v in errs.values()), errs
     assert torch.count_nonzero(dg[E:]) == 0 and torch.count_nonzero(db[E:]) == 0
+
+
+@pytest.mark.parametrize("M,shapes", [
+    (394, [(200, 136, False, 0)]),                                                   # ragged: token tail, N / K edges, one tile each way
+    (25216, [(384, 1344, False, 0), (1344, 384, False, 0), (384, 384, False, 0), (1152, 384, True, 384)]),   # a supernet-S block (E 384, H 6)
+    (25216, [(448, 1792, False, 0), (1792, 448, False, 0), (448, 448, False, 0), (1344, 448, True, 448)]),   # the widest block
+    (3000, [(320, 960, False, 0), (960, 320, True, 320)]),
+    (64, [(128, 128, True, 0)]),                                                     # one step: fewer units than workgroups
+])
+def test_grouped_wgrad_matches_fp64_and_is_reproducible(M, shapes):
+    """cream_wgrad_group (csrc/gemm_mfma.hpp: gemm_tn_group_kernel — all weight gradients of a block in one launch, stream-K
+    ranges, last-arriver reduction in range order) against dy^T x in fp64: added INTO the existing gradient (active slice
+    only, qkv rows through the interleave), bias column sums, bit-identical across repeated launches (fixed summation order
+    whatever the arrival order; counters left zero), nothing written outside the slice."""
+    from cream_amd.autoformer import block as K
+    torch.manual_seed(M)
+    probs, refs = [], []
+    for (N, Kd, bias, inter) in shapes:
+        dy = (torch.randn(M, N, device=DEV) * 0.5).to(torch.bfloat16)
+        x = torch.randn(M, Kd, device=DEV).to(torch.bfloat16)
+        w = torch.nn.Parameter(torch.zeros(N + 24, Kd + 40, device=DEV))
+        b = torch.nn.Parameter(torch.zeros(N + 24, device=DEV)) if bias else None
+        probs.append((dy, x, w, b, inter))
+        refs.append((dy.double().T @ x.double(), dy.double().sum(0)))
+    runs = []
+    for rep in range(3):
+        for (_, _, w, b, _) in probs:
+            w.grad = torch.full_like(w, 0.25)                       # pre-existing gradient: the kernel accumulates
+            if b is not None:
+                b.grad = torch.full_like(b, -0.5)
+        K.wgrad_group(probs)
+        torch.cuda.synchronize()
+        runs.append([(w.grad.clone(), b.grad.clone() if b is not None else None) for (_, _, w, b, _) in probs])
+    assert int(K.wgrad_workspace(torch.device(DEV))[1].abs().sum()) == 0          # counters back to zero
+    worst = 0.0
+    for i, ((dy, x, w, b, inter), (rw, rb)) in enumerate(zip(probs, refs)):
+        N, Kd = dy.shape[1], x.shape[1]
+        gw, gb = runs[0][i]
+        rows = torch.arange(N, device=DEV)
+        rows = 3 * (rows % inter) + rows // inter if inter else rows
+        got = gw[rows][:, :Kd].double() - 0.25
+        worst = max(worst, _rel(got, rw))
+        mask = torch.ones_like(gw, dtype=torch.bool)
+        mask[rows[:, None], torch.arange(Kd, device=DEV)[None, :]] = False
+        assert torch.all(gw[mask] == 0.25), "written outside the active slice"
+        if gb is not None:
+            worst = max(worst, _rel(gb[:N].double() + 0.5, rb))
+            assert torch.all(gb[N:] == -0.5)
+        for rep in (1, 2):
+            assert torch.equal(runs[rep][i][0], gw), "not bit-reproducible"
+            if gb is not None:
+                assert torch.equal(runs[rep][i][1], gb)
+    print(f"[grouped wgrad M={M} {[s[:2] for s in shapes]}] worst rel err vs fp64 {worst:.2e}")
+    assert worst < 2e-5                                             # bf16 operands are exact inputs here; fp32 accumulation over M
+
+
+def test_block_backward_grouped_wgrad_equals_split_k_path():
+    """The optional grouped weight-gradient launch inside the native block backward (block.WGRAD_GROUPED) against the default
+    split-K + finalize path on the same B = 128 block: identical dx, every parameter gradient equal to fp32 summation-order
+    noise (both add exact bf16 x bf16 products in fp32, in different fixed orders), both bit-reproducible."""
+    from cream_amd.autoformer import block as K, engine
+    torch.manual_seed(0)
+    m = engine.build_supernet("S", drop_path_rate=0.0, depth=2).to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[384] * 2, num_heads=[6, 5], mlp_ratio=[3.5, 4.0])
+    m.set_sample_config(cfg)
+    m.train()
+    x = torch.randn(128, 3, 224, 224, device=DEV)
+    t = torch.softmax(torch.randn(128, 1000, device=DEV), -1)
+    res = {}
+    try:
+        for grouped in (False, True, True):
+            K.WGRAD_GROUPED = grouped
+            m.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = engine.soft_target_cross_entropy(m(x), t)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.setdefault(grouped, []).append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        K.WGRAD_GROUPED = False
+    worst = 0.0
+    for k, a in res[False][0].items():
+        b = res[True][0][k]
+        assert torch.equal(res[True][1][k], b), k                  # grouped path reproducible
+        if float(a.abs().max()) == 0.0:
+            assert float(b.abs().max()) == 0.0, k
+            continue
+        worst = max(worst, _rel(b, a))
+    print(f"[grouped vs split-K weight gradients inside the block backward] worst rel difference {worst:.2e}")
+    assert worst < 1e-5
