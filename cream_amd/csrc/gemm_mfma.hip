@@ -180,7 +180,11 @@ int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, co
     if (!parts || !dy || !x || !aligned16(dy) || !aligned16(x) || !aligned16(parts)) return CREAM_ERR_BAD_ARG;
     TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts};
     const int grid = ((N + 127) / 128) * ((K + 127) / 128) * S;
-    hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    // the bias-free instantiation has no bias accumulators (126 instead of 165 VGPRs: room for two more waves of the main chain's
+    // kernels per SIMD next to two of these — measured neutral on the step, 10.76 vs 10.75 ms in a same-box A/B x3: the two
+    // streams share throughput, not register space)
+    if (bias_parts) hipLaunchKernelGGL((gemm_tn_kernel<2, 64, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 64, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

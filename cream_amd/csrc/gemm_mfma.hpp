@@ -440,7 +440,7 @@ struct TnTile {
     int M, N, K, n0, k0;
 };
 
-template <int BM = 64, int NST = 2>
+template <int BM = 64, int NST = 2, bool CAN_BIAS = true>
 __device__ __forceinline__ void tn_accumulate(const TnTile& t, int s_lo, int s_hi, bool want_bias, f32x16 (&acc)[2][2],
                                               f32x16 (&bacc)[2], uint16_t* lds, int tid)
 {
@@ -561,7 +561,11 @@ __device__ __forceinline__ void tn_accumulate(const TnTile& t, int s_lo, int s_h
             step(buf, with_bias);
         }
     };
-    if (want_bias && wk == 0) run(Yes{}); else run(No{});
+    if constexpr (CAN_BIAS) {
+        if (want_bias && wk == 0) run(Yes{}); else run(No{});
+    } else {
+        run(No{});
+    }
 }
 
 __device__ __forceinline__ void tn_zero(f32x16 (&acc)[2][2], f32x16 (&bacc)[2]) {
@@ -573,7 +577,7 @@ __device__ __forceinline__ void tn_zero(f32x16 (&acc)[2][2], f32x16 (&bacc)[2]) 
     }
 }
 
-template <int OCC, int BM = 64, int NST = 2>
+template <int OCC, int BM = 64, int NST = 2, bool CAN_BIAS = true>
 __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
 {
     constexpr int BT = 128;
@@ -590,11 +594,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
     const int tsteps = (p.M + BM - 1) / BM;
     const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
-    const bool want_bias = p.bias_parts && k0 == 0;
+    const bool want_bias = CAN_BIAS && p.bias_parts && k0 == 0;
     f32x16 acc[2][2], bacc[2];
     tn_zero(acc, bacc);
     const TnTile t{p.dY, p.X, p.ldy, p.ldx, p.M, p.N, p.K, n0, k0};
-    tn_accumulate<BM, NST>(t, s_lo, s_hi, want_bias, acc, bacc, lds, threadIdx.x);
+    tn_accumulate<BM, NST, CAN_BIAS>(t, s_lo, s_hi, want_bias, acc, bacc, lds, threadIdx.x);
     // ---- partial tile: D[n][k], lane = column k (l & 31), registers = rows n -------------------------
     const int g = lane >> 5, c32 = lane & 31;
     float* out = p.parts + (int64_t)split * p.N * p.K;
