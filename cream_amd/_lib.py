@@ -84,6 +84,7 @@ SIGNATURES = {
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
+    "cream_soft_ce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "cream_wgrad_group_slots": (_i, []),
     "cream_wgrad_group_workspace": (_i64, []),
     "cream_wgrad_group_max_tiles": (_i, []),

@@ -373,14 +373,15 @@ class GradJobs:
         self.n = 0
         self.keep = []
 
-    def add(self, param, src, nparts, pstride, rows, cols, interleave=0, src_offset=0):
+    def add(self, param, src, nparts, pstride, rows, cols, interleave=0, src_offset=0, ld=None):
         if param.grad is None:
             param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
         g = param.grad
+        assert g.is_contiguous() or g.dim() <= 2
         j = self.jobs[self.n]
         j.dst = g.data_ptr()
         j.src = src.data_ptr() + src_offset * src.element_size()
-        j.ld = g.stride(0) if g.dim() == 2 else cols
+        j.ld = ld if ld is not None else (g.stride(0) if g.dim() == 2 else cols)
         j.pstride = pstride
         j.nparts, j.rows, j.cols = nparts, rows, cols
         j.interleave = interleave
@@ -584,6 +585,143 @@ def patch_operands(pe, fresh=True):
     return ops
 
 
+class HeadOperands:
+    """bf16 operand copies of the classifier (LinearSuper `head`, supernet_transformer.py:136): W (classes, E_super), its
+    transpose and the bias — the head runs on the same NT / TN GEMMs as the block projections."""
+
+    def __init__(self, head):
+        self.mod = head
+        w = head.weight
+        bf = dict(dtype=torch.bfloat16, device=w.device)
+        self.w = torch.empty(tuple(w.shape), **bf)
+        self.wt = torch.empty((w.shape[1], w.shape[0]), **bf)
+        self.b = torch.empty((w.shape[0],), **bf)
+        self.key = self._key()
+        self.versions = None
+        self._table = None
+        _register(self)
+
+    def _key(self):
+        return (self.mod.weight.data_ptr(),)
+
+    def jobs(self, grads=False, states=None, weight_decay=0.0):
+        m = self.mod
+        out = []
+        for prm, mir, mir_t in ((m.weight, self.w, self.wt), (m.bias, self.b, None)):
+            st = states[prm] if states else (None, None)
+            out.append((prm, param_job(prm.detach(), prm.grad if grads else None, st[0], st[1], mir, mir_t, weight_decay=weight_decay)))
+        return out
+
+    def refresh(self):
+        if self._table is None:
+            self._table = JobTable([j for _, j in self.jobs()], self.w.device)
+        self._table.launch(update=False)
+        self.mark_fresh()
+
+    def mark_fresh(self):
+        self.versions = (self.mod.weight._version, self.mod.bias._version)
+
+    def stale(self):
+        return self.versions != (self.mod.weight._version, self.mod.bias._version)
+
+
+def head_operands(head, fresh=True):
+    ops = head.__dict__.get(_OPS_KEY)
+    if ops is None or ops.key != ops._key():
+        ops = head.__dict__[_OPS_KEY] = HeadOperands(head)
+    if fresh and ops.stale():
+        ops.refresh()
+    return ops
+
+
+def head_supported(head, feat):
+    return (NATIVE_ENDS_GRADS and feat.is_cuda and feat.dim() == 2 and feat.dtype == torch.float32
+            and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and getattr(head, 'bias', None) is not None and not getattr(head, 'scale', False)
+            and head.weight.dtype == torch.float32 and head.sample_in_dim % 8 == 0 and head.sample_out_dim % 8 == 0
+            and head.sample_in_dim == feat.shape[1])
+
+
+# Parameter gradients of the two ends of forward_features and of the classifier are ADDED INTO p.grad by one
+# cream_grad_finalize launch per node (fixed summation order) and announced through the on_grads_ready hooks, like the
+# blocks' — instead of zero-filled super-shaped temporaries + reductions + autograd's accumulate (round 2: ~45 fills and
+# 19 copies per step in this path).
+NATIVE_ENDS_GRADS = os.environ.get('CREAM_NATIVE_ENDS_GRADS', '1') != '0'
+
+
+def _accumulate_and_notify(jobs, params):
+    jobs.launch()
+    if _grad_ready_hooks:
+        for fn in _grad_ready_hooks:
+            fn(params)
+
+
+class HeadFunction(torch.autograd.Function):
+    """logits (B, classes) bf16 = feat (B, E) . W[:, :E]^T + b on the own NT GEMM (LinearSuper.forward of the classifier,
+    Linear_super.py:51-54 under autocast); backward: dgrad on the transposed copy, weight + bias gradient in one TN launch
+    whose partials go straight into weight.grad[:, :E] / bias.grad."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, head):
+        ops = head_operands(head)
+        C, E = head.sample_out_dim, head.sample_in_dim
+        x = feat.to(torch.bfloat16).contiguous()
+        logits = linear_fwd(x, ops.w, ops.b, C, E)
+        ctx.save_for_backward(x)
+        ctx.head, ctx.dims = head, (C, E)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        (x,) = ctx.saved_tensors
+        head = ctx.head
+        C, E = ctx.dims
+        ops = head_operands(head, fresh=False)
+        dl = dlogits if dlogits.dtype == torch.bfloat16 else dlogits.to(torch.bfloat16)
+        dl = dl.contiguous()
+        dfeat = linear_dgrad(dl, ops.wt, C, E).float()
+        parts, bparts = linear_wgrad_parts(dl, x, want_bias=True)
+        jobs = GradJobs()
+        jobs.add(head.weight, parts, parts.shape[0], C * E, C, E)
+        jobs.add(head.bias, bparts, bparts.shape[0], C, 1, C)
+        _accumulate_and_notify(jobs, [head.weight, head.bias])
+        return dfeat, None, None, None
+
+
+def head(head_mod, feat):
+    return HeadFunction.apply(feat, head_mod.weight, head_mod.bias, head_mod)
+
+
+class SoftTargetCEFunction(torch.autograd.Function):
+    """mean_b sum_c -t log_softmax(x) with the logit gradient produced by the SAME launch (cream_soft_ce)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lib = _lib.load()
+        B, C = logits.shape
+        x = logits.contiguous()
+        t = target.contiguous()
+        rows = torch.empty(B, dtype=torch.float32, device=x.device)
+        dl = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        code = _lib.BF16 if x.dtype == torch.bfloat16 else _lib.F32
+        _lib.check(lib.cream_soft_ce(_p(rows), _p(dl), _p(x), _p(t), B, C, code, 1.0 / B, _stream()), "cream_soft_ce")
+        ctx.save_for_backward(dl)
+        ctx.out_dtype = logits.dtype
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        out = torch.empty(dl.shape, dtype=ctx.out_dtype, device=dl.device)
+        torch.mul(dl, g, out=out)                                # one rounding to the logits' dtype, as at the autocast boundary
+        return out, None
+
+
+def soft_ce_supported(logits, target):
+    return (logits.is_cuda and logits.dim() == 2 and logits.shape[1] <= 2048 and logits.dtype in (torch.bfloat16, torch.float32)
+            and target.dtype == torch.float32 and target.shape == logits.shape and not target.requires_grad)
+
+
 class PatchEmbedFunction(torch.autograd.Function):
     """y (B*P, E) = patches (B*P, K) . W[:E]^T + b[:E] on the own GEMMs; backward = the split-K TN product
     (weight and bias gradient in one launch) added into the active rows of the conv weight's gradient.  The
@@ -644,6 +782,7 @@ class StemFunction(torch.autograd.Function):
                                            pos.shape[-1] if pos is not None else 0, B, N, E, stream), "cream_stem_assemble")
         ctx.save_for_backward(patches)
         ctx.pe, ctx.E, ctx.K, ctx.dims = pe, E, K, (B, N)
+        ctx.params = (weight, bias, cls, pos)
         ctx.shapes = (tuple(weight.shape), tuple(bias.shape), tuple(cls.shape), tuple(pos.shape) if pos is not None else None)
         return x0
 
@@ -660,6 +799,20 @@ class StemFunction(torch.autograd.Function):
         _lib.check(lib.cream_stem_bwd(_p(dy), _p(psum), _p(dx0), B, N, E, _stream()), "cream_stem_bwd")
         parts, bparts = linear_wgrad_parts(dy, patches, want_bias=True)
         wshape, bshape, cshape, pshape = ctx.shapes
+        if NATIVE_ENDS_GRADS:
+            # every parameter gradient of the stem in ONE launch, added into the active slices of the .grad tensors
+            pe, (w, b, cls, pos) = ctx.pe, ctx.params
+            jobs = GradJobs()
+            jobs.add(w, parts, parts.shape[0], E * K, E, K, ld=K)
+            jobs.add(b, bparts, bparts.shape[0], E, 1, E)
+            chunks = psum.shape[0]
+            jobs.add(cls, psum, chunks, N * E, 1, E, ld=cshape[-1])                       # token 0 = class token
+            params = [w, b, cls]
+            if pos is not None:
+                jobs.add(pos, psum, chunks, N * E, N, E, ld=pshape[-1])
+                params.append(pos)
+            _accumulate_and_notify(jobs, params)
+            return None, None, None, None, None, None, None
         gw = torch.zeros((wshape[0], K), dtype=torch.float32, device=dev)
         gb = torch.zeros(bshape, dtype=torch.float32, device=dev)
         torch.sum(parts, dim=0, out=gw[:E])
@@ -1059,6 +1212,7 @@ class StackFunction(torch.autograd.Function):
                                           tail_eps, stream), "cream_tail_fwd")
             ctx.tail_ptrs = (cur, pend_f, pend_s)
             ctx.tail_shapes = (tuple(tail_w.shape), tuple(tail_b.shape))
+            ctx.tail_params = (tail_w, tail_b) if isinstance(tail_w, torch.nn.Parameter) else None
             ctx.save_for_backward(x, *wss, *([scales] if scales is not None else []), xm, stats, gamma)
             return pooled
         out = torch.empty((B, N, E), dtype=torch.float32, device=dev)
@@ -1121,11 +1275,20 @@ class StackFunction(torch.autograd.Function):
                                           stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), sp, B, N, E, stream),
                        "cream_tail_bwd")
             wshape, bshape = ctx.tail_shapes
-            gw = torch.zeros(wshape, dtype=torch.float32, device=dev)
-            gb = torch.zeros(bshape, dtype=torch.float32, device=dev)
-            torch.sum(g * xm, dim=0, out=gw[:E])
-            torch.sum(g, dim=0, out=gb[:E])
-            tail_grads = (gw, gb)
+            if NATIVE_ENDS_GRADS and ctx.tail_params is not None:
+                # dgamma = sum_b g * xm, dbeta = sum_b g: the batch is the "parts" axis of one finalize launch
+                tw, tb = ctx.tail_params
+                gx = g * xm
+                jobs = GradJobs()
+                jobs.add(tw, gx, B, E, 1, E)
+                jobs.add(tb, g, B, E, 1, E)
+                _accumulate_and_notify(jobs, [tw, tb])
+            else:
+                gw = torch.zeros(wshape, dtype=torch.float32, device=dev)
+                gb = torch.zeros(bshape, dtype=torch.float32, device=dev)
+                torch.sum(g * xm, dim=0, out=gw[:E])
+                torch.sum(g, dim=0, out=gb[:E])
+                tail_grads = (gw, gb)
         else:
             dx_t = dout.contiguous().view(M, E)
             df_t, part = scale_cast_colsum(dx_t, scales[L - 1, 1] if scales is not None else None, N)

@@ -56,7 +56,10 @@ def build_supernet(size='S', drop_path_rate=0.1, num_classes=1000, img_size=224,
 
 
 def soft_target_cross_entropy(logits, target):
-    """timm.loss.SoftTargetCrossEntropy: mean_b sum_c -t[b,c] log_softmax(x)[b,c] (fp32)."""
+    """timm.loss.SoftTargetCrossEntropy: mean_b sum_c -t[b,c] log_softmax(x)[b,c] (fp32).  Device tensors: one launch
+    that also produces the logit gradient (csrc/stem_tail.hip: cream_soft_ce)."""
+    if logits.is_cuda and _block.soft_ce_supported(logits, target):
+        return _block.SoftTargetCEFunction.apply(logits, target)
     return torch.sum(-target * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()
 
 
@@ -134,6 +137,14 @@ class NativeAdamW(torch.optim.Optimizer):
                         j.weight_decay = wd[p]
                         jobs.append(j)
                         done.add(p)
+        head = getattr(self.model, 'head', None)
+        if head is not None and hasattr(head, 'sample_in_dim') and getattr(head, 'bias', None) is not None and head.weight in wd:
+            ops = _block.head_operands(head, fresh=False)
+            self._ops.append(ops)
+            for p, j in ops.jobs(grads=True, states=states):
+                j.weight_decay = wd[p]
+                jobs.append(j)
+                done.add(p)
         for p in wd:
             if p not in done:
                 jobs.append(_block.param_job(p.detach(), p.grad, states[p][0], states[p][1], weight_decay=wd[p]))

@@ -314,4 +314,7 @@ class Vision_TransformerSuper(nn.Module):
         return x[:, 0]
 
     def forward(self, x):
-        return self.head(self.forward_features(x))
+        feat = self.forward_features(x)
+        if feat.is_cuda and NATIVE_ENDS and not isinstance(self.head, nn.Identity) and _block.head_supported(self.head, feat):
+            return _block.head(self.head, feat)          # bf16 throughput mode: classifier on the own GEMMs
+        return self.head(feat)

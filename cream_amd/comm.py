@@ -118,6 +118,7 @@ class GradReducer:
             self.flat[b] = buf
         self.bucket_index = {id(p): b for b, mem in self.members.items() for _, p in mem}
         self.pending = {}
+        self._seen = set()
         self.works = []
         self.active = set()
         self.bytes_sent = 0
@@ -198,6 +199,7 @@ class GradReducer:
         depth = config["layer_num"] if config is not None else None
         self.active = set()
         self.pending = {}
+        self._seen = set()
         for b, mem in self.members.items():
             if depth is not None and b.startswith("block") and int(b[5:]) >= depth:
                 continue
@@ -261,8 +263,11 @@ class GradReducer:
 
     def _hook(self, p):
         b = self.bucket_index.get(id(p))
-        if b is None or b not in self.pending:
+        if b is None or b not in self.pending or id(p) in self._seen:
             return
+        # a parameter counts ONCE per step: nodes that write their gradients themselves announce them explicitly
+        # (block.on_grads_ready), and autograd may still run the parameter's accumulate hook with an undefined gradient
+        self._seen.add(id(p))
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)

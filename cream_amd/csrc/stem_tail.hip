@@ -276,7 +276,87 @@ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+// ---- soft-target cross entropy: loss rows AND the logit gradient in one pass -----------------------
+// timm.loss.SoftTargetCrossEntropy as the step uses it (supernet_engine.py:60-66: criterion(outputs, targets) with the
+// Mixup / label-smoothing soft targets): loss_b = sum_c -t[b,c] log_softmax(x[b,:])[c], mean over the batch.  One
+// workgroup per row: max, log-sum-exp, the row loss and d loss / d x[b,c] = (softmax(x)[c] sum_c t - t[c]) * gscale —
+// what autograd derives, in fp32 (the caller scales it by the incoming gradient and rounds once to the bf16 operand type
+// of the head's dgrad / wgrad GEMMs, like the cast at the autocast boundary).  The framework spent ~10 launches on this (log_softmax, mul, neg, two reductions, their backward).
+template <typename TX>
+__global__ __launch_bounds__(256) void soft_ce_kernel(float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                      const TX* __restrict__ logits, const float* __restrict__ target, int C,
+                                                      float gscale)
+{
+    __shared__ float red[3][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TX* x = logits + (int64_t)row * C;
+    const float* t = target + (int64_t)row * C;
+    constexpr int PER = 8;                                    // classes per thread: C <= 2048
+    float xv[PER], tv[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        const bool ok = c < C;
+        float v = -INFINITY;
+        if (ok) {
+            if constexpr (sizeof(TX) == 2) v = bf2f((short)x[c]); else v = x[c];
+        }
+        xv[i] = v;
+        tv[i] = ok ? t[c] : 0.f;
+        mx = fmaxf(mx, v);
+    }
+    auto block_reduce = [&](float v, int slot, bool is_max) -> float {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
+        if (lane == 0) red[slot][wave] = v;
+        __syncthreads();
+        const float a = red[slot][0], b = red[slot][1], c = red[slot][2], d = red[slot][3];
+        return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);          // fixed order
+    };
+    mx = block_reduce(mx, 0, true);
+    float se = 0.f, st = 0.f, stx = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float e = xv[i] == -INFINITY ? 0.f : __expf(xv[i] - mx);
+        se += e;
+        st += tv[i];
+        stx += tv[i] == 0.f ? 0.f : tv[i] * (xv[i] - mx);
+        xv[i] = e;
+    }
+    se = block_reduce(se, 1, false);
+    // pack the two target sums into one more pass through the same slot array (after everyone has read slot 1)
+    st = block_reduce(st, 2, false);
+    __syncthreads();
+    stx = block_reduce(stx, 0, false);
+    const float lse = __logf(se);
+    if (tid == 0) loss_rows[row] = st * lse - stx;            // sum_c t (lse - (x - mx))
+    const float inv = 1.f / se;
+    float* d = dlogits + (int64_t)row * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        if (c < C) d[c] = (xv[i] * inv * st - tv[i]) * gscale;
+    }
+}
+
 extern "C" {
+
+int cream_soft_ce(float* loss_rows, float* dlogits, const void* logits, const float* target, int B, int C, int logits_dtype,
+                  float grad_scale, void* stream)
+{
+    if (B <= 0 || C <= 0 || C > 2048) return B == 0 ? CREAM_OK : CREAM_ERR_TOO_LARGE;
+    if (!loss_rows || !dlogits || !logits || !target) return CREAM_ERR_BAD_ARG;
+    if (logits_dtype == CREAM_BF16)
+        hipLaunchKernelGGL(soft_ce_kernel<uint16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, loss_rows, dlogits,
+                           (const uint16_t*)logits, target, C, grad_scale);
+    else if (logits_dtype == CREAM_F32)
+        hipLaunchKernelGGL(soft_ce_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, loss_rows, dlogits,
+                           (const float*)logits, target, C, grad_scale);
+    else
+        return CREAM_ERR_BAD_DTYPE;
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
 
 int cream_tail_chunks(int N) { return N <= 0 ? 0 : (N + TAIL_ROWS - 1) / TAIL_ROWS; }
 

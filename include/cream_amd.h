@@ -381,6 +381,16 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- soft-target cross entropy (loss rows + logit gradient in one launch) --------------------------
+ * criterion(outputs, targets) of the step body (AutoFormer/supernet_engine.py:60-66) with timm's
+ * SoftTargetCrossEntropy (third-party, not vendored: restated from its published definition —
+ * loss = mean_b sum_c -t[b,c] log_softmax(x[b,:])[c]; parity unpinned, as for the framework formulation it replaces):
+ *   loss_rows[b] = sum_c t[b,c] (logsumexp(x[b,:]) - x[b,c])                  (the caller takes the mean)
+ *   dlogits[b,c] = (softmax(x[b,:])[c] * sum_c t[b,c] - t[b,c]) * grad_scale   f32 (grad_scale = 1 / B for the mean)
+ * logits (B x C) bf16 or f32 (logits_dtype), target (B x C) f32, C <= 2048; softmax statistics in fp32. */
+int cream_soft_ce(float* loss_rows, float* dlogits, const void* logits, const float* target, int B, int C, int logits_dtype,
+                  float grad_scale, void* stream);
+
 /* ---- all weight gradients of a transformer block in ONE launch --------------------------------
  * dW_i[rowmap(n)][k] += sum_m dy_i[m][n] x_i[m][k]  and  dbias_i[n] += sum_m dy_i[m][n]   for up to 4 projections
  * over the same M tokens — what autograd derives for LinearSuper / qkv_super (Linear_super.py:71-81,

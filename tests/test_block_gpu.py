@@ -750,3 +750,48 @@ def test_block_backward_grouped_wgrad_equals_split_k_path():
         worst = max(worst, _rel(b, a))
     print(f"[grouped vs split-K weight gradients inside the block backward] worst rel difference {worst:.2e}")
     assert worst < 1e-5
+
+
+@pytest.mark.parametrize("B,C,dt", [(128, 1000, torch.bfloat16), (5, 1000, torch.float32), (16, 2048, torch.bfloat16), (3, 37, torch.float32)])
+def test_soft_target_ce_kernel_matches_torch(B, C, dt):
+    """cream_soft_ce (loss rows + logit gradient in one launch) against the framework formulation of
+    timm.loss.SoftTargetCrossEntropy in fp64 on the same (rounded) logits: loss and d loss / d logits, also under an
+    incoming gradient != 1 and with unnormalised targets (Mixup's soft labels sum to 1; the kernel does not assume it)."""
+    from cream_amd.autoformer import block as K
+    torch.manual_seed(B * C)
+    logits = (4 * torch.randn(B, C, device=DEV)).to(dt).requires_grad_()
+    target = torch.softmax(torch.randn(B, C, device=DEV), -1) * (1.0 + 0.1 * torch.rand(B, 1, device=DEV))
+    assert K.soft_ce_supported(logits, target)
+    loss = K.SoftTargetCEFunction.apply(logits, target)
+    (g,) = torch.autograd.grad(loss, logits, torch.tensor(0.75, device=DEV))
+    x = logits.detach().double().requires_grad_()
+    ref = torch.sum(-target.double() * torch.log_softmax(x, -1), -1).mean()
+    (rg,) = torch.autograd.grad(ref, x, torch.tensor(0.75, device=DEV, dtype=torch.float64))
+    el, eg = abs(float(loss) - float(ref)) / abs(float(ref)), _rel(g.double(), rg)
+    print(f"[soft CE B={B} C={C} {dt}] loss {el:.1e} dlogits {eg:.1e}")
+    assert el < 2e-6 and eg < (4e-3 if dt == torch.bfloat16 else 5e-6)        # bf16: the returned gradient is rounded to bf16
+    assert g.dtype == dt
+
+
+def test_native_head_matches_fp32_linear():
+    """The classifier on the own GEMMs (block.HeadFunction: NT forward, dgrad on the transposed copy, weight + bias gradient
+    through one TN launch added into the active slice of the .grad tensors) against F.linear in fp32 on the same inputs."""
+    from cream_amd.autoformer import block as K, engine
+    torch.manual_seed(3)
+    m = engine.build_supernet("S", drop_path_rate=0.0, depth=1).to(DEV)
+    cfg = dict(layer_num=1, embed_dim=[384], num_heads=[6], mlp_ratio=[3.5])
+    m.set_sample_config(cfg)
+    feat = torch.randn(128, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(128, 1000, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert K.head_supported(m.head, feat)
+        y = K.head(m.head, feat)
+    m.head.weight.grad = torch.full_like(m.head.weight, 0.5)        # the node ADDS into existing gradients
+    m.head.bias.grad = None
+    (dx,) = torch.autograd.grad(y, feat, gy.to(torch.bfloat16))
+    w, b = m.head.weight.detach()[:, :384], m.head.bias.detach()
+    errs = dict(y=_rel(y.float(), feat.detach() @ w.T + b), dx=_rel(dx, gy @ w),
+                dw=_rel(m.head.weight.grad[:, :384] - 0.5, gy.T @ feat.detach()), db=_rel(m.head.bias.grad, gy.sum(0)))
+    print("[native head]", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 8e-3 for v in errs.values()), errs                 # bf16 operands (feat, W, dlogits rounded to bf16)
+    assert torch.all(m.head.weight.grad[:, 384:] == 0.5)

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do
-CREAM_TN_AB_OLD=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('old (165 VGPR)', d['value'], d['ms_per_step'])"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bias-free (126 VGPR)', d['value'], d['ms_per_step'])"
-done
+timeout 600 python -m pytest tests/test_block_gpu.py -m gpu -x -q -s -k "soft_target_ce or native_head" 2>&1 | grep -E "^\.*\[|passed|failed|Error|assert" | tail
