@@ -52,3 +52,66 @@ class RASampler(torch.utils.data.Sampler):
 
     def set_epoch(self, epoch):
         self.epoch = epoch
+
+
+class Mixup:
+    """Batch-mode Mixup / CutMix with label smoothing as the step's `mixup_fn(samples, targets)` (supernet_engine.py:52-53;
+    constructed at supernet_train.py:245-251: mixup 0.8, cutmix 1.0, prob 1.0, switch_prob 0.5, mode 'batch', smoothing 0.1).
+    timm.data.Mixup is third-party code that the reference does not vendor: restated here from its published definition —
+    parity UNPINNED (no reference-made fixture can exist) — with numpy's global RNG in timm's draw order (apply?, cutmix?,
+    lambda ~ Beta, box centre y, x), so that a seeded run makes the same decisions.  Works in place on device tensors:
+        mixup : x <- lam x + (1 - lam) x.flip(0)
+        cutmix: x[:, :, box] <- x.flip(0)[:, :, box],  lam <- 1 - box area / image area
+        target: lam onehot_s(y) + (1 - lam) onehot_s(y.flip(0)),  onehot_s = smoothing / C off, 1 - smoothing + off on."""
+
+    def __init__(self, mixup_alpha=0.8, cutmix_alpha=1.0, prob=1.0, switch_prob=0.5, mode='batch', label_smoothing=0.1,
+                 num_classes=1000):
+        assert mode == 'batch', "the recipe's mode (supernet_train.py:249); 'pair' / 'elem' are not on this path"
+        self.mixup_alpha, self.cutmix_alpha = mixup_alpha, cutmix_alpha
+        self.mix_prob, self.switch_prob = prob, switch_prob
+        self.label_smoothing, self.num_classes = label_smoothing, num_classes
+        self.mixup_enabled = True
+
+    def _params_per_batch(self):
+        import numpy as np
+        lam, use_cutmix = 1.0, False
+        if self.mixup_enabled and np.random.rand() < self.mix_prob:
+            if self.mixup_alpha > 0. and self.cutmix_alpha > 0.:
+                use_cutmix = np.random.rand() < self.switch_prob
+                lam = np.random.beta(self.cutmix_alpha, self.cutmix_alpha) if use_cutmix else \
+                    np.random.beta(self.mixup_alpha, self.mixup_alpha)
+            elif self.mixup_alpha > 0.:
+                lam = np.random.beta(self.mixup_alpha, self.mixup_alpha)
+            elif self.cutmix_alpha > 0.:
+                use_cutmix = True
+                lam = np.random.beta(self.cutmix_alpha, self.cutmix_alpha)
+        return float(lam), use_cutmix
+
+    @staticmethod
+    def rand_bbox(height, width, lam):
+        import numpy as np
+        ratio = (1.0 - lam) ** 0.5
+        cut_h, cut_w = int(height * ratio), int(width * ratio)
+        cy, cx = np.random.randint(0, height), np.random.randint(0, width)
+        yl, yh = int(np.clip(cy - cut_h // 2, 0, height)), int(np.clip(cy + cut_h // 2, 0, height))
+        xl, xh = int(np.clip(cx - cut_w // 2, 0, width)), int(np.clip(cx + cut_w // 2, 0, width))
+        return yl, yh, xl, xh
+
+    def mix_targets(self, target, lam):
+        off = self.label_smoothing / self.num_classes
+        on = 1.0 - self.label_smoothing + off
+        y = torch.full((target.shape[0], self.num_classes), off, device=target.device, dtype=torch.float32)
+        y.scatter_(1, target.long().view(-1, 1), on)
+        return y * lam + y.flip(0) * (1.0 - lam)
+
+    def __call__(self, x, target):
+        assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
+        lam, use_cutmix = self._params_per_batch()
+        if lam != 1.0:
+            if use_cutmix:
+                yl, yh, xl, xh = self.rand_bbox(x.shape[-2], x.shape[-1], lam)
+                lam = 1.0 - (yh - yl) * (xh - xl) / float(x.shape[-2] * x.shape[-1])     # corrected for the clipped box
+                x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh]
+            else:
+                x.copy_(x * lam + x.flip(0) * (1.0 - lam))
+        return x, self.mix_targets(target, lam)

@@ -177,3 +177,41 @@ def deit_irpe(size='tiny', img_size=224, rpe_on='k', method='product', mode='ctx
 def deit_tiny_patch16_224_ctx_product_50_shared_k(**kwargs):
     """BASELINE config 1 (rpe_models.py:48-61): 5,755,816 parameters."""
     return deit_irpe('tiny', rpe_on='k', **kwargs)
+
+
+# The checkpoints the reference's model zoo provides (rpe_models.py:10-19) and the constructors that take them
+# (rpe_models.py:48-193): same names, same state-dict keys (tests/golden/irpe_zoo.json, made from the reference's classes).
+PROVIDED_CHECKPOINTS = {
+    'deit_tiny_patch16_224_ctx_product_50_shared_k': ('tiny', 'k'),
+    'deit_small_patch16_224_ctx_product_50_shared_k': ('small', 'k'),
+    'deit_small_patch16_224_ctx_product_50_shared_qk': ('small', 'qk'),
+    'deit_small_patch16_224_ctx_product_50_shared_qkv': ('small', 'qkv'),
+    'deit_base_patch16_224_ctx_product_50_shared_k': ('base', 'k'),
+    'deit_base_patch16_224_ctx_product_50_shared_qkv': ('base', 'qkv'),
+}
+
+
+def create_zoo_model(name, checkpoint=None, **kwargs):
+    """`register_rpe_model` of rpe_models.py:22-43 without the download: build the named model and, if `checkpoint` (a path
+    or the loaded dictionary of a published `<name>.pth`: {'model': state_dict}) is given, load it strictly.  Files are read
+    with the tensors-only unpickler."""
+    assert name in PROVIDED_CHECKPOINTS, f'Sorry that the checkpoint `{name}` is not provided yet.'       # rpe_models.py:30-31
+    size, rpe_on = PROVIDED_CHECKPOINTS[name]
+    model = deit_irpe(size, rpe_on=rpe_on, **kwargs)
+    if checkpoint is not None:
+        ckpt = checkpoint if isinstance(checkpoint, dict) else torch.load(checkpoint, map_location='cpu', weights_only=True)
+        model.load_state_dict(ckpt['model'])
+    return model
+
+
+def _zoo_entry(name):
+    def build(pretrained=False, checkpoint=None, **kwargs):
+        assert not pretrained or checkpoint is not None, "no network here: pass checkpoint=<path or dict> instead of pretrained"
+        return create_zoo_model(name, checkpoint, **kwargs)
+    build.__name__ = name
+    return build
+
+
+for _n in PROVIDED_CHECKPOINTS:
+    if _n not in globals():
+        globals()[_n] = _zoo_entry(_n)

@@ -613,6 +613,21 @@ def minivit():
     save('minivit.npz', **outs)
 
 
+def irpe_zoo():
+    """The six checkpoints the reference's model zoo provides (rpe_models.py:10-19): state-dict keys, shapes and
+    parameter counts of the registered constructors that load them (rpe_models.py:48-193) — what a published
+    `<name>.pth` ({'model': state_dict}) must fit into."""
+    irpe2, rvt, models, rpe_models = refshim.load_irpe_models()
+    meta = {}
+    for name in sorted(rpe_models._provided_checkpoints):
+        model = getattr(rpe_models, name)()
+        sd = model.state_dict()
+        meta[name] = dict(keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                          n_params=sum(p.numel() for p in model.parameters()))
+    json.dump(meta, open(os.path.join(HERE, 'irpe_zoo.json'), 'w'))
+    print('irpe_zoo.json', {k: v['n_params'] for k, v in meta.items()})
+
+
 if __name__ == '__main__':
     assert refshim.have_reference(), "needs the reference checkout at /root/reference"
     which = sys.argv[1:] or ['autoformer', 'irpe']
@@ -638,3 +653,5 @@ if __name__ == '__main__':
         rasampler()
     if 'tinyclip_ckpt' in which:
         tinyclip_ckpt()
+    if 'irpe_zoo' in which:
+        irpe_zoo()

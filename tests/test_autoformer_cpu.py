@@ -243,3 +243,35 @@ def test_checkpoint_layout_and_resume(tmp_path):
     m3 = engine.build_supernet("T", depth=2)
     assert engine.load_checkpoint({"model": ck["model"]}, m3) == 0
     assert engine.load_checkpoint(path, m3, eval_only=True) == 0
+
+
+def test_mixup_cutmix_batch_mode_properties():
+    """Mixup / CutMix of the step (supernet_train.py:245-251 -> timm.data.Mixup, third-party and not vendored: restated,
+    parity unpinned): soft targets sum to 1 and equal lam * onehot_s(y) + (1 - lam) * onehot_s(y flipped); mixup blends the
+    batch with its flip; cutmix pastes exactly one box and lam is the surviving area; seeded numpy draws are reproducible."""
+    import numpy as np
+    from cream_amd.autoformer.data import Mixup
+    fn = Mixup(num_classes=10)
+    seen = set()
+    for seed in range(12):
+        np.random.seed(seed)
+        x0 = torch.randn(4, 3, 32, 32)
+        y = torch.tensor([1, 3, 5, 7])
+        np.random.seed(seed)
+        x, t = fn(x0.clone(), y)
+        np.random.seed(seed)
+        lam, cut = fn._params_per_batch()
+        seen.add(cut)
+        assert torch.allclose(t.sum(1), torch.ones(4), atol=1e-6)
+        if cut:
+            yl, yh, xl, xh = fn.rand_bbox(32, 32, lam)
+            lam = 1.0 - (yh - yl) * (xh - xl) / 1024.0
+            ref = x0.clone()
+            ref[:, :, yl:yh, xl:xh] = x0.flip(0)[:, :, yl:yh, xl:xh]
+            assert torch.equal(x, ref)
+        else:
+            assert torch.allclose(x, x0 * lam + x0.flip(0) * (1 - lam), atol=1e-6)
+        on, off = 0.9 + 0.01, 0.01
+        oh = torch.full((4, 10), off).scatter_(1, y.view(-1, 1), on)
+        assert torch.allclose(t, oh * lam + oh.flip(0) * (1 - lam), atol=1e-6)
+    assert seen == {True, False}

@@ -17,15 +17,17 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def _worker(rank, world, port, q, backend="gloo"):
+    local = rank if backend == "nccl" else 0                   # RCCL: one GPU per rank; gloo: both ranks drive the one GPU of the box
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
     try:
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda:0")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
         from cream_amd import comm
         from cream_amd.autoformer import engine
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         torch.manual_seed(11 + rank)                           # different initial weights per rank (reducer broadcasts)
         model = engine.build_supernet("S", drop_path_rate=0.0, depth=3).to(dev)
         choices = dict(mlp_ratio=[3.0, 3.5, 4.0], num_heads=[5, 6, 7], depth=[2, 3], embed_dim=[320, 384, 448])
@@ -67,6 +69,7 @@ def _worker(rank, world, port, q):
         # active-slice messages (csrc/slices.hip on the device): exactly the elements this configuration can write
         active = sum(4 * r * c for r, c in (comm.autoformer_active_slice(n, p, cfg) for n, p in model.named_parameters()))
         assert sent == active, (sent, active)
+        assert reducer.use_avg == (backend == "nccl")          # RCCL: one AVG all-reduce per message
         q.put((rank, err, in_sync, sent, full, float(loss.detach()), None))
         dist.barrier()
         dist.destroy_process_group()
@@ -93,4 +96,25 @@ def test_two_ranks_on_the_device_native_path():
         assert err < 1e-5, err                                  # the kernels are atomics-free and bit-reproducible: measured 0.0
         assert in_sync
         assert sent <= full                                     # slices of the sampled sub-network, not whole buckets
+    assert all(p.exitcode == 0 for p in procs)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the gpurun box has one; the 8-GPU node runs this)")
+def test_two_ranks_rccl():
+    """The same two-rank step over the `nccl` backend (= RCCL over xGMI): one process per GPU, the reducer's AVG all-reduce
+    of the active-slice messages on its communication stream, NativeAdamW on the arena — gradients equal the mean of the
+    ranks' local gradients, replicas identical after optimizer steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30900 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, err, in_sync, sent, full, loss, tb in res:
+        assert tb is None, f"rank {rank} failed:\n{tb}"
+        print(f"[2 ranks, RCCL] rank {rank}: reducer vs mean of local gradients {err:.2e}, in sync {in_sync}, sent {sent / 1e6:.1f} MB")
+        assert err < 1e-5 and in_sync and 0 < sent <= full
     assert all(p.exitcode == 0 for p in procs)

@@ -285,3 +285,32 @@ def test_irpe_oracle_is_pinned():
     for k, v in fix.items():
         if k.startswith("full|"):
             assert max_rel(holder[k[5:]].grad, v) < 1e-5, k
+
+
+def test_model_zoo_checkpoints_fit():
+    """The six checkpoints of the reference's model zoo (rpe_models.py:10-19): the constructors of the same names produce
+    exactly the state-dict keys, shapes and parameter counts of the reference's classes (fixture irpe_zoo.json, generated by
+    instantiating them), a published-format file ({'model': state_dict}) loads strictly through the tensors-only reader,
+    and an unknown name fails like the reference's assertion."""
+    import cream_amd.rpe_attention as R
+    zoo = load_json("irpe_zoo.json")
+    assert set(zoo) == set(R.PROVIDED_CHECKPOINTS)
+    for name, rec in zoo.items():
+        m = getattr(R, name)()
+        sd = m.state_dict()
+        assert list(sd.keys()) == rec["keys"], name
+        assert [list(v.shape) for v in sd.values()] == rec["shapes"], name
+        assert sum(p.numel() for p in m.parameters()) == rec["n_params"], name
+    import tempfile
+    name = "deit_small_patch16_224_ctx_product_50_shared_qkv"
+    src = getattr(R, name)()
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(0.01)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, name + ".pth")
+        torch.save({"model": src.state_dict()}, path)
+        dst = R.create_zoo_model(name, path)
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    with pytest.raises(AssertionError, match="not provided"):
+        R.create_zoo_model("deit_tiny_patch16_224_ctx_product_50_shared_qkv")
