@@ -377,9 +377,10 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     for (int ks = 0; ks < 4; ++ks) qs[ks] = scaled(qs[ks], a.scale);          // q * scale in q's dtype (:73)
     u32x4v sk, sv4 = {}, sik = {}, siv = {}, siq = {};
     sk = rows_load(kp, a.sn, 0, a.L, false);
-    if constexpr (!HV) sv4 = rows_load(vp, a.sn, 0, a.L, true);
+    sv4 = rows_load(vp, a.sn, 0, a.L, true);
     if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
     if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
+    if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, 0);
     if constexpr (HK) { if (a.wk) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }
     if constexpr (HQ) {
         if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
@@ -390,9 +391,10 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
         for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f;
     }
     rows_store(kbuf, sk);
-    if constexpr (!HV) rows_store(vbuf, sv4);
+    rows_store(vbuf, sv4);
     if constexpr (HK) ids_store(smem + L::idk, sik);
     if constexpr (HQ) ids_store(smem + L::idq, siq);
+    if constexpr (HV) ids_store(smem + L::idv, siv);
     __syncthreads();
     if constexpr (HK) {
         if (active) {
@@ -406,8 +408,13 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
     f32x16 o[2] = {f32x16{}, f32x16{}};
     float l4[4] = {0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY;
-    if constexpr (!HV) {
-        // ---- single pass, online softmax (no bucket sums to rescale): running maximum m, o and l rescaled ----
+    {
+        // ---- ONE pass, online softmax with a LAZY reference maximum: m moves only when a tile's maximum exceeds it by more
+        // than RESCALE_T (probabilities then stay below e^8 — exact in fp32 sums, fine as bf16 MFMA operands), so that the
+        // rescaling of the running state — o, l and, with rpe on values, the 64 bucket sums of the row in LDS — is a rare,
+        // wave-uniform branch instead of per-tile work.  (Round 2 ran TWO passes whenever rpe_v was present — all scores
+        // and both bias gathers twice — because the bucket sums could not be rescaled cheaply every tile.)
+        constexpr float RESCALE_T = 8.f;
         float lrun = 0.f;
         for (int t = 0; t < NT; ++t) {
             const int cur = t & 1, nxt = cur ^ 1;
@@ -417,6 +424,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                 sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
                 if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
                 if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
+                if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
             }
             if (active) {
                 f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
@@ -430,11 +438,23 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
 #pragma unroll
                 for (int r = 4; r < 16; ++r) t4[r & 3] = fmaxf(t4[r & 3], s[r]);
                 float tm = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
-                tm = fmaxf(tm, __shfl_xor(tm, 32));
-                const float mn = fmaxf(m, tm);                       // finite: every tile has a valid key
-                const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
-                const float mLn = mn * LOG2E;
-                m = mn;
+                tm = fmaxf(tm, __shfl_xor(tm, 32));                  // finite: every tile has a valid key
+                const bool grow = tm > m + RESCALE_T;                // (always on the first tile: m = -inf)
+                if (__any(grow)) {
+                    const float mn = grow ? tm : m;
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);      // 1 for the rows that keep their reference
+                    m = mn;
+                    lrun *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                    if constexpr (HV) {
+                        float* row = svw + c32 * LKP + 32 * g;       // this lane's half of the row's 64 bucket sums
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) row[i] *= alpha;        // (row pitch 65 floats: scalar accesses, conflict-free)
+                        wave_lds_fence();
+                    }
+                }
+                const float mLn = m * LOG2E;
                 float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -442,9 +462,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                     s[r] = p;
                     ps[r & 3] += p;
                 }
-                lrun = lrun * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                lrun += (ps[0] + ps[1]) + (ps[2] + ps[3]);
                 const short* vb = vbuf + cur * 32 * KP;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -452,97 +470,23 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                     o[0] = TT::mma(load_perm_tr(vb, 0, s2, lane), pb, o[0]);
                     o[1] = TT::mma(load_perm_tr(vb, 1, s2, lane), pb, o[1]);
                 }
+                if constexpr (HV) {
+                    uint32_t w[4];
+                    lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
+                    scatter_add16(svw + c32 * LKP, w, s, g);
+                }
             }
             if (more) {
                 rows_store(kbuf + nxt * 32 * KP, sk);
                 rows_store(vbuf + nxt * 32 * KP, sv4);
                 if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
                 if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
+                if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
                 __syncthreads();
                 if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
             }
         }
-        l4[0] = lrun;                                  // (lrun already holds this lane's half; halves are added below)
-    } else {
-    // ---- pass 1: row maxima ----------------------------------------------------------------------
-    // tiles 0..NT-1 (pass 1) and again 0..NT-1 (pass 2) form one stream of staged tiles
-    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int t = 0; t < NT; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        const int tn = t + 1 < NT ? t + 1 : 0;
-        const bool with_v = t + 1 >= NT;
-        sk = rows_load(kp, a.sn, tn * 32, a.L, false);
-        if (with_v) sv4 = rows_load(vp, a.sn, tn * 32, a.L, true);
-        if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, tn);
-        if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, tn);
-        if constexpr (HV) { if (with_v) siv = ids_load(a.idv, a.NP, q0, tn); }
-        if (active) {
-            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
-                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
-            if (t == NT - 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * 32 + acc_row(r, g) >= a.L) s[r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], s[r]);
-        }
-        rows_store(kbuf + nxt * 32 * KP, sk);
-        if (with_v) rows_store(vbuf + nxt * 32 * KP, sv4);
-        if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
-        if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
-        if constexpr (HV) { if (with_v) ids_store(smem + L::idv + nxt * 128 * IDP, siv); }
-        __syncthreads();
-        if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
-    }
-    m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    const float mL = m * LOG2E;
-
-    // ---- pass 2: probabilities, P.V, bucket sums -------------------------------------------------
-    for (int t = 0; t < NT; ++t) {
-        const int cur = (NT + t) & 1, nxt = cur ^ 1;
-        const bool more = t + 1 < NT;
-        if (more) {
-            sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
-            sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
-            if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
-            if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
-            if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
-        }
-        if (active) {
-            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
-                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = t < NT - 1 || t * 32 + acc_row(r, g) < a.L;
-                const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -mL)) : 0.f;
-                s[r] = p;
-                l4[r & 3] += p;
-            }
-            const short* vb = vbuf + cur * 32 * KP;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const F pb = TT::from_acc(s, s2);
-                o[0] = TT::mma(load_perm_tr(vb, 0, s2, lane), pb, o[0]);
-                o[1] = TT::mma(load_perm_tr(vb, 1, s2, lane), pb, o[1]);
-            }
-            if constexpr (HV) {
-                uint32_t w[4];
-                lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
-                scatter_add16(svw + c32 * LKP, w, s, g);
-            }
-        }
-        if (more) {
-            rows_store(kbuf + nxt * 32 * KP, sk);
-            rows_store(vbuf + nxt * 32 * KP, sv4);
-            if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
-            if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
-            if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
-            __syncthreads();
-            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
-        }
-    }
+        l4[0] = lrun;                                  // (this lane's half; the halves are added below)
     }
     if (!active) return;
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);

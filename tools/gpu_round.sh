@@ -20,8 +20,12 @@ echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
 # counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 [ -z "$QUICK" ] && for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|rpe_|gemm_|ln_|adamw|grad_finalize' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$N.err
+  # full-size steps only (no batch-4 host leg, no extra legs): the per-kernel means are those of the benchmarked shapes
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|gemm_|ln_|adamw|grad_finalize|soft_ce|tail_|stem_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-host-leg --no-kernel-timing > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
+  # config 4: the fused iRPE attention kernels and the rpe_index kernels under the same counters (bench.py reads their mfma_util / traffic)
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_' -d $OUT/${TAG}_pmc_irpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_pmc_irpe_$N.err
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'rpe_gather|rpe_scatter' -d $OUT/${TAG}_pmc_rpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_pmc_rpe_$N.err"
 done
 # BASELINE config 4: rocprofv3 kernel trace + HBM counters of the rpe_index kernels, stall counters of both kernel families
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_rpe_prof -o rpe -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_rpe_prof.err
