@@ -255,11 +255,9 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     hipStream_t main = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : main;
 
     // ---- MLP branch ----------------------------------------------------------------------------
-    // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
-    PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
-                                 main));
     // Two ways to the weight gradients (measured in one call on one box, twice: 10.92 vs 11.58 ms per step):
-    //   grouped == false (default): one split-K launch per projection as soon as its operands exist, partials added by
+    //   grouped == false (default): one split-K launch per projection AS SOON AS its operands exist (launching them in two
+    //       pairs behind dgrad_mul / the attention backward instead: 11.0 vs 10.83 ms, same-box A/B x3), partials added by
     //       cream_grad_finalize — short workgroups that interleave with the main chain;
     //   grouped == true (the caller hands over slabs + counters): ONE stream-K launch per block with the reduction in the
     //       kernel (cream_wgrad_group) — 25 % less side-stream time standalone, but its long-lived workgroups hold half of
@@ -267,8 +265,14 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     const bool grouped = G->wgrad_slabs && G->wgrad_counters;
     const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
     if (!grouped) {
-        if (!fork(main, side)) return CREAM_ERR_LAUNCH;
+        if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // df, g complete on main
         PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
+    }
+    // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
+    PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+                                 main));
+    if (!grouped) {
+        if (!fork(main, side)) return CREAM_ERR_LAUNCH;
         PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
@@ -276,6 +280,10 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
+    if (!grouped) {
+        if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // dp complete on main
+        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+    }
     PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
@@ -284,13 +292,12 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
                              at<void>(ws, L.de), at<float>(ws, L.delta), at<void>(ws, L.dout), at<void>(fws, FL.o),
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
-    // ---- all four weight gradients (+ the qkv bias gradient: column sums of dqkv) in ONE launch on the side stream: their
-    // operands are complete on the main stream here; the launch overlaps this block's last passes and the next block's chain
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;
+    if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // dqkv complete on main
     if (!grouped) {
-        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+        // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
         PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
     } else {
+        // all four weight gradients (+ the qkv bias gradient) in ONE launch: their operands are complete on the main stream here
         cream_wgrad_problem W[4] = {
             {df, at<void>(fws, FL.g), E, F, G->w2, G->ld_w2, nullptr, E, F, 0, 0},
             {at<void>(ws, L.dh), at<void>(fws, FL.c), F, E, G->w1, G->ld_w1, nullptr, F, E, 0, 0},

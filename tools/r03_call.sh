@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_irpe_fused_gpu.py tests/test_irpe_gpu.py tests/test_minivit.py tests/test_tinyclip_model.py -m gpu -x -q 2>&1 | tail -4
-python tools/bench_irpe_attention.py 2>/dev/null | cut -c1-400
+for rep in 1 2 3; do
+CREAM_TN_LATE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TN late (pairs)', d['value'], d['ms_per_step'])"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TN early (round-2 order)', d['value'], d['ms_per_step'])"
+done
