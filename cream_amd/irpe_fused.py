@@ -205,6 +205,38 @@ class _Fused(torch.autograd.Function):
         return dqkv, None, res[0], res[1], res[2], None
 
 
+def plain_fwd(qkv, scale):
+    """Attention without any relative position term, forward only, outside autograd: qkv (B, L, 3, H, 64) bf16 ->
+    (out (B, L, H*64) bf16, lse (B, H, L) fp32).  For callers that sequence their own backward (cream_amd.tinyclip.native)."""
+    B, L, _, H, D = qkv.shape
+    out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    d = _desc(qkv, scale, (None, None, None), out, lse, None)
+    with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, 0, False)):
+        rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cream_irpe_attn_fwd")
+    return out, lse
+
+
+def plain_bwd(dout, qkv, out, lse, scale):
+    """Backward of plain_fwd: -> dqkv (B, L, 3, H, 64) bf16 (two launches)."""
+    B, L, _, H, D = qkv.shape
+    dqkv = torch.empty((B, L, 3, H, D), dtype=qkv.dtype, device=qkv.device)
+    d = _desc(qkv, scale, (None, None, None), out, lse, None)
+    dout = dout.contiguous()
+    d.dout = dout.data_ptr()
+    es = dqkv.element_size()
+    sb, sn, s3, sh, _ = dqkv.stride()
+    d.dq, d.dk, d.dv = dqkv.data_ptr(), dqkv.data_ptr() + s3 * es, dqkv.data_ptr() + 2 * s3 * es
+    d.dsb, d.dsn, d.dsh = sb, sn, sh
+    delta = torch.empty((B, H, padded_len(L)), dtype=torch.float32, device=qkv.device)
+    d.delta = delta.data_ptr()
+    with torch.cuda.device(qkv.device), timing.region("irpe_attn_bwd", flops=_flops(B, H, L, 0, True)):
+        rc = _lib.load().cream_irpe_attn_bwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cream_irpe_attn_bwd")
+    return dqkv
+
+
 def attention(qkv, scale, rpe_q, rpe_k, rpe_v):
     """qkv (B, L, 3, H, 64) bf16 -> (B, L, H*64)."""
     assert qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] == 64 and qkv.stride(4) == 1

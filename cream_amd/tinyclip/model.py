@@ -22,7 +22,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .. import irpe_fused
+
+NATIVE_TOWERS = os.environ.get('CREAM_TINYCLIP_NATIVE', '1') != '0'     # image towers on cream_amd.tinyclip.native
 
 
 class LayerNorm(nn.LayerNorm):
@@ -99,6 +103,10 @@ class Transformer(nn.Module):
         self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio, act_layer) for _ in range(layers)])
 
     def forward(self, x, attn_mask=None):
+        if x.is_cuda and NATIVE_TOWERS:
+            from . import native
+            if native.supported(self, x, attn_mask):       # bf16 autocast, heads of 64, no mask: the own kernels end to end
+                return native.tower(self, x)
         for blk in self.resblocks:
             x = blk(x, attn_mask)
         return x

@@ -1,0 +1,188 @@
+"""TinyCLIP image towers on the framework's own kernels — the run of `ResidualAttentionBlock`s
+(TinyCLIP/src/open_clip/model.py:208-315, `Transformer` :342-427) of a ViT tower as ONE autograd node under bf16 autocast:
+
+    x1 = x  + out_proj(attn(ln_1(x)))          attn = plain multi-head attention, heads of 64 (no mask)
+    x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
+
+on the kernels the AutoFormer block uses (cream_amd.autoformer.block wrappers over the C ABI): LayerNorm passes with the
+residual add of the previous branch folded in (csrc/block_ops.hip), the own MFMA GEMMs with bias / erf-GELU / GELU'
+epilogues on bf16 operand copies of the weights (csrc/gemm_mfma.hpp), the fused flash-style attention of csrc/irpe_attn.hip
+without any relative position term, split-K weight gradients on a side stream whose partials cream_grad_finalize adds
+straight into `.grad`.  Round 2 ran the towers' projections, LayerNorms and GELUs through the framework (46 of 85 ms of the
+distillation step in a vendor GEMM library, ~20 ms in separate elementwise launches).
+
+fp32 residual stream inside the node (the reference's autocast keeps its stream in the 16-bit dtype; ours is the more
+accurate of the two), bf16 GEMM operands, output cast back to the caller's dtype.  The text tower (77 tokens, causal mask,
+< 1 % of the step's FLOPs) and every fp32 / CPU / masked call keep the composed module path.
+"""
+import torch
+
+from .. import irpe_fused
+from ..autoformer import block as K
+
+_OPS_KEY = '_cream_tc_operands'
+
+
+class BlockOperands:
+    """bf16 operand copies of one ResidualAttentionBlock: W (out, in) and W^T (in, out) of in_proj ([q; k; v] rows, as
+    nn.MultiheadAttention packs them), out_proj, c_fc, c_proj, and the biases — written by cream_adamw_step's copy mode in one
+    launch; stale after any optimizer step (block._register's global post-step hook) or version change."""
+
+    def __init__(self, blk):
+        at, mlp = blk.attn, blk.mlp
+        self.params = [(at.in_proj_weight, at.in_proj_bias), (at.out_proj.weight, at.out_proj.bias),
+                       (mlp.c_fc.weight, mlp.c_fc.bias), (mlp.c_proj.weight, mlp.c_proj.bias)]
+        dev = at.in_proj_weight.device
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self.w = [torch.empty(tuple(w.shape), **bf) for w, _ in self.params]
+        self.wt = [torch.empty((w.shape[1], w.shape[0]), **bf) for w, _ in self.params]
+        self.b = [torch.empty(tuple(b.shape), **bf) for _, b in self.params]
+        self.key = self._key()
+        self.versions = None
+        self._table = None
+        K._register(self)
+
+    def _key(self):
+        return tuple(w.data_ptr() for w, _ in self.params)
+
+    def _versions(self):
+        return tuple(p._version for pair in self.params for p in pair)
+
+    def refresh(self):
+        if self._table is None:
+            jobs = []
+            for (w, b), mw, mwt, mb in zip(self.params, self.w, self.wt, self.b):
+                jobs.append(K.param_job(w.detach(), mir=mw, mir_t=mwt))
+                jobs.append(K.param_job(b.detach(), mir=mb))
+            self._table = K.JobTable(jobs, self.w[0].device)
+        self._table.launch(update=False)
+        self.versions = self._versions()
+
+    def stale(self):
+        return self.versions != self._versions()
+
+
+def operands(blk):
+    ops = blk.__dict__.get(_OPS_KEY)
+    if ops is None or ops.key != ops._key():
+        ops = blk.__dict__[_OPS_KEY] = BlockOperands(blk)
+    if ops.stale():
+        ops.refresh()
+    return ops
+
+
+def supported(transformer, x, attn_mask):
+    blk = transformer.resblocks[0] if len(transformer.resblocks) else None
+    return (blk is not None and attn_mask is None and x.is_cuda and x.dim() == 3
+            and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and transformer.head_dim == 64 and transformer.width % 8 == 0 and x.shape[1] <= 2048
+            and isinstance(blk.mlp.gelu, torch.nn.GELU) and getattr(blk.mlp.gelu, 'approximate', 'none') == 'none'
+            and isinstance(blk.ln_attn, torch.nn.Identity) and blk.attn.in_proj_weight.dtype == torch.float32
+            and blk.mlp.c_fc.weight.shape[0] % 8 == 0)
+
+
+def _block_forward(blk, ops, x, pend, B, L, keep):
+    """x (M, D) fp32 stream (or, with pend = previous branch output f, the stream before that add).  -> (x1, f, saved)"""
+    M, D = x.shape
+    H = blk.attn.num_heads
+    F_ = blk.mlp.c_fc.weight.shape[0]
+    (wqkv, wo, w1, w2), (bqkv, bo, b1, b2) = ops.w, ops.b
+    ln1, ln2 = blk.ln_1, blk.ln_2
+    if pend is None:
+        xin = x
+        a, mean1, rstd1 = K.ln_fwd(x, ln1.weight, ln1.bias, ln1.eps)
+    else:
+        xin, a, mean1, rstd1 = K.add_ln_fwd(x, pend, None, L, ln1.weight, ln1.bias, ln1.eps)
+    qkv = K.linear_fwd(a, wqkv, bqkv, 3 * D, D)
+    o, lse = irpe_fused.plain_fwd(qkv.view(B, L, 3, H, 64), 0.125)
+    p = K.linear_fwd(o.view(M, D), wo, bo, D, D)
+    x1, c, mean2, rstd2 = K.add_ln_fwd(xin, p, None, L, ln2.weight, ln2.bias, ln2.eps)
+    gp, g = K.linear_gelu_fwd(c, w1, b1, F_, D)
+    f = K.linear_fwd(g, w2, b2, D, F_)
+    saved = (xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g) if keep else None
+    return x1, f, saved
+
+
+def _block_backward(blk, ops, saved, dx2, df, pb2, B, L, want_prev):
+    """dx2 (M, D) fp32 gradient of the block's output stream, df (M, D) bf16 = gradient of the c_proj output with its
+    per-slab column sums pb2 = (tensor, nparts, pstride, offset).  -> (dx, df_prev, pb2_prev)"""
+    xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g = saved
+    M, D = xin.shape
+    H = blk.attn.num_heads
+    F_ = blk.mlp.c_fc.weight.shape[0]
+    wqkv_t, wo_t, w1_t, w2_t = ops.wt
+    at, mlp, ln1, ln2 = blk.attn, blk.mlp, blk.ln_1, blk.ln_2
+    jobs = K.GradJobs()
+    pw2, _ = K.wgrad_parts_async(df, g)
+    jobs.add(mlp.c_proj.weight, pw2, pw2.shape[0], D * F_, D, F_)
+    jobs.add(mlp.c_proj.bias, pb2[0], pb2[1], pb2[2], 1, D, src_offset=pb2[3])
+    dh, pb1 = K.linear_dgrad_mul(df, w2_t, gp, D, F_)
+    pw1, _ = K.wgrad_parts_async(dh, c)
+    jobs.add(mlp.c_fc.weight, pw1, pw1.shape[0], F_ * D, F_, D)
+    jobs.add(mlp.c_fc.bias, pb1, pb1.shape[0], F_, 1, F_)
+    dc = K.linear_dgrad(dh, w1_t, F_, D)
+    dx1, dp, pl2 = K.ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight, dx2, None, L, True)
+    P = pl2.shape[0]
+    jobs.add(ln2.weight, pl2, P, 3 * D, 1, D)
+    jobs.add(ln2.bias, pl2, P, 3 * D, 1, D, src_offset=D)
+    jobs.add(at.out_proj.bias, pl2, P, 3 * D, 1, D, src_offset=2 * D)
+    pwp, _ = K.wgrad_parts_async(dp, o.view(M, D))
+    jobs.add(at.out_proj.weight, pwp, pwp.shape[0], D * D, D, D)
+    do = K.linear_dgrad(dp, wo_t, D, D)
+    dqkv = irpe_fused.plain_bwd(do.view(B, L, D), qkv.view(B, L, 3, H, 64), o, lse, 0.125)
+    dqkv2d = dqkv.view(M, 3 * D)
+    pwq, pbq = K.wgrad_parts_async(dqkv2d, a, want_bias=True)
+    jobs.add(at.in_proj_weight, pwq, pwq.shape[0], 3 * D * D, 3 * D, D)
+    jobs.add(at.in_proj_bias, pbq, pbq.shape[0], 3 * D, 1, 3 * D)
+    da = K.linear_dgrad(dqkv2d, wqkv_t, 3 * D, D)
+    dx, df_prev, pl1 = K.ln_bwd_raw(da, xin, mean1, rstd1, ln1.weight, dx1, None, L, want_prev)
+    jobs.add(ln1.weight, pl1, P, 3 * D, 1, D)
+    jobs.add(ln1.bias, pl1, P, 3 * D, 1, D, src_offset=D)
+    K.finalize_on_side_stream(jobs, blk, [df, g, pw2, pb2[0], dh, c, pw1, pb1, pl2, dp, o, pwp, dqkv, a, pwq, pbq, pl1])
+    return dx, df_prev, (pl1, P, 3 * D, 2 * D)
+
+
+class TowerStack(torch.autograd.Function):
+    """x (B, L, D) any float dtype -> (B, L, D) same dtype: all blocks of a tower."""
+
+    @staticmethod
+    def forward(ctx, x, transformer, *params):
+        B, L, D = x.shape
+        M = B * L
+        blks = list(transformer.resblocks)
+        keep = any(ctx.needs_input_grad)            # (False under no_grad: the frozen teacher saves nothing)
+        cur = x.reshape(M, D).float().contiguous()
+        pend = None
+        saved = []
+        for blk in blks:
+            x1, f, sv = _block_forward(blk, operands(blk), cur, pend, B, L, keep)
+            if keep:
+                saved.extend(sv)
+            cur, pend = x1, f
+        out = K.residual_add(cur, pend, None, L * D)
+        ctx.blks, ctx.dims, ctx.nsaved = blks, (B, L, D), (len(saved) // len(blks) if keep else 0)
+        ctx.in_dtype = x.dtype
+        if keep:
+            ctx.save_for_backward(*saved)
+        return out.view(B, L, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        blks, (B, L, D), ns = ctx.blks, ctx.dims, ctx.nsaved
+        tens = ctx.saved_tensors
+        M = B * L
+        dx = dout.reshape(M, D).float().contiguous()
+        df, part = K.scale_cast_colsum(dx, None, L)
+        pb2 = (part, part.shape[0], D, 0)
+        for i in range(len(blks) - 1, -1, -1):
+            blk = blks[i]
+            dx, df, pb2 = _block_backward(blk, operands(blk), tens[i * ns:(i + 1) * ns], dx, df, pb2, B, L, i > 0)
+        K.join_side_stream(dx.device)
+        return (dx.view(B, L, D).to(ctx.in_dtype), None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def tower(transformer, x):
+    """Run `transformer.resblocks` natively.  The parameters are passed to the node only so that autograd schedules its
+    backward (they receive their gradients in place, announced through block.on_grads_ready)."""
+    params = [p for p in transformer.parameters()]
+    return TowerStack.apply(x, transformer, *params)

@@ -115,6 +115,59 @@ def test_image_tower_takes_the_fused_attention_under_autocast():
     print(f"[tinyclip gpu bf16 {tag}] worst {worst:.2e}")
 
 
+@pytest.mark.gpu
+def test_native_tower_matches_the_module_path():
+    """cream_amd.tinyclip.native (the run of ResidualAttentionBlocks of an image tower as one autograd node on the own GEMM /
+    LayerNorm / attention kernels, weight gradients added in place from the side stream) against the module-by-module path of
+    the same Transformer under the same bf16 autocast, and both against the fp32 module path: output, input gradient and every
+    parameter gradient.  The frozen-teacher use (no_grad) must give the same output and save nothing."""
+    import cream_amd.tinyclip.model as M
+    from cream_amd import timing
+    from cream_amd.tinyclip import native
+    torch.manual_seed(5)
+    tr = M.Transformer(width=256, layers=3, heads=4).to("cuda:0")
+    with torch.no_grad():
+        for n, p in tr.named_parameters():
+            if n.endswith("bias") or "ln_" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    x0 = torch.randn(6, 197, 256, device="cuda:0")
+    gy = torch.randn(6, 197, 256, device="cuda:0")
+
+    def run(native_on, amp):
+        M.NATIVE_TOWERS = native_on
+        tr.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = tr(x.to(torch.bfloat16) if amp else x)
+        y.float().backward(gy)
+        torch.cuda.synchronize()
+        return y.detach().float(), x.grad.clone(), {k: p.grad.clone() for k, p in tr.named_parameters()}
+
+    try:
+        ref = run(False, False)
+        timing.reset(); timing.enable(True)
+        nat = run(True, True)
+        timing.enable(False)
+        assert {"gemm_nt", "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad", "ln_fwd", "ln_bwd", "irpe_attn_fwd", "irpe_attn_bwd"} <= set(timing.summary())
+        mod = run(False, True)
+        assert native.supported(tr, x0.to(torch.bfloat16), None) is False        # (outside autocast)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            M.NATIVE_TOWERS = True
+            y_t = tr(x0.to(torch.bfloat16)).float()
+    finally:
+        M.NATIVE_TOWERS = True
+        timing.reset()
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+    e_nat = max([rel(nat[0], ref[0]), rel(nat[1], ref[1])] + [rel(nat[2][k], ref[2][k]) for k in ref[2]])
+    e_mod = max([rel(mod[0], ref[0]), rel(mod[1], ref[1])] + [rel(mod[2][k], ref[2][k]) for k in ref[2]])
+    print(f"[tinyclip tower 3 x 256] native bf16 vs fp32 modules {e_nat:.2e}; framework bf16 autocast vs fp32 modules {e_mod:.2e}")
+    assert e_nat < 3e-2, e_nat                        # bf16 operands; the fp32 residual stream makes it no worse than the framework's
+    assert e_nat < 1.5 * e_mod + 5e-3
+    assert rel(y_t, nat[0]) < 1e-6                    # same kernels, nothing saved
+
+
 # ---- the distillation step across two ranks (gloo) == the same step on the global batch in one process ------------
 def _tiny_pair():
     from cream_amd.tinyclip.model import CLIP

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do
-CREAM_TN_LATE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TN late (pairs)', d['value'], d['ms_per_step'])"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TN early (round-2 order)', d['value'], d['ms_per_step'])"
-done
+timeout 900 python -m pytest tests/test_tinyclip_model.py -m gpu -x -q -s 2>&1 | grep -E "^\.*\[|passed|failed|Error|assert" | tail -8
