@@ -139,7 +139,8 @@ class IrpeAttnDesc(ctypes.Structure):
                 [(n, _vp) for n in ("idq", "idk", "idv", "idq_t", "idk_t", "idv_t")] +
                 [(n, _c.c_int32) for n in ("B", "H", "L", "NP", "nb")] + [("scale", _f)] +
                 [(n, _vp) for n in ("dout", "dq", "dk", "dv")] + [(n, _i64) for n in ("dsb", "dsn", "dsh")] +
-                [(n, _vp) for n in ("delta", "lkg", "gg", "dlk", "dlq", "bq", "bk")] + [(n, _i64) for n in ("bq_hs", "bk_hs")])
+                [(n, _vp) for n in ("delta", "lkg", "gg", "dlk", "dlq", "bq", "bk")] + [(n, _i64) for n in ("bq_hs", "bk_hs")] +
+                [("causal", _c.c_int32), ("reserved", _c.c_int32)])
 
 
 class ParamJob(ctypes.Structure):

@@ -73,6 +73,7 @@ struct Args {
     const uint8_t *idq_t, *idk_t, *idv_t;   // (NP, NP) key-major:    [j][i] of the same
     int B, H, L, NP, nb;
     float scale;
+    int causal;                       // key j takes part for query i only if j <= i (text towers); 0: full attention
     // backward
     const short* dout;                // (B, L, H, 64)
     short *dq, *dk, *dv;
@@ -434,6 +435,11 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                     for (int r = 0; r < 16; ++r)
                         if (t * 32 + acc_row(r, g) >= a.L) s[r] = -INFINITY;
                 }
+                if (a.causal && t * 32 + 31 > q0 + wave * 32) {      // (wave-uniform: tiles at or beyond the diagonal; key 0 is always visible)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * 32 + acc_row(r, g) > qi) s[r] = -INFINITY;
+                }
                 float t4[4] = {s[0], s[1], s[2], s[3]};
 #pragma unroll
                 for (int r = 4; r < 16; ++r) t4[r & 3] = fmaxf(t4[r & 3], s[r]);
@@ -655,7 +661,8 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = t < NT - 1 || t * 32 + acc_row(r, g) < a.L;
+                const int key = t * 32 + acc_row(r, g);
+                const bool ok = (t < NT - 1 || key < a.L) && !(a.causal && key > qi);
                 const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -lseL)) : 0.f;
                 s[r] = p * (dp[r] - delta);
             }
@@ -836,7 +843,8 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rr + e;
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ls[e]));
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ls[e]));
+                    if (a.causal && t * 32 + acc_row(r, g) < kj) p = 0.f;          // query before this lane's key
                     s[r] = p;
                     ds[r] = p * (dp[r] - dl[e]);
                 }
@@ -1000,7 +1008,7 @@ Args to_args(const cream_irpe_attn_desc* d) {
     a.bq = d->bq; a.bk = d->bk; a.bq_hs = d->bq_hs; a.bk_hs = d->bk_hs;
     a.idq = d->idq; a.idk = d->idk; a.idv = d->idv;
     a.idq_t = d->idq_t; a.idk_t = d->idk_t; a.idv_t = d->idv_t;
-    a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale;
+    a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale; a.causal = d->causal;
     a.dout = (const short*)d->dout;
     a.dq = (short*)d->dq; a.dk = (short*)d->dk; a.dv = (short*)d->dv;
     a.dsb = d->dsb; a.dsn = d->dsn; a.dsh = d->dsh;

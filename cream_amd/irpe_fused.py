@@ -205,24 +205,26 @@ class _Fused(torch.autograd.Function):
         return dqkv, None, res[0], res[1], res[2], None
 
 
-def plain_fwd(qkv, scale):
+def plain_fwd(qkv, scale, causal=False):
     """Attention without any relative position term, forward only, outside autograd: qkv (B, L, 3, H, 64) bf16 ->
     (out (B, L, H*64) bf16, lse (B, H, L) fp32).  For callers that sequence their own backward (cream_amd.tinyclip.native)."""
     B, L, _, H, D = qkv.shape
     out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
     d = _desc(qkv, scale, (None, None, None), out, lse, None)
+    d.causal = 1 if causal else 0
     with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, 0, False)):
         rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "cream_irpe_attn_fwd")
     return out, lse
 
 
-def plain_bwd(dout, qkv, out, lse, scale):
+def plain_bwd(dout, qkv, out, lse, scale, causal=False):
     """Backward of plain_fwd: -> dqkv (B, L, 3, H, 64) bf16 (two launches)."""
     B, L, _, H, D = qkv.shape
     dqkv = torch.empty((B, L, 3, H, D), dtype=qkv.dtype, device=qkv.device)
     d = _desc(qkv, scale, (None, None, None), out, lse, None)
+    d.causal = 1 if causal else 0
     dout = dout.contiguous()
     d.dout = dout.data_ptr()
     es = dqkv.element_size()

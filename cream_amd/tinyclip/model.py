@@ -9,8 +9,9 @@ Same constructor configuration (the JSON files of open_clip/model_configs), para
 What is different is the execution: the towers run batch-first (the reference permutes to sequence-first for
 `nn.MultiheadAttention` and back), and the attention core of a block whose heads are 64 wide runs — under bf16 autocast
 on the device — on the fused flash-style kernels of csrc/irpe_attn.hip (`irpe_fused.attention` without any relative
-position term: nothing of size L^2 reaches HBM, forward one launch, backward two).  The text tower's causal attention
-(77 tokens, < 1 % of the step's FLOPs) and every fp32 / CPU call use the composed form with the reference's additive mask.
+position term: nothing of size L^2 reaches HBM, forward one launch, backward two).  Under bf16 autocast on the device the
+whole run of blocks of a tower — image AND text (causal mask inside the attention kernels) — is one autograd node on the
+own GEMM / LayerNorm / attention kernels (cream_amd.tinyclip.native); every fp32 / CPU call uses the composed form.
 
 Not mirrored (outside the affinity-mimicking step of BASELINE config 5): the learnable pruning masks (`l0module.py`,
 `hidden_z` / `heads_z` / ... arguments and `prune()`), the ResNet / timm image towers, gradient checkpointing.
@@ -102,11 +103,12 @@ class Transformer(nn.Module):
         self.width, self.layers, self.num_heads, self.head_dim, self.mlp_ratio = width, layers, heads, width // heads, mlp_ratio
         self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio, act_layer) for _ in range(layers)])
 
-    def forward(self, x, attn_mask=None):
+    def forward(self, x, attn_mask=None, causal=False):
+        """`causal=True`: the caller states that attn_mask is the upper-triangular -inf mask (the text tower's buffer)."""
         if x.is_cuda and NATIVE_TOWERS:
             from . import native
-            if native.supported(self, x, attn_mask):       # bf16 autocast, heads of 64, no mask: the own kernels end to end
-                return native.tower(self, x)
+            if native.supported(self, x, attn_mask, causal):   # bf16 autocast, heads of 64: the own kernels end to end
+                return native.tower(self, x, causal and attn_mask is not None)
         for blk in self.resblocks:
             x = blk(x, attn_mask)
         return x
@@ -193,7 +195,7 @@ class TextEncoder(nn.Module):
 
     def forward(self, text, normalized=False):                                  # model.py:764-805
         x = self.token_embedding(text) + self.positional_embedding
-        x = self.ln_final(self.transformer(x, attn_mask=self.attn_mask[:x.shape[1], :x.shape[1]]))
+        x = self.ln_final(self.transformer(x, attn_mask=self.attn_mask[:x.shape[1], :x.shape[1]], causal=True))
         x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection   # the eot token
         return F.normalize(x, dim=-1) if normalized else x
 

@@ -12,8 +12,9 @@ straight into `.grad`.  Round 2 ran the towers' projections, LayerNorms and GELU
 distillation step in a vendor GEMM library, ~20 ms in separate elementwise launches).
 
 fp32 residual stream inside the node (the reference's autocast keeps its stream in the 16-bit dtype; ours is the more
-accurate of the two), bf16 GEMM operands, output cast back to the caller's dtype.  The text tower (77 tokens, causal mask,
-< 1 % of the step's FLOPs) and every fp32 / CPU / masked call keep the composed module path.
+accurate of the two), bf16 GEMM operands, output cast back to the caller's dtype.  The text towers run the same node with
+the causal mask applied inside the attention kernels (`causal`: keys j <= i only, model.py:756-762 without an (L, L)
+tensor); every fp32 / CPU call and any other mask keeps the composed module path.
 """
 import torch
 
@@ -71,9 +72,10 @@ def operands(blk):
     return ops
 
 
-def supported(transformer, x, attn_mask):
+def supported(transformer, x, attn_mask, causal=False):
+    """`causal`: the caller vouches that `attn_mask` is the additive upper-triangular -inf mask (TextEncoder's buffer)."""
     blk = transformer.resblocks[0] if len(transformer.resblocks) else None
-    return (blk is not None and attn_mask is None and x.is_cuda and x.dim() == 3
+    return (blk is not None and (attn_mask is None or causal) and x.is_cuda and x.dim() == 3
             and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and transformer.head_dim == 64 and transformer.width % 8 == 0 and x.shape[1] <= 2048
             and isinstance(blk.mlp.gelu, torch.nn.GELU) and getattr(blk.mlp.gelu, 'approximate', 'none') == 'none'
@@ -81,7 +83,7 @@ def supported(transformer, x, attn_mask):
             and blk.mlp.c_fc.weight.shape[0] % 8 == 0)
 
 
-def _block_forward(blk, ops, x, pend, B, L, keep):
+def _block_forward(blk, ops, x, pend, B, L, keep, causal):
     """x (M, D) fp32 stream (or, with pend = previous branch output f, the stream before that add).  -> (x1, f, saved)"""
     M, D = x.shape
     H = blk.attn.num_heads
@@ -94,7 +96,7 @@ def _block_forward(blk, ops, x, pend, B, L, keep):
     else:
         xin, a, mean1, rstd1 = K.add_ln_fwd(x, pend, None, L, ln1.weight, ln1.bias, ln1.eps)
     qkv = K.linear_fwd(a, wqkv, bqkv, 3 * D, D)
-    o, lse = irpe_fused.plain_fwd(qkv.view(B, L, 3, H, 64), 0.125)
+    o, lse = irpe_fused.plain_fwd(qkv.view(B, L, 3, H, 64), 0.125, causal)
     p = K.linear_fwd(o.view(M, D), wo, bo, D, D)
     x1, c, mean2, rstd2 = K.add_ln_fwd(xin, p, None, L, ln2.weight, ln2.bias, ln2.eps)
     gp, g = K.linear_gelu_fwd(c, w1, b1, F_, D)
@@ -103,7 +105,7 @@ def _block_forward(blk, ops, x, pend, B, L, keep):
     return x1, f, saved
 
 
-def _block_backward(blk, ops, saved, dx2, df, pb2, B, L, want_prev):
+def _block_backward(blk, ops, saved, dx2, df, pb2, B, L, want_prev, causal):
     """dx2 (M, D) fp32 gradient of the block's output stream, df (M, D) bf16 = gradient of the c_proj output with its
     per-slab column sums pb2 = (tensor, nparts, pstride, offset).  -> (dx, df_prev, pb2_prev)"""
     xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g = saved
@@ -129,7 +131,7 @@ def _block_backward(blk, ops, saved, dx2, df, pb2, B, L, want_prev):
     pwp, _ = K.wgrad_parts_async(dp, o.view(M, D))
     jobs.add(at.out_proj.weight, pwp, pwp.shape[0], D * D, D, D)
     do = K.linear_dgrad(dp, wo_t, D, D)
-    dqkv = irpe_fused.plain_bwd(do.view(B, L, D), qkv.view(B, L, 3, H, 64), o, lse, 0.125)
+    dqkv = irpe_fused.plain_bwd(do.view(B, L, D), qkv.view(B, L, 3, H, 64), o, lse, 0.125, causal)
     dqkv2d = dqkv.view(M, 3 * D)
     pwq, pbq = K.wgrad_parts_async(dqkv2d, a, want_bias=True)
     jobs.add(at.in_proj_weight, pwq, pwq.shape[0], 3 * D * D, 3 * D, D)
@@ -146,7 +148,7 @@ class TowerStack(torch.autograd.Function):
     """x (B, L, D) any float dtype -> (B, L, D) same dtype: all blocks of a tower."""
 
     @staticmethod
-    def forward(ctx, x, transformer, *params):
+    def forward(ctx, x, transformer, causal, *params):
         B, L, D = x.shape
         M = B * L
         blks = list(transformer.resblocks)
@@ -155,13 +157,13 @@ class TowerStack(torch.autograd.Function):
         pend = None
         saved = []
         for blk in blks:
-            x1, f, sv = _block_forward(blk, operands(blk), cur, pend, B, L, keep)
+            x1, f, sv = _block_forward(blk, operands(blk), cur, pend, B, L, keep, causal)
             if keep:
                 saved.extend(sv)
             cur, pend = x1, f
         out = K.residual_add(cur, pend, None, L * D)
         ctx.blks, ctx.dims, ctx.nsaved = blks, (B, L, D), (len(saved) // len(blks) if keep else 0)
-        ctx.in_dtype = x.dtype
+        ctx.in_dtype, ctx.causal = x.dtype, causal
         if keep:
             ctx.save_for_backward(*saved)
         return out.view(B, L, D).to(x.dtype)
@@ -176,13 +178,13 @@ class TowerStack(torch.autograd.Function):
         pb2 = (part, part.shape[0], D, 0)
         for i in range(len(blks) - 1, -1, -1):
             blk = blks[i]
-            dx, df, pb2 = _block_backward(blk, operands(blk), tens[i * ns:(i + 1) * ns], dx, df, pb2, B, L, i > 0)
+            dx, df, pb2 = _block_backward(blk, operands(blk), tens[i * ns:(i + 1) * ns], dx, df, pb2, B, L, i > 0, ctx.causal)
         K.join_side_stream(dx.device)
-        return (dx.view(B, L, D).to(ctx.in_dtype), None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx.view(B, L, D).to(ctx.in_dtype), None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
-def tower(transformer, x):
+def tower(transformer, x, causal=False):
     """Run `transformer.resblocks` natively.  The parameters are passed to the node only so that autograd schedules its
     backward (they receive their gradients in place, announced through block.on_grads_ready)."""
     params = [p for p in transformer.parameters()]
-    return TowerStack.apply(x, transformer, *params)
+    return TowerStack.apply(x, transformer, bool(causal), *params)

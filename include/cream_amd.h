@@ -201,6 +201,9 @@ typedef struct cream_irpe_attn_desc {
      * table here INSTEAD of wq / wk; its gradient is the sum of the dlq / dlk rows over batch and tokens (caller) */
     const float *bq, *bk;
     int64_t bq_hs, bk_hs;
+    /* causal != 0: key j takes part for query i only if j <= i — the additive upper-triangular -inf mask of the text
+     * towers (TinyCLIP/src/open_clip/model.py:756-762) without an (L, L) tensor; 0: full attention */
+    int32_t causal, reserved;
 } cream_irpe_attn_desc;
 
 int cream_irpe_padded_len(int L);

@@ -191,3 +191,27 @@ def test_fused_irpe_attention_at_config4_matches_restatement(rpe_on):
     for rounded in (True, False):
         for k, v in report[rounded].items():
             assert v < bound[k], (k, v, rounded, report)
+
+
+@pytest.mark.parametrize("L,B,H", [(77, 4, 8), (197, 2, 3), (33, 2, 1)])
+def test_causal_attention_matches_masked_reference(L, B, H):
+    """The `causal` switch of cream_irpe_attn_fwd / _bwd (keys j <= i only — the text towers' additive upper-triangular -inf
+    mask, TinyCLIP/src/open_clip/model.py:756-762, without an (L, L) tensor) against masked softmax attention in fp32 on the
+    same bf16 inputs: output, log-sum-exp, dq / dk / dv."""
+    torch.manual_seed(L)
+    qkv = (0.8 * torch.randn(B, L, 3, H, 64, device=DEV)).to(torch.bfloat16)
+    gy = torch.randn(B, L, H * 64, device=DEV).to(torch.bfloat16)
+    out, lse = irpe_fused.plain_fwd(qkv, 0.125, causal=True)
+    dqkv = irpe_fused.plain_bwd(gy, qkv, out, lse, 0.125, causal=True)
+    x = qkv.float().requires_grad_()
+    q, k, v = x.permute(2, 0, 3, 1, 4).unbind(0)
+    a = (q * 0.125) @ k.transpose(-2, -1) + torch.full((L, L), float("-inf"), device=DEV).triu_(1)
+    ref = (a.softmax(-1) @ v).transpose(1, 2).reshape(B, L, H * 64)
+    (rg,) = torch.autograd.grad(ref, x, gy.float())
+    errs = dict(y=max_rel(out.float(), ref), lse=max_rel(lse, torch.logsumexp(a, -1)),
+                **{n: max_rel(g_, r_) for n, g_, r_ in zip(("dq", "dk", "dv"), dqkv.float().unbind(2), rg.unbind(2))})
+    print(f"[causal attention L={L}]", {k_: f"{v_:.2e}" for k_, v_ in errs.items()})
+    assert all(v_ < 1.3e-2 for v_ in errs.values()), errs
+
+
+from cream_amd import irpe_fused  # noqa: E402
