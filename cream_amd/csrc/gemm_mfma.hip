@@ -168,7 +168,7 @@ int cream_linear_wgrad_splits(int M, int N, int K)
     // 512 keeps the kernel itself at its best rate
     constexpr int slots = 512;
     int s = slots / tiles;
-    if (s > 16) s = 16;
+    if (s > 16) s = 16;                                         // (32 for the small proj gradient: 10.64 vs 10.60 ms per step, A/B x3)
     if (s > steps) s = steps;
     return s < 1 ? 1 : s;
 }

@@ -599,20 +599,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
     tn_zero(acc, bacc);
     const TnTile t{p.dY, p.X, p.ldy, p.ldx, p.M, p.N, p.K, n0, k0};
     tn_accumulate<BM, NST, CAN_BIAS>(t, s_lo, s_hi, want_bias, acc, bacc, lds, threadIdx.x);
-    // ---- partial tile: D[n][k], lane = column k (l & 31), registers = rows n -------------------------
-    const int g = lane >> 5, c32 = lane & 31;
-    float* out = p.parts + (int64_t)split * p.N * p.K;
+    // ---- partial tile: the accumulators (lane = column k, registers = rows n) leave through LDS — the stages are idle —
+    //      as [128 n][128 k] fp32, so that the partial is written in 16-byte row chunks (16 stores per thread instead of 64
+    //      4-byte ones: the kernel's epilogue was as long as its 25-36 step main loop, profiles/r03_wgrad_group.md)
+    const int g = lane >> 5, c32 = lane & 31, tid = threadIdx.x;
+    float* ct = reinterpret_cast<float*>(lds);
+    __syncthreads();                                                       // every wave is done reading the stages
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int k = k0 + wk * 64 + b * 32 + c32;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 64 + a * 32 + acc_row(r, g);
-                if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[a][b][r];
-            }
-        }
+            for (int r = 0; r < 16; ++r) ct[(wn * 64 + a * 32 + acc_row(r, g)) * BT + wk * 64 + b * 32 + c32] = acc[a][b][r];
     if (want_bias && wk == 0 && c32 == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -621,6 +619,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
                 const int n = n0 + wn * 64 + a * 32 + acc_row(r, g);
                 if (n < p.N) p.bias_parts[(int64_t)split * p.N + n] = bacc[a][r];
             }
+    }
+    __syncthreads();
+    float* out = p.parts + (int64_t)split * p.N * p.K;
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+    if (k0 + c4 < p.K) {                                                   // K % 8 == 0: a 4-chunk is all in or all out
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + r0 + 8 * i;
+            if (n < p.N)
+                *reinterpret_cast<f32x4v*>(out + (int64_t)n * p.K + k0 + c4) = *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4);
+        }
     }
 }
 

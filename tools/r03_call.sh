@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python tools/bench_tinyclip.py 2>&1 | tail -1 | cut -c1-200
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_tc_prof -o tc -- python $GRAFT_REPO_ROOT/tools/bench_tinyclip.py > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/r03_tc_prof.err
-cd $GRAFT_REPO_ROOT
-python tools/summarize_rocprof.py $(find gpurun_out/r03_tc_prof -name '*kernel_stats.csv' | head -1) | head -34
-find gpurun_out/r03_tc_prof -name '*kernel_trace.csv' -delete; find gpurun_out -name '*.db' -delete
+for rep in 1 2 3; do for C in 16 32; do
+CREAM_WGRAD_SCAP=$C python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cap $C', d['value'], d['ms_per_step'])"
+done; done
