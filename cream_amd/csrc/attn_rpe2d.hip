@@ -693,6 +693,191 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     }   // items
 }
 
+// ---------------------------------------------------------------------------------------
+// forward, AutoFormer geometry (N = 197, 14 x 14 grid, bf16) with K and V WHOLE in LDS
+// ---------------------------------------------------------------------------------------
+// The tile-streamed kernel above passes 15 barriers per (b, h) item with 6 MFMAs per wave between two of them: half of a
+// wave's cycles were parked at barriers / s_waitcnt.  One item's K and V are only 25 KB each, so here
+// they are committed to LDS in ONE piece: 4 barriers per item, and between them every wave runs its whole row block —
+// 42 score MFMAs, the exact softmax in registers, 42 P.V / slot-sum MFMAs — without meeting anybody.
+// LDS (147.7 KB, one workgroup per CU):  [K 224 x 72] [pad] [V 224 x 72] | tables | masks | one-hot operands.
+// The per-wave fp32 shift scratch (7 x 9 KB) is never live together with both matrices: the lookup / slot-extension
+// scratch of the prologue lies over [pad | V] (V is committed after the scores), the slot -> bucket scratch of the
+// epilogue over [K | pad] (K is dead after the scores).  The next matrix is always in flight in registers: V during
+// the scores, the next item's K during P.V.
+constexpr int W14_NP = 224, W14_KP = 72, W14_THREADS = 448;
+constexpr int W14_MAT = W14_NP * W14_KP * 2;                                    // one matrix in LDS (bytes)
+constexpr int W14_SCR = 7 * 32 * LP * 4;                                        // shift scratch of the 7 waves
+constexpr int W14_PAD = W14_SCR - W14_MAT;
+static_assert(W14_PAD > 0 && W14_PAD % 16 == 0, "scratch = matrix + pad");
+constexpr size_t fwd14_lds_bytes() {
+    return (size_t)2 * W14_MAT + W14_PAD + (size_t)128 * table_pitch<hip_bfloat16>() * 2 + (size_t)W14_NP * 4 + onehot_bytes(W14_NP);
+}
+
+struct MatRegs { u32x4v v[4]; };                                                // 224 x 64 bf16 = 1792 chunks of 16 B / 448 threads
+__device__ __forceinline__ void mat_load(MatRegs& r, const short* src, int64_t rs, int nrows) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * W14_THREADS, row = c >> 3, cc = c & 7;
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (int64_t)min(row, nrows - 1) * rs + cc * 8);
+        r.v[i] = row < nrows ? v : u32x4v{0, 0, 0, 0};
+    }
+}
+__device__ __forceinline__ void mat_store(const MatRegs& r, short* dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * W14_THREADS, row = c >> 3, cc = c & 7;
+        *reinterpret_cast<u32x4v*>(dst + row * W14_KP + cc * 8) = r.v[i];
+    }
+}
+
+__global__ __launch_bounds__(W14_THREADS) void attn_rpe2d_fwd14_kernel(const FwdArgs a) {
+    using T = hip_bfloat16;
+    using TT = Tr<T>;
+    using F = TT::frag;
+    constexpr int NT = 7, N = 197, NP = W14_NP, kp = W14_KP, tp = table_pitch<T>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short* kbuf = reinterpret_cast<short*>(smem);
+    short* vbuf = reinterpret_cast<short*>(smem + W14_MAT + W14_PAD);
+    float* scrA = reinterpret_cast<float*>(smem + W14_MAT);                     // [pad | V]: lookups -> slot extension
+    float* scrB = reinterpret_cast<float*>(smem);                               // [K | pad]: slot sums -> bucket sums
+    short* tvt = reinterpret_cast<short*>(smem + 2 * W14_MAT + W14_PAD);        // value tables^T [64][tp]
+    short* tkr = tvt + 64 * tp;                                                 // key table rows [64][tp]
+    uint32_t* masks = reinterpret_cast<uint32_t*>(tkr + 64 * tp);
+    short* ohr = reinterpret_cast<short*>(masks + NP);
+    short* oht = ohr + NP * OHP;
+    constexpr int otp = oht_pitch(NP);
+    const RelGeom G{N, G14, G14, G14};
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int qi = wave * 32 + c32;
+    const bool qok = qi < N;
+    const int qr = qi > 0 ? (qi - 1) / G14 : 0, qc = qi > 0 ? (qi - 1) - qr * G14 : 0;
+
+    // ---- once per (persistent) workgroup: tables, key slot masks, one-hot operands ----------------------------
+    {
+        TabRegs rv, rk;
+        tab_load(rv, a.tvv, a.tvh, a.ldt, a.nb);
+        tab_load(rk, a.tkv, a.tkh, a.ldt, a.nb);
+        tab_store_T<T>(rv, tvt);
+        tab_store_R<T>(rk, tkr);
+    }
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) masks[j] = key_mask(j, G);
+    __syncthreads();
+    fill_onehot(ohr, oht, masks, NP);
+
+    MatRegs mr;
+    int item = blockIdx.x;
+    if (item < a.nitems) {
+        const int b = item / a.H, h = item - b * a.H;
+        mat_load(mr, reinterpret_cast<const short*>(a.k) + (int64_t)b * a.sb + (int64_t)h * a.sh, a.sn, N);
+    }
+    for (; item < a.nitems; item += gridDim.x) {
+        const int b = item / a.H, h = item - b * a.H;
+        const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+        const short* qp = reinterpret_cast<const short*>(a.q) + base;
+        const short* vpg = reinterpret_cast<const short*>(a.v) + base;
+        PROF_DECL
+        PROF_MARK();
+        F qb[4];
+        load_row<T>(qb, qp + (int64_t)min(qi, N - 1) * a.sn, g);
+        __syncthreads();                               // previous item: P.V reads of V and the [K | pad] scratch are over
+        mat_store(mr, kbuf);
+        mat_load(mr, vpg, a.sn, N);                    // V travels during the scores
+        __syncthreads();
+        PROF_MARK();
+
+        // ---- this wave's query tile: bucket lookups -> slot extension (scratch over [pad | V]) -----------------
+        float* scr = scrA + wave * 32 * LP;
+        if (!qok) zero_frags<T, 4>(qb);
+        F qe[2];
+        table_lookups<T>(scr, qb, tkr, a.tkv, a.tkh, a.ldt, a.nb, lane);
+        wave_lds_fence();
+        build_ext14(qe, scr, lane, wave == 0, qr, qc);
+        PROF_MARK();
+
+        // ---- S^T: all keys against this wave's 32 queries, no barrier in between ------------------------------
+        f32x16 s[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t] = f32x16{};
+            const short* kb = kbuf + t * 32 * kp;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s[t] = TT::mma(TT::load(kb + c32 * kp + ks * 16 + g * 8), qb[ks], s[t]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[t] = TT::mma(TT::load(ohr + (t * 32 + c32) * OHP + ks * 16 + g * 8), qe[ks], s[t]);
+        }
+        PROF_MARK();
+        // ---- softmax over keys (in-lane + one exchange with the partner lane); keys >= N only in the last tile ---
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((NT - 1) * 32 + acc_row(r, g) >= N) s[NT - 1][r] = -INFINITY;
+        float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], s[t][r]);
+        float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float sc = a.scale * LOG2E, msc = m * sc;
+        float l4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sc, -msc));
+                s[t][r] = p;
+                l4[r & 3] += p;
+            }
+        float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        l += __shfl_xor(l, 32);
+        const float inv_l = 1.f / l;
+        if (qok && g == 0) a.lse[((int64_t)b * a.H + h) * N + qi] = (msc + log2f(l)) * (1.f / LOG2E);
+
+        PROF_MARK();
+        __syncthreads();                               // everybody is done with K and with the [pad | V] scratch
+        mat_store(mr, vbuf);
+        {
+            const int nxt = item + gridDim.x;          // the next item's K travels during P.V
+            if (nxt < a.nitems) {
+                const int nb_ = nxt / a.H, nh = nxt - nb_ * a.H;
+                mat_load(mr, reinterpret_cast<const short*>(a.k) + (int64_t)nb_ * a.sb + (int64_t)nh * a.sh, a.sn, N);
+            }
+        }
+        __syncthreads();
+
+        PROF_MARK();
+        // ---- [O | slot sums]^T = [V | one-hot]^T . P^T ---------------------------------------------------------
+        f32x16 o[2] = {f32x16{}, f32x16{}};
+        f32x16 ox = {};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const short* vb = vbuf + t * 32 * kp;
+#pragma unroll
+            for (int st2 = 0; st2 < 2; ++st2) {
+                const F pb = TT::from_acc(s[t], st2);
+                o[0] = TT::mma(load_perm_tr(vb, kp, 0, st2, lane), pb, o[0]);
+                o[1] = TT::mma(load_perm_tr(vb, kp, 1, st2, lane), pb, o[1]);
+                ox = TT::mma(TT::load_perm(oht + c32 * otp + t * 32, st2, g), pb, ox);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; ox[r] *= inv_l; }
+
+        PROF_MARK();
+        // ---- value-side relative position term: slot sums -> bucket sums -> . tables (scratch over [K | pad]) ---
+        float bk[32];
+        slots_to_buckets14(bk, scrB + wave * 32 * LP, ox, lane, wave == 0, min(qr, G14 - 1), qc);
+        store_buckets_T<T>(reinterpret_cast<short*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);
+        add_bucket_product<T>(o, tvt, bk, lane);
+        PROF_MARK();
+        if (qok) store_rows_64<T>(reinterpret_cast<short*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64, o, g);
+        PROF_MARK();
+        PROF_FLUSH();
+    }
+}
+
 // one persistent workgroup per CU (the forward's LDS footprint allows exactly one)
 int fwd_persistent_grid() {
     static int cus = 0;
@@ -726,13 +911,30 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rpe2d_fwd14_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    FwdArgs aa = a;
+    aa.nitems = B * a.H;
+    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    hipLaunchKernelGGL(attn_rpe2d_fwd14_kernel, dim3(grid), dim3(W14_THREADS), fwd14_lds_bytes(), st, aa);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 template <typename T>
 int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     const int nt = a.NP / 32;
     if (nt <= 2) return launch_fwd_nt<T, 2>(a, B, st);
     if (nt <= 4) return launch_fwd_nt<T, 4>(a, B, st);
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
-        if (fast_geometry(a.G)) return launch_fwd_nt<T, 7, true>(a, B, st);
+        // (the tile-streamed kernel's own FAST instantiation, launch_fwd_nt<T, 7, true>: 46.5 us against 40.6 us at B = 128, H = 6;
+        //  10.56 vs 10.48 ms per step in a same-box A/B x3)
+        if (fast_geometry(a.G)) return launch_fwd14(a, B, st);
     }
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);

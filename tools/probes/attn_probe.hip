@@ -36,14 +36,16 @@ int main(int argc, char** argv) {
     }
     std::vector<long long> hp((size_t)B * H * 8 * 12);
     hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost);
-    const char* names[] = {"prologue+sync", "lookups+ext", "S tiles (K stream)", "softmax", "PV (V stream)", "buckets+mma", "store O"};
-    double sum[7] = {0}; double tot = 0; int cnt = 0;
-    for (int blk = 0; blk < B * H; ++blk) for (int w = 0; w < 7; ++w) {
+    // (whole-K/V forward of the AutoFormer geometry: the stamps of each persistent workgroup's LAST item)
+    const char* names[] = {"q load+K commit+2 sync", "lookups+ext", "scores (42 mfma)", "softmax", "sync+V commit+sync", "PV (42 mfma)", "buckets+mma", "store O"};
+    double sum[8] = {0}; double tot = 0; int cnt = 0;
+    for (int blk = 0; blk < 256; ++blk) for (int w = 0; w < 7; ++w) {
         long long* d = &hp[((size_t)blk * 8 + w) * 12];
-        for (int i = 0; i < 7; ++i) sum[i] += (double)(d[i + 1] - d[i]);
-        tot += (double)(d[7] - d[0]); ++cnt;
+        if (d[8] <= d[0]) continue;
+        for (int i = 0; i < 8; ++i) sum[i] += (double)(d[i + 1] - d[i]);
+        tot += (double)(d[8] - d[0]); ++cnt;
     }
-    for (int i = 0; i < 7; ++i) printf("%-20s %10.0f cycles\n", names[i], sum[i] / cnt);
+    for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles\n", names[i], sum[i] / cnt);
     printf("%-12s %10.0f cycles (s_memtime ticks, 100 MHz?)\n", "total", tot / cnt);
     // ---- backward ---------------------------------------------------------------------------
     uint16_t *ddo, *ddqkv, *ddlt, *dqe, *dde; float *ddelta, *ddtab;
