@@ -67,6 +67,9 @@ SIGNATURES = {
     "cream_colsum_slabs": (_i, [_i]),
     "cream_colsum": (_i, [_vp, _vp, _i, _i, _vp]),
     "cream_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
+    "cream_block_fuse_ln": (_i, [_i]),
+    "cream_linear_add_ln_supported": (_i, [_i, _i]),
+    "cream_linear_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
     "cream_colsum128_slabs": (_i, [_i]),
     "cream_colsum128": (_i, [_vp, _vp, _i, _i, _vp]),
     "cream_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -191,6 +194,8 @@ def load():
             raise CreamLibraryError(f"cream_amd: symbol {name} missing from {LIB_PATH}") from e
         fn.restype = res
         fn.argtypes = args
+    # process-wide switches of the native block driver (csrc/block_seq.cpp)
+    lib.cream_block_fuse_ln(int(os.environ.get("CREAM_FUSE_LN", "0") != "0"))
     _lib = lib
     return lib
 

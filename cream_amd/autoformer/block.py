@@ -67,6 +67,25 @@ def add_ln_fwd(x2d, res, sample_scale, rows_per_sample, gamma, beta, eps):
     return x1, y, mean, rstd
 
 
+def linear_add_ln_supported(E, K):
+    return bool(_lib.load().cream_linear_add_ln_supported(int(E), int(K)))
+
+
+def linear_add_ln_fwd(a, w, bias, x2d, sample_scale, rows_per_sample, gamma, beta, eps, K):
+    """x1 = x + s_b * bf16(a . W[:E, :K]^T + bias), y = LN(x1): projection, residual add and the next LayerNorm
+    in ONE kernel (csrc/gemm_ln.hip); the same bits as linear_fwd + add_ln_fwd.  -> (x1, y, mean, rstd)"""
+    M, E = x2d.shape
+    x1 = torch.empty_like(x2d)
+    y = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    with timing.region("gemm_nt_add_ln", flops=2 * M * E * K, nbytes=M * E * (4 + 4 + 2) + M * K * 2):
+        _lib.check(_lib.load().cream_linear_add_ln_fwd(_p(x1), _p(y), _p(mean), _p(rstd), _p(a), _p(w), _p(bias), _p(x2d),
+                                                      _p(sample_scale), rows_per_sample, _p(gamma), _p(beta), M, E, K,
+                                                      w.stride(0), float(eps), _stream()), "cream_linear_add_ln_fwd")
+    return x1, y, mean, rstd
+
+
 def ln_bwd_raw(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
     """-> (dx, dx_scaled or None, partial (P, 3, E): per-slab [dgamma, dbeta, colsum(dx_scaled)])"""
     M, E = x2d.shape

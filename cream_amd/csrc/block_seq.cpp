@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -140,9 +141,11 @@ bool fork(hipStream_t main, hipStream_t side) {
 // streams live, the weight-gradient GEMMs contending with the main chain.  bench.py reads them for the
 // roofline entry.  Off by default (one relaxed load per launch).
 enum ProfKind { K_LN_FWD = 0, K_GEMM_NT, K_GEMM_NT_GELU, K_GEMM_NT_MUL, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD,
-                K_GRAD_FINALIZE, K_COUNT };
+                K_GRAD_FINALIZE, K_GEMM_NT_LN, K_COUNT };
 const char* const kProfNames[K_COUNT] = {"ln_fwd", "gemm_nt", "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad", "attn_rpe2d_fwd",
-                                         "attn_rpe2d_bwd", "ln_bwd", "grad_finalize"};
+                                         "attn_rpe2d_bwd", "ln_bwd", "grad_finalize", "gemm_nt_add_ln"};
+// projection + residual add + LayerNorm as one kernel where the shapes allow (cream_block_fuse_ln)
+std::atomic<int> g_fuse_ln{0};
 struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
 bool g_prof_on = false;
 std::mutex g_prof_mu;
@@ -222,10 +225,17 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
                              d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
                              CREAM_BF16, stream));
-    PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
-    // x1 = x + s1 * p ; c = LN2(x1)
-    PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
-                         at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
+    if (g_fuse_ln.load(std::memory_order_relaxed) && cream_linear_add_ln_supported(E, Q)) {
+        // proj, x1 = x + s1 * p and c = LN2(x1) in one kernel: the branch output p never crosses HBM (csrc/gemm_ln.hip)
+        PTRY(K_GEMM_NT_LN, stream, 2.0 * M * E * Q, (double)M * E * 10 + (double)M * Q * 2,
+             cream_linear_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), at<void>(ws, L.o), d->wproj,
+                                     d->bproj, xin, dp1, N, d->ln2_g, d->ln2_b, M, E, Q, d->ld_proj, d->eps2, stream));
+    } else {
+        PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
+        // x1 = x + s1 * p ; c = LN2(x1)
+        PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
+                             at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
+    }
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
     PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
                                   d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
@@ -340,6 +350,11 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));
     return CREAM_OK;
+}
+
+int cream_block_fuse_ln(int on)
+{
+    return g_fuse_ln.exchange(on ? 1 : 0);
 }
 
 int cream_block_prof_enable(int on)

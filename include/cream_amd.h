@@ -244,6 +244,22 @@ int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float
                      const float* sample_scale, int rows_per_sample, const float* gamma,
                      const float* beta, int M, int E, float eps, void* stream);
 
+/* A projection whose output width is the embedding dimension, the residual add and the LayerNorm
+ * that follows, in ONE kernel (csrc/gemm_ln.hip) — supernet_transformer.py:262-276:
+ *   x = residual + drop_path(self.attn(...)) ; x = self.ffn_layer_norm(x)   and, across the block
+ * boundary, fc2 -> residual add -> the next block's attn_layer_norm.  Same results, bit for bit, as
+ * cream_linear_fwd followed by cream_add_ln_fwd:
+ *   p = bf16(a(M x K, bf16) . w[:E, :K]^T + bias)   (w: row stride ldw elements; bias bf16 or NULL)
+ *   xsum(f32) = x(f32) + sample_scale[row / rows_per_sample] * p   (scale may be NULL = 1)
+ *   y(bf16) = LayerNorm(xsum; gamma, beta, eps), mean / rstd of xsum saved.
+ * The M x E branch output p is never written.  Shapes: cream_linear_add_ln_supported(E, K) != 0
+ * (E a multiple of 64 in [192, 512], K a multiple of 32), else CREAM_ERR_TOO_LARGE. */
+int cream_linear_add_ln_supported(int E, int K);
+int cream_linear_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const void* a, const void* w,
+                            const void* bias, const float* x, const float* sample_scale, int rows_per_sample,
+                            const float* gamma, const float* beta, int M, int E, int K, int64_t ldw, float eps,
+                            void* stream);
+
 /* Number of row slabs ln_bwd reduces over: partial must hold cream_ln_partials()*3*E floats. */
 int cream_ln_partials(void);
 
@@ -519,6 +535,11 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const
                     int64_t pb2_pstride, const float* dp1, const float* prev_scale, int want_prev,
                     void* stream, void* side_stream);
 
+
+/* Switch (process-wide, returns the previous value): cream_block_fwd runs proj + residual add +
+ * ffn_layer_norm as ONE kernel (cream_linear_add_ln_fwd) where cream_linear_add_ln_supported says so.
+ * Results are identical either way. */
+int cream_block_fuse_ln(int on);
 
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).

@@ -795,3 +795,68 @@ def test_native_head_matches_fp32_linear():
     print("[native head]", {k: f"{v:.1e}" for k, v in errs.items()})
     assert all(v < 8e-3 for v in errs.values()), errs                 # bf16 operands (feat, W, dlogits rounded to bf16)
     assert torch.all(m.head.weight.grad[:, 384:] == 0.5)
+
+
+@pytest.mark.parametrize("M,E,K,ldw,bias,scale", [(197 * 8, 384, 384, 448, True, True), (25216, 448, 448, 448, True, True),
+                                                   (25216, 320, 1120, 1792, True, False), (1000, 192, 32, 40, False, True),
+                                                   (67, 512, 1344, 1344, True, True), (197 * 4, 256, 96, 96, False, False)])
+def test_projection_residual_layernorm_kernel_equals_the_two_kernel_path(M, E, K, ldw, bias, scale):
+    """cream_linear_add_ln_fwd (csrc/gemm_ln.hip: 64 complete rows per workgroup, LayerNorm in the epilogue) against
+    cream_linear_fwd + cream_add_ln_fwd: same MFMA sequence per output, same LayerNorm arithmetic -> identical bits.
+    Ragged M (tail tile), every supported width class, row stride > K, with / without bias and per-sample scale."""
+    from cream_amd.autoformer import block as K_
+    assert K_.linear_add_ln_supported(E, K) and not K_.linear_add_ln_supported(216, K) and not K_.linear_add_ln_supported(E, K + 8)
+    g = torch.Generator(device=DEV).manual_seed(M + E + K)
+    N = 197 if M % 197 == 0 else 7
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(E + 3, ldw, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(E, device=DEV, generator=g).bfloat16() if bias else None
+    x = torch.randn(M, E, device=DEV, generator=g) * 3 + 0.5
+    sc = ((torch.rand((M + N - 1) // N, device=DEV, generator=g) > 0.3).float() / 0.7) if scale else None
+    gamma = torch.randn(E, device=DEV, generator=g)
+    beta = torch.randn(E, device=DEV, generator=g)
+    p = K_.linear_fwd(a, w, b, E, K)
+    want = K_.add_ln_fwd(x, p, sc, N, gamma, beta, 1e-5)
+    got = K_.linear_add_ln_fwd(a, w, b, x, sc, N, gamma, beta, 1e-5, K)
+    torch.cuda.synchronize()
+    for name, u, v in zip(("x1", "y", "mean", "rstd"), got, want):
+        assert torch.equal(u, v), (name, float((u.float() - v.float()).abs().max()))
+    # and against fp32 math on the same bf16 operands
+    ref = x + (sc.repeat_interleave(N)[:M, None] if scale else 1.0) * (a.float() @ w[:E, :K].float().t() + (b.float() if bias else 0)).bfloat16().float()
+    assert _rel(got[0], ref) < 2e-2
+    assert _rel(got[1].float(), F.layer_norm(got[0], (E,), gamma, beta, 1e-5)) < 1e-2
+
+
+def test_native_block_forward_with_fused_projection_layernorm_is_bit_identical():
+    """cream_block_fuse_ln(1): cream_block_fwd runs proj + residual add + ffn_layer_norm as one kernel; outputs and every
+    gradient of a 3-block stack (with drop-path scales) equal the unfused sequencing bit for bit."""
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K
+    lib = _lib.load()
+    m = _supernet(depth=3).to(DEV)
+    cfg = dict(layer_num=3, embed_dim=[448] * 3, num_heads=[7, 5, 6], mlp_ratio=[4.0, 3.0, 3.5])
+    m.set_sample_config(cfg)
+    m.train()
+    g = torch.Generator(device=DEV).manual_seed(13)
+    B = 4
+    x0 = torch.randn(B, 197, 448, device=DEV, generator=g)
+    scales = (torch.rand(3, 2, B, device=DEV, generator=g) > 0.3).float() / 0.7
+    dout = torch.randn(B, 197, 448, device=DEV, generator=g)
+    blks = list(m.blocks)
+    res = []
+    prev = lib.cream_block_fuse_ln(0)
+    try:
+        for fuse in (0, 1):
+            lib.cream_block_fuse_ln(fuse)
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            y = K.StackFunction.apply(x, scales, blks)
+            y.backward(dout)
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                             if p.grad is not None}))
+    finally:
+        lib.cream_block_fuse_ln(prev)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k, v in res[0][2].items():
+        assert torch.equal(v, res[1][2][k]), k

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do
-CREAM_ATTN_OLD_FWD=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('old fwd', d['value'], d['ms_per_step'])"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('whole-KV fwd', d['value'], d['ms_per_step'])"
-done
+mkdir -p gpurun_out
+/opt/rocm/bin/rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null | grep -v "^$" | head -30
+bash tools/sample_clocks.sh gpurun_out/r03_clocks_step.txt python bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-host-leg --no-kernel-timing 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+grep -c sclk gpurun_out/r03_clocks_step.txt
