@@ -439,6 +439,18 @@ __global__ __launch_bounds__(64) void rpe_scatter_planes(
 
         auto consume = [&](const Stage& st, int ch) {
             const int c0 = ch * CT;
+#if defined(RPE_SCATTER_ABLATE) && RPE_SCATTER_ABLATE >= 2   // probe switch (tools/probes/scatter_probe.hip): loads only
+            {
+                ACC* slot = bins + lane;
+                ACC sum = *slot;
+#pragma unroll
+                for (int t = 0; t < NLD; ++t)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) sum += (ACC)cvt<T>::load(st.p[t].e[v]);
+                *slot = sum + (ACC)st.ids;
+                return;
+            }
+#endif
             // registers -> LDS tile (row-wise, 16-byte writes); keys past the row end were
             // loaded as zero
 #pragma unroll
@@ -525,8 +537,12 @@ __global__ __launch_bounds__(64) void rpe_scatter_planes(
         for (int ub = 0; ub < nb; ub += WAVE) {
             const int u = ub + lane;
             if (u < nb) {
+#if defined(RPE_SCATTER_ABLATE) && RPE_SCATTER_ABLATE == 3   // probe switch: loads only and (almost) no flush
+                for (int r = 0; r < 1; ++r) {
+#else
 #pragma unroll 8
                 for (int r = 0; r < WAVE; ++r) {
+#endif
                     union { E raw; T val; } c;
                     c.val = cvt<T>::store(bins[u * BP + r]);
                     bufop<BYTES>::st(c.raw, rs_gi, (int)((r * plane_gi + u) * BYTES));
