@@ -1,8 +1,11 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-CREAM_NT_PIPE=1 timeout 600 python -m pytest tests/test_block_gpu.py -x -q -m gpu -k "native_linear or qkv_segment or fused_gelu or hidden_width or block_at_bench or native_block_sequencing or patch_embedding" 2>&1 | tail -5
+python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg"
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], d["ms_per_step"])'
 for rep in 1 2 3; do
-for pipe in 0 1 3; do
-CREAM_NT_PIPE=$pipe python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pipe=$pipe', d['value'], d['ms_per_step'])"
-done
+$B 2>/dev/null | python -c "$P" "default            "
+CREAM_MAIN_PRIORITY=-1 $B 2>/dev/null | python -c "$P" "main high          "
+CREAM_SIDE_PRIORITY=1 $B 2>/dev/null | python -c "$P" "side low(+1)       "
+CREAM_SIDE_PRIORITY=-1 $B 2>/dev/null | python -c "$P" "side HIGH          "
+CREAM_MAIN_PRIORITY=0 $B 2>/dev/null | python -c "$P" "main on own stream0"
 done
