@@ -143,7 +143,7 @@ class IrpeAttnDesc(ctypes.Structure):
                 [(n, _c.c_int32) for n in ("B", "H", "L", "NP", "nb")] + [("scale", _f)] +
                 [(n, _vp) for n in ("dout", "dq", "dk", "dv")] + [(n, _i64) for n in ("dsb", "dsn", "dsh")] +
                 [(n, _vp) for n in ("delta", "lkg", "gg", "dlk", "dlq", "bq", "bk")] + [(n, _i64) for n in ("bq_hs", "bk_hs")] +
-                [("causal", _c.c_int32), ("reserved", _c.c_int32)])
+                [("causal", _c.c_int32), ("reserved", _c.c_int32), ("dropout_p", _c.c_float), ("dropout_seed", _c.c_uint32)])
 
 
 class ParamJob(ctypes.Structure):

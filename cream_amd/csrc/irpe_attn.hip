@@ -74,6 +74,12 @@ struct Args {
     int B, H, L, NP, nb;
     float scale;
     int causal;                       // key j takes part for query i only if j <= i (text towers); 0: full attention
+    // attention dropout (rpe_vision_transformer.py:86 `attn = self.attn_drop(attn)`): P[i,j] -> keep[i,j] P[i,j] / (1 - p)
+    // AFTER the softmax normalisation, for the value product and the value-side bucket sums alike.  keep is a pure
+    // function of (seed, b, h, i, j) — see drop_keep — so that the backward launches regenerate it.
+    uint32_t drop_thr;                // keep iff hash >= drop_thr = round(p 2^32); 0: no dropout
+    uint32_t drop_seed;
+    float drop_scale;                 // 1 / (1 - p)
     // backward
     const short* dout;                // (B, L, H, 64)
     short *dq, *dk, *dv;
@@ -82,6 +88,19 @@ struct Args {
     short *lkg, *gg;                  // (B, H, NP, 64) rpe_k lookups / value-side lookups of dO   (A -> B)
     short *dlk, *dlq;                 // (B, H, NP, 64) bucket gradients (-> table gradients)
 };
+
+// counter-based keep mask: a 32-bit avalanche mix (two multiply-xorshift rounds) of a per-(b,h) key and the pair (i, j).
+// cream_amd/irpe_fused.py `dropout_keep_mask` restates it in numpy for the tests.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_key(uint32_t seed, int bh) { return mix32(seed ^ ((uint32_t)(bh + 1) * 0x9E3779B9u)); }
+__device__ __forceinline__ bool drop_keep(uint32_t key, int i, int j, uint32_t thr) {
+    return mix32(key ^ (((uint32_t)i << 16) | (uint32_t)j)) >= thr;
+}
 
 // consecutive logical workgroups (the blocks of one (b,h), which share the streamed side) on one XCD
 __device__ __forceinline__ int xcd_order(int bid, int n) {
@@ -469,6 +488,12 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                     ps[r & 3] += p;
                 }
                 lrun += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                if (a.drop_thr) {                                    // (wave-uniform) the normaliser above is the undropped sum
+                    const uint32_t dkey = drop_key(a.drop_seed, bh);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        s[r] = drop_keep(dkey, qi, t * 32 + acc_row(r, g), a.drop_thr) ? s[r] * a.drop_scale : 0.f;
+                }
                 const short* vb = vbuf + cur * 32 * KP;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -664,7 +689,9 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
                 const int key = t * 32 + acc_row(r, g);
                 const bool ok = (t < NT - 1 || key < a.L) && !(a.causal && key > qi);
                 const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -lseL)) : 0.f;
-                s[r] = p * (dp[r] - delta);
+                float dpr = dp[r];                                   // gradient of the DROPPED map -> of the softmax output
+                if (a.drop_thr) dpr = drop_keep(drop_key(a.drop_seed, bh), qi, key, a.drop_thr) ? dpr * a.drop_scale : 0.f;
+                s[r] = p * (dpr - delta);
             }
             if constexpr (HK) {
                 uint32_t w[4];
@@ -845,8 +872,14 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
                     const int r = 4 * rr + e;
                     float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ls[e]));
                     if (a.causal && t * 32 + acc_row(r, g) < kj) p = 0.f;          // query before this lane's key
-                    s[r] = p;
-                    ds[r] = p * (dp[r] - dl[e]);
+                    float dpr = dp[r], pd = p;
+                    if (a.drop_thr) {                                              // dv takes the dropped map, dS the mask on dP
+                        const bool keep = drop_keep(drop_key(a.drop_seed, bh), t * 32 + acc_row(r, g), kj, a.drop_thr);
+                        dpr = keep ? dpr * a.drop_scale : 0.f;
+                        pd = keep ? p * a.drop_scale : 0.f;
+                    }
+                    s[r] = pd;
+                    ds[r] = p * (dpr - dl[e]);
                 }
             }
             if constexpr (HQ) {
@@ -983,6 +1016,7 @@ int check(const cream_irpe_attn_desc* d, bool bwd) {
     if (d->B <= 0 || d->H <= 0 || d->L <= 0 || d->nb <= 0 || d->nb > 64) return CREAM_ERR_BAD_ARG;
     if (d->NP != (d->L + 31) / 32 * 32) return CREAM_ERR_BAD_ARG;
     if (d->NP > 2048) return CREAM_ERR_TOO_LARGE;
+    if (!(d->dropout_p >= 0.f) || d->dropout_p >= 1.f) return CREAM_ERR_BAD_ARG;          // (NP <= 2048: (i, j) fit 16 bits each)
     if (d->sn % 8 || d->sh % 8 || d->sb % 8 || !aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v) || !aligned16(d->out))
         return CREAM_ERR_BAD_ARG;
     const bool hq = d->wq != nullptr || d->bq != nullptr, hk = d->wk != nullptr || d->bk != nullptr, hv = d->wv != nullptr;
@@ -1009,6 +1043,10 @@ Args to_args(const cream_irpe_attn_desc* d) {
     a.idq = d->idq; a.idk = d->idk; a.idv = d->idv;
     a.idq_t = d->idq_t; a.idk_t = d->idk_t; a.idv_t = d->idv_t;
     a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale; a.causal = d->causal;
+    const double thr = (double)d->dropout_p * 4294967296.0;
+    a.drop_thr = d->dropout_p > 0.f ? (uint32_t)(thr < 1.0 ? 1.0 : (thr > 4294967295.0 ? 4294967295.0 : thr)) : 0u;
+    a.drop_seed = d->dropout_seed;
+    a.drop_scale = 1.f / (1.f - d->dropout_p);
     a.dout = (const short*)d->dout;
     a.dq = (short*)d->dq; a.dk = (short*)d->dk; a.dv = (short*)d->dv;
     a.dsb = d->dsb; a.dsn = d->dsn; a.dsh = d->dsh;

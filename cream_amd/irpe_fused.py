@@ -60,10 +60,11 @@ def _term(rpe, L, device):
     return w, hs, asis, tr, rpe.num_buckets, bias
 
 
-def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active):
+def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active=False):
+    """(attention dropout no longer excludes the fused path: the kernels regenerate the keep mask from a seed)"""
     if os.environ.get("CREAM_IRPE_FUSED", "1") == "0":
         return False
-    if device.type != "cuda" or qkv_dtype != torch.bfloat16 or head_dim != 64 or attn_drop_active or L > 2048:
+    if device.type != "cuda" or qkv_dtype != torch.bfloat16 or head_dim != 64 or L > 2048:
         return False
     from .irpe import iRPE
     nbs = set()
@@ -109,19 +110,53 @@ def _desc(qkv, scale, terms, out, lse, sv):
     return d
 
 
+def dropout_keep_mask(seed, B, H, L):
+    """The keep mask of the kernels' attention dropout as a (B, H, L, L) uint32 array of hash values: element (b, h, i, j)
+    is kept iff value >= round(p * 2^32).  numpy restatement of `drop_key` / `drop_keep` in csrc/irpe_attn.hip (a 32-bit
+    multiply-xorshift mix of a per-(b, h) key and (i << 16 | j)); used by the tests to build the reference."""
+    import numpy as np
+
+    def mix32(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(16)
+        return x
+
+    bh = np.arange(B * H, dtype=np.uint64)
+    key = mix32(np.uint64(seed & 0xFFFFFFFF) ^ (((bh + np.uint64(1)) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)))
+    i = np.arange(L, dtype=np.uint64)[:, None]
+    j = np.arange(L, dtype=np.uint64)[None, :]
+    pair = (i << np.uint64(16)) | j
+    return mix32(key[:, None, None] ^ pair[None]).astype(np.uint32).reshape(B, H, L, L)
+
+
+def dropout_threshold(p):
+    """round(p * 2^32) clamped to [1, 2^32 - 1] as the C ABI computes it (cream_irpe_attn_desc.dropout_p is a float)."""
+    import numpy as np
+    thr = float(np.float32(p)) * 4294967296.0
+    return int(min(max(thr, 1.0), 4294967295.0))
+
+
+def _new_seed():
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())      # host generator: follows torch.manual_seed
+
+
 def _flops(B, H, L, n_terms, bwd):
     return (2.5 if bwd else 1.0) * 4.0 * B * H * L * L * 64 + (3 if bwd else 1) * n_terms * 2.0 * B * H * L * 64 * 64
 
 
 class _Fused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, scale, wq, wk, wv, terms):
+    def forward(ctx, qkv, scale, wq, wk, wv, terms, drop_p=0.0, seed=0):
         B, L, _, H, D = qkv.shape
         NP = padded_len(L)
         out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
         sv = torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=qkv.device) if terms[2] is not None else None
         d = _desc(qkv, scale, terms, out, lse, sv)
+        d.dropout_p, d.dropout_seed = float(drop_p), int(seed)
+        ctx.drop = (float(drop_p), int(seed))
         n_terms = sum(t is not None for t in terms)
         with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, n_terms, False)):
             rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
@@ -143,6 +178,7 @@ class _Fused(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
         d = _desc(qkv, scale, terms, out, lse, sv)
+        d.dropout_p, d.dropout_seed = ctx.drop
         d.dout = dout.data_ptr()
         es = dqkv.element_size()
         sb, sn, s3, sh, _ = dqkv.stride()
@@ -202,7 +238,7 @@ class _Fused(torch.autograd.Function):
                 res.append(gpart[:, :nb].to(w.dtype).contiguous())
                 continue
             res.append((gpart[:, :, :nb] if transposed else gpart[:, :nb, :]).to(w.dtype).contiguous())
-        return dqkv, None, res[0], res[1], res[2], None
+        return dqkv, None, res[0], res[1], res[2], None, None, None
 
 
 def plain_fwd(qkv, scale, causal=False):
@@ -239,10 +275,14 @@ def plain_bwd(dout, qkv, out, lse, scale, causal=False):
     return dqkv
 
 
-def attention(qkv, scale, rpe_q, rpe_k, rpe_v):
-    """qkv (B, L, 3, H, 64) bf16 -> (B, L, H*64)."""
+def attention(qkv, scale, rpe_q, rpe_k, rpe_v, dropout_p=0.0, seed=None):
+    """qkv (B, L, 3, H, 64) bf16 -> (B, L, H*64).  dropout_p > 0: attention dropout inside the kernels
+    (rpe_vision_transformer.py:86); `seed` (default: drawn from torch's host generator) fixes the keep mask, which
+    `dropout_keep_mask` reproduces."""
     assert qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] == 64 and qkv.stride(4) == 1
     L, dev = qkv.shape[1], qkv.device
     terms = tuple(_term(r, L, dev) for r in (rpe_q, rpe_k, rpe_v))
     ws = [t[0] if t is not None else None for t in terms]
-    return _Fused.apply(qkv, float(scale), ws[0], ws[1], ws[2], terms)
+    if dropout_p and seed is None:
+        seed = _new_seed()
+    return _Fused.apply(qkv, float(scale), ws[0], ws[1], ws[2], terms, float(dropout_p or 0.0), int(seed or 0))

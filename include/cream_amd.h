@@ -204,6 +204,12 @@ typedef struct cream_irpe_attn_desc {
     /* causal != 0: key j takes part for query i only if j <= i — the additive upper-triangular -inf mask of the text
      * towers (TinyCLIP/src/open_clip/model.py:756-762) without an (L, L) tensor; 0: full attention */
     int32_t causal, reserved;
+    /* attention dropout (rpe_vision_transformer.py:86, multihead_super.py:145 `attn = self.attn_drop(attn)`):
+     * P[i,j] -> keep[i,j] P[i,j] / (1 - dropout_p) after the softmax, for the value product and the value-side
+     * bucket sums alike; keep is a pure function of (dropout_seed, b, h, i, j) — the SAME seed must be given to
+     * cream_irpe_attn_bwd.  0 <= dropout_p < 1 (0: none); L <= 65535 with dropout. */
+    float dropout_p;
+    uint32_t dropout_seed;
 } cream_irpe_attn_desc;
 
 int cream_irpe_padded_len(int L);

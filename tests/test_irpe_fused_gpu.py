@@ -18,7 +18,7 @@ def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def _restatement(qkv, scale, mods, round_lookups=True):
+def _restatement(qkv, scale, mods, round_lookups=True, keep=None):
     """round_lookups: the lookups (s q) W leave the reference's autocast matmul as 16-bit values (irpe.py:646 under amp) and the
     kernel keeps them as bf16 rows in LDS; False evaluates the same algebra in pure fp32 (reported next to the asserted comparison)."""
     rnd = (lambda t: t.to(torch.bfloat16).float()) if round_lookups else (lambda t: t)
@@ -49,6 +49,8 @@ def _restatement(qkv, scale, mods, round_lookups=True):
         lq = rnd((k * scale) @ w_of(rq))
         a = a + lq.gather(-1, ids_of(rq).expand(*lq.shape[:2], L, L)).transpose(2, 3)
     p = a.softmax(-1)
+    if keep is not None:                                                       # attn_drop (:86): mask / (1 - rate), given
+        p = p * keep
     out = p @ v
     if rv is not None:
         sv = torch.zeros(*p.shape[:3], rv.num_buckets, device=p.device).scatter_add_(-1, ids_of(rv).expand_as(p), p)
@@ -215,3 +217,72 @@ def test_causal_attention_matches_masked_reference(L, B, H):
 
 
 from cream_amd import irpe_fused  # noqa: E402
+
+
+@pytest.mark.parametrize("rpe_on,rate,L", [("", 0.1, 197), ("qkv", 0.1, 197), ("kv", 0.5, 50), ("k", 0.25, 577)])
+def test_fused_attention_dropout_matches_masked_restatement(rpe_on, rate, L):
+    """Attention dropout inside the fused kernels (rpe_vision_transformer.py:86: the softmax output is dropped BEFORE the
+    value product and the value-side bucket sums): the keep mask is a counter-based hash of (seed, b, h, i, j), restated in
+    numpy by irpe_fused.dropout_keep_mask — forward and every gradient against the fp32 restatement with THAT mask; the
+    kept fraction is the requested one; another seed gives another mask, the same seed the same bits."""
+    import numpy as np
+    from cream_amd import irpe as I, irpe_fused
+    B, H = 2, 3
+    torch.manual_seed(21)
+    mods = [None, None, None]
+    if rpe_on:
+        cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on=rpe_on)
+        mods = list(I.build_rpe(cfg, head_dim=64, num_heads=H))
+    for m in mods:
+        if m is not None:
+            m.to(DEV)
+            with torch.no_grad():
+                _table(m).copy_(0.3 * torch.randn_like(_table(m)))
+            _table(m).requires_grad_()
+    qkv = (0.8 * torch.randn(B, L, 3, H, 64, device=DEV)).to(torch.bfloat16).requires_grad_()
+    gy = torch.randn(B, L, H * 64, device=DEV).to(torch.bfloat16)
+    seed = 12345
+    hashes = irpe_fused.dropout_keep_mask(seed, B, H, L)
+    keep_np = hashes >= np.uint32(irpe_fused.dropout_threshold(rate))
+    assert abs(keep_np.mean() - (1 - rate)) < 4e-3, keep_np.mean()
+    assert (irpe_fused.dropout_keep_mask(seed + 1, B, H, L) >= np.uint32(irpe_fused.dropout_threshold(rate))).mean() != keep_np.mean()
+    keep = torch.from_numpy(keep_np).to(DEV).float() / (1.0 - float(np.float32(rate)))
+    y = irpe_fused.attention(qkv, 0.125, *mods, dropout_p=rate, seed=seed)
+    y2 = irpe_fused.attention(qkv, 0.125, *mods, dropout_p=rate, seed=seed)
+    y3 = irpe_fused.attention(qkv, 0.125, *mods, dropout_p=rate, seed=seed + 1)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    params = [_table(m) for m in mods if m is not None]
+    got = torch.autograd.grad(y, [qkv] + params, gy)
+    ref = _restatement(qkv, 0.125, mods, keep=keep)
+    want = torch.autograd.grad(ref, [qkv] + params, gy.float())
+    errs = dict(y=max_rel(y.float(), ref))
+    for name, a, b in zip(["dq", "dk", "dv"], got[0].float().unbind(2), want[0].float().unbind(2)):
+        errs[name] = max_rel(a, b)
+    for name, a, b in zip([c for c, m in zip("qkv", mods) if m is not None], got[1:], want[1:]):
+        errs["dW" + name] = max_rel(a.float(), b.float())
+    print(f"[fused irpe dropout {rpe_on or 'none'} p={rate} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(torch.isfinite(t).all() for t in got)
+    for k, v in errs.items():
+        assert v < 1.5e-2, (k, v, errs)
+    # without the mask the restatement is far away: the comparison above is a statement about the mask
+    assert max_rel(y.float(), _restatement(qkv, 0.125, mods).detach()) > 5e-2
+
+
+def test_module_with_attention_dropout_stays_on_the_fused_kernels():
+    from cream_amd import irpe as I, timing
+    from cream_amd.rpe_attention import RPEAttention
+    cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="k")
+    att = RPEAttention(192, num_heads=3, qkv_bias=True, attn_drop=0.1, rpe_config=cfg).to(DEV)
+    x = torch.randn(2, 197, 192, device=DEV, requires_grad=True)
+    timing.reset()
+    timing.enable(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = att(x)
+    y.float().sum().backward()
+    timing.enable(False)
+    names = set(timing.summary())
+    assert {"irpe_attn_fwd", "irpe_attn_bwd"} <= names and not {"rpe_index_fwd", "rpe_index_bwd"} & names, names
+    att.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        a, b = att(x), att(x)
+    assert torch.equal(a, b)                                   # no dropout outside training

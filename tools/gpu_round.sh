@@ -25,7 +25,7 @@ echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
   echo "pmc $N exit $?"
   # config 4: the fused iRPE attention kernels and the rpe_index kernels under the same counters (bench.py reads their mfma_util / traffic)
   timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_' -d $OUT/${TAG}_pmc_irpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_pmc_irpe_$N.err
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'rpe_gather|rpe_scatter' -d $OUT/${TAG}_pmc_rpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_pmc_rpe_$N.err"
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'rpe_gather|rpe_scatter' -d $OUT/${TAG}_pmc_rpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_pmc_rpe_$N.err
 done
 # BASELINE config 4: rocprofv3 kernel trace + HBM counters of the rpe_index kernels, stall counters of both kernel families
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_rpe_prof -o rpe -- python $REPO/tools/bench_rpe_index.py > /dev/null 2> $OUT/${TAG}_rpe_prof.err
