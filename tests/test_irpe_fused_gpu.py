@@ -244,7 +244,7 @@ def test_fused_attention_dropout_matches_masked_restatement(rpe_on, rate, L):
     seed = 12345
     hashes = irpe_fused.dropout_keep_mask(seed, B, H, L)
     keep_np = hashes >= np.uint32(irpe_fused.dropout_threshold(rate))
-    assert abs(keep_np.mean() - (1 - rate)) < 4e-3, keep_np.mean()
+    assert abs(keep_np.mean() - (1 - rate)) < 4.5 * (rate * (1 - rate) / keep_np.size) ** 0.5, keep_np.mean()     # 4.5 sigma
     assert (irpe_fused.dropout_keep_mask(seed + 1, B, H, L) >= np.uint32(irpe_fused.dropout_threshold(rate))).mean() != keep_np.mean()
     keep = torch.from_numpy(keep_np).to(DEV).float() / (1.0 - float(np.float32(rate)))
     y = irpe_fused.attention(qkv, 0.125, *mods, dropout_p=rate, seed=seed)
