@@ -124,7 +124,7 @@ class SliceJob(ctypes.Structure):
 
 class BlockDesc(ctypes.Structure):
     """struct cream_block_desc of include/cream_amd.h."""
-    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "F_valid", "reserved1")] +
+    _fields_ = ([(n, _c.c_int32) for n in ("B", "N", "E", "H", "F", "gh", "gw", "mr", "F_valid", "inference")] +
                 [(n, _f) for n in ("eps1", "eps2", "attn_scale", "reserved_f")] +
                 [(n, _vp) for n in ("wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj", "w1", "w1_t", "b1",
                                     "w2", "w2_t", "b2")] +

@@ -202,12 +202,13 @@ def linear_fwd_seg(x, w3, bias, N, K, nseg, out=None):
     return out
 
 
-def linear_gelu_fwd(x, w, bias, N, K):
+def linear_gelu_fwd(x, w, bias, N, K, want_grad=True):
     """-> (gp, g) with h = bf16(x . W^T + bias): gp = gelu'(float(h)), g = gelu(float(h)), both bf16, in
-    one pass (fc1 + activation; gp is everything the backward needs of h)."""
+    one pass (fc1 + activation; gp is everything the backward needs of h).  want_grad=False: gp is None and is
+    not written (forward without a backward)."""
     M = x.shape[0]
-    h = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    g = torch.empty_like(h)
+    g = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    h = torch.empty_like(g) if want_grad else None
     with timing.region("gemm_nt_gelu", flops=2 * M * N * K):
         _lib.check(_lib.load().cream_linear_gelu_fwd(_p(h), _p(g), _p(x), _p(w), _p(bias), M, N, K, w.stride(0), _stream()),
                    "cream_linear_gelu_fwd")
@@ -1203,8 +1204,10 @@ class StackFunction(torch.autograd.Function):
         sc_ptr = scales.data_ptr() if scales is not None else 0
         cur, pend_f, pend_s = x.data_ptr(), 0, 0
         descs, wss, xptrs = [], [], []
+        inference = not any(ctx.needs_input_grad)          # (no_grad evaluation: nothing only the backward reads is written)
         for i, blk in enumerate(blks):
             d = _block_desc(blk, B, N)
+            d.inference = 1 if inference else 0
             ft, off_x, off_x1, off_f = _ws_layout(d)[:4]
             ws = torch.empty(ft, dtype=torch.uint8, device=dev)
             wp = ws.data_ptr()

@@ -237,7 +237,7 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
                              at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
     }
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
-    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
+    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(d->inference ? nullptr : at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
                                   d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
     PTRY(K_GEMM_NT, stream, 2.0 * M * E * F, 0, cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;

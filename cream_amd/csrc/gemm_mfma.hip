@@ -109,7 +109,8 @@ int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bi
 int cream_linear_gelu_fwd_pad(void* gp, void* g, const void* x, const void* w, const void* bias, int M, int N, int Nvalid,
                               int K, int64_t ldw, void* stream)
 {
-    const int rc = check_nt(gp, x, w, M, N, K, ldw, K);
+    // gp == NULL: forward without a backward (evaluation, a frozen teacher): only gelu(h) is written — half the output bytes
+    const int rc = check_nt(gp ? gp : g, x, w, M, N, K, ldw, K);
     if (rc) return rc < 0 ? rc : CREAM_OK;
     if (!g || !bias || !aligned16(g) || Nvalid <= 0 || Nvalid > N) return CREAM_ERR_BAD_ARG;
     NtParams p = plain(gp, x, w, M, N, K, ldw);

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                             gb[e] &= keep;
                         }
                     }
-                    *reinterpret_cast<u32x4v*>(o) = pb;
+                    if (p.out) *reinterpret_cast<u32x4v*>(o) = pb;          // (no gelu' without a backward: inference, frozen teacher)
                     *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
                 } else {   // EPI_MUL_COLSUM
                     const u32x4v fb = auxv[j];

@@ -99,7 +99,7 @@ def _block_forward(blk, ops, x, pend, B, L, keep, causal):
     o, lse = irpe_fused.plain_fwd(qkv.view(B, L, 3, H, 64), 0.125, causal)
     p = K.linear_fwd(o.view(M, D), wo, bo, D, D)
     x1, c, mean2, rstd2 = K.add_ln_fwd(xin, p, None, L, ln2.weight, ln2.bias, ln2.eps)
-    gp, g = K.linear_gelu_fwd(c, w1, b1, F_, D)
+    gp, g = K.linear_gelu_fwd(c, w1, b1, F_, D, want_grad=keep)      # (the frozen teacher writes no gelu')
     f = K.linear_fwd(g, w2, b2, D, F_)
     saved = (xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g) if keep else None
     return x1, f, saved

@@ -329,7 +329,9 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
  *   cream_linear_gelu_fwd     with h = bf16(x . W^T + bias): g = gelu(float(h)) and gp = gelu'(float(h)), both
  *                             bf16, in one pass (fc1 + the fp32 gelu of supernet_transformer.py:14-16, on the
  *                             bf16-rounded h exactly as under the reference's autocast; the derivative shares
- *                             Phi and the exponential with the value and is what the backward needs of h)
+ *                             Phi and the exponential with the value and is what the backward needs of h);
+ *                             gp == NULL: only g is written (a forward without a backward: evaluation sweeps
+ *                             of supernet_engine.py:114-160, TinyCLIP's frozen teacher) — half the output bytes
  *   cream_linear_dgrad        dx(M x K) = dy(M x N) . W(N x K); `wt` is the TRANSPOSED copy W^T
  *                             (K rows, N contiguous, row stride ldwt)
  *   cream_linear_dgrad_seg    the same with the contraction index in segments of `kseg` (the
@@ -488,7 +490,9 @@ int cream_slices_copy(const cream_slice_job* jobs_dev, int njobs, float* packed,
 typedef struct cream_block_desc {
     int32_t B, N, E, H, F;        /* batch, tokens, embed dim, heads (head dim 64), mlp hidden     */
     int32_t gh, gw, mr;           /* token grid (N = gh*gw + 1) and max_relative_position          */
-    int32_t F_valid, reserved1;     /* F_valid > 0: F is the sampled hidden width rounded UP to a multiple of 8 and only the
+    int32_t F_valid, inference;     /* inference != 0: a forward without a backward (supernet_engine.py:114-160 evaluate, the
+                                       evolution search): tensors that only the backward reads (gelu'(h)) are not written.
+                                       F_valid > 0: F is the sampled hidden width rounded UP to a multiple of 8 and only the
                                        first F_valid hidden units exist (the fc1 epilogue writes zeros for the rest, which
                                        makes every product over the padded columns vanish); 0: F itself is exact */
     float eps1, eps2, attn_scale;

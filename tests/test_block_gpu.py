@@ -860,3 +860,28 @@ def test_native_block_forward_with_fused_projection_layernorm_is_bit_identical()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for k, v in res[0][2].items():
         assert torch.equal(v, res[1][2][k]), k
+
+
+def test_forward_without_backward_skips_the_gelu_derivative_and_gives_the_same_output():
+    """A forward that no backward will follow (no_grad evaluation, a frozen teacher): the fc1 epilogue writes gelu(h) only
+    (cream_linear_gelu_fwd with gp = NULL, cream_block_desc.inference) — same outputs bit for bit."""
+    from cream_amd.autoformer import block as K
+    g_ = torch.Generator(device=DEV).manual_seed(5)
+    M, E, F_ = 197 * 4, 384, 1344
+    x = torch.randn(M, E, device=DEV, generator=g_).bfloat16()
+    w = (torch.randn(F_, E, device=DEV, generator=g_) * E ** -0.5).bfloat16()
+    b = torch.randn(F_, device=DEV, generator=g_).bfloat16()
+    gp, g = K.linear_gelu_fwd(x, w, b, F_, E)
+    gp2, g2 = K.linear_gelu_fwd(x, w, b, F_, E, want_grad=False)
+    assert gp2 is None and gp is not None and torch.equal(g, g2)
+    m = _supernet(depth=2).to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[448] * 2, num_heads=[7, 6], mlp_ratio=[4.0, 3.5])
+    m.set_sample_config(cfg)
+    m.eval()
+    x0 = torch.randn(3, 197, 448, device=DEV, generator=g_)
+    blks = list(m.blocks)
+    y_grad = K.StackFunction.apply(x0.clone().requires_grad_(), None, blks)
+    with torch.no_grad():
+        y_eval = K.StackFunction.apply(x0, None, blks)
+    torch.cuda.synchronize()
+    assert torch.equal(y_grad.detach(), y_eval)

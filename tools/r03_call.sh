@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-host-leg"
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], d["ms_per_step"])'
-for rep in 1 2 3; do
-$B 2>/dev/null | python -c "$P" "default            "
-CREAM_NT_NARROW=1 $B 2>/dev/null | python -c "$P" "all NT 128x64 occ3 "
-done
+timeout 300 python -m pytest tests/test_block_gpu.py tests/test_tinyclip_model.py -x -q -m gpu -k "without_backward or native_tower or fused_gelu" 2>&1 | tail -3
+timeout 300 python tools/bench_subnet_eval.py 2>/dev/null | cut -c1-400
+timeout 300 python tools/bench_tinyclip.py 2>/dev/null | tail -2 | cut -c1-400
