@@ -681,7 +681,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     if constexpr (FAST) slots_to_buckets14(bk, scr, ox, lane, wave == 0, min(qr, G14 - 1), qc);
     else slots_to_buckets(bk, scr, ox, lane, qi, qr, qc, G);
     // S'^T (64 buckets x NP queries) for backward (dTvv / dTvh)
-    store_buckets_T<T>(reinterpret_cast<E*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);
+    if (a.sp) store_buckets_T<T>(reinterpret_cast<E*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);   // (NULL: no backward will follow)
     add_bucket_product<T>(o, tvt, bk, lane);
     PROF_MARK();
 
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(W14_THREADS) void attn_rpe2d_fwd14_kernel(const Fwd
         // ---- value-side relative position term: slot sums -> bucket sums -> . tables (scratch over [K | pad]) ---
         float bk[32];
         slots_to_buckets14(bk, scrB + wave * 32 * LP, ox, lane, wave == 0, min(qr, G14 - 1), qc);
-        store_buckets_T<T>(reinterpret_cast<short*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);
+        if (a.sp) store_buckets_T<T>(reinterpret_cast<short*>(a.sp) + ((int64_t)b * a.H + h) * 64 * NP + qi, NP, bk, g);
         add_bucket_product<T>(o, tvt, bk, lane);
         PROF_MARK();
         if (qok) store_rows_64<T>(reinterpret_cast<short*>(a.out) + (((int64_t)b * N + qi) * a.H + h) * 64, o, g);
@@ -1468,7 +1468,7 @@ int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const v
 {
     if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
     if (B == 0 || H == 0) return CREAM_OK;
-    if (!out || !lse || !sp || !q || !k || !v || !tkv || !tkh || !tvv || !tvh) return CREAM_ERR_BAD_ARG;
+    if (!out || !lse || !q || !k || !v || !tkv || !tkh || !tvv || !tvh) return CREAM_ERR_BAD_ARG;     // (sp == NULL: forward only)
     if (!geom_ok(N, gh, gw, mr, 2 * mr + 2)) return CREAM_ERR_TOO_LARGE;
     if (ldt < 64) return CREAM_ERR_BAD_ARG;
     const int esz = dtype == CREAM_F32 ? 4 : 2;

@@ -222,7 +222,7 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
                              stream));
     const uint16_t* qkv = at<uint16_t>(ws, L.qkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
-    PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
+    PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), d->inference ? nullptr : at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
                              d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
                              CREAM_BF16, stream));
     if (g_fuse_ln.load(std::memory_order_relaxed) && cream_linear_add_ln_supported(E, Q)) {

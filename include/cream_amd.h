@@ -104,7 +104,8 @@ int cream_attn_rpe2d_dtab_parts(int B, int H);
  *   out     : (B, N, H, 64) contiguous, same dtype as q
  *   lse     : (B, H, N) fp32       log-sum-exp of the scaled logits   (saved for backward)
  *   sp      : (B, H, 64, NP) same dtype as q: bucket sums S'^T, rows 0..31 vertical table,
- *             32..63 horizontal table, NP = cream_attn_rpe2d_padded_len(N)  (for backward)
+ *             32..63 horizontal table, NP = cream_attn_rpe2d_padded_len(N)  (for backward; NULL: not
+ *             written — a forward that no backward follows)
  * Limits: N <= 256, gh + gw + 1 <= 32, 2*mr + 2 <= 32, 16-byte aligned rows
  * (CREAM_ERR_TOO_LARGE / CREAM_ERR_BAD_ARG otherwise).  dtype: CREAM_BF16 (bf16 MFMA, fp32
  * accumulate and softmax) or CREAM_F32 (fp32 MFMA, exact fp32 products). */
