@@ -360,8 +360,8 @@ __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const shor
     __syncthreads();
 }
 
-template <bool HQ, bool HK, bool HV>
-__global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
+template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
     using L = LdsF<HQ, HK, HV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {
                     ps[r & 3] += p;
                 }
                 lrun += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-                if (a.drop_thr) {                                    // (wave-uniform) the normaliser above is the undropped sum
+                if constexpr (DROP) {                                // the normaliser above is the undropped sum
                     const uint32_t dkey = drop_key(a.drop_seed, bh);
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -561,8 +561,8 @@ template <bool HQ, bool HK, bool HV> struct LdsA {
     static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
 };
 
-template <bool HQ, bool HK, bool HV>
-__global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
+template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
     using L = LdsA<HQ, HK, HV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {
                 const bool ok = (t < NT - 1 || key < a.L) && !(a.causal && key > qi);
                 const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -lseL)) : 0.f;
                 float dpr = dp[r];                                   // gradient of the DROPPED map -> of the softmax output
-                if (a.drop_thr) dpr = drop_keep(drop_key(a.drop_seed, bh), qi, key, a.drop_thr) ? dpr * a.drop_scale : 0.f;
+                if constexpr (DROP) dpr = drop_keep(drop_key(a.drop_seed, bh), qi, key, a.drop_thr) ? dpr * a.drop_scale : 0.f;
                 s[r] = p * (dpr - delta);
             }
             if constexpr (HK) {
@@ -756,8 +756,8 @@ template <bool HQ, bool HK, bool HV> struct LdsB {
     static constexpr int fixed = stats;
 };
 
-template <bool HQ, bool HK, bool HV>
-__global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
+template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
     using L = LdsB<HQ, HK, HV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, KB = (NT + QW - 1) / QW;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {
                     float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ls[e]));
                     if (a.causal && t * 32 + acc_row(r, g) < kj) p = 0.f;          // query before this lane's key
                     float dpr = dp[r], pd = p;
-                    if (a.drop_thr) {                                              // dv takes the dropped map, dS the mask on dP
+                    if constexpr (DROP) {                                          // dv takes the dropped map, dS the mask on dP
                         const bool keep = drop_keep(drop_key(a.drop_seed, bh), t * 32 + acc_row(r, g), kj, a.drop_thr);
                         dpr = keep ? dpr * a.drop_scale : 0.f;
                         pd = keep ? p * a.drop_scale : 0.f;
@@ -1001,12 +1001,19 @@ int launch(K kern, const Args& a, size_t lds, hipStream_t st) {
 }
 
 template <bool HQ, bool HK, bool HV> int launch_fwd(const Args& a, hipStream_t st) {
+    if (a.drop_thr) return launch(irpe_attn_fwd_kernel<HQ, HK, HV, true>, a, LdsF<HQ, HK, HV>::total, st);
     return launch(irpe_attn_fwd_kernel<HQ, HK, HV>, a, LdsF<HQ, HK, HV>::total, st);
 }
 template <bool HQ, bool HK, bool HV> int launch_bwd(const Args& a, hipStream_t st) {
+    const size_t ldsb = LdsB<HQ, HK, HV>::fixed + (size_t)a.NP * 8;
+    if (a.drop_thr) {
+        const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV, true>, a, LdsA<HQ, HK, HV>::total, st);
+        if (rc) return rc;
+        return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV, true>, a, ldsb, st);
+    }
     const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV>, a, LdsA<HQ, HK, HV>::total, st);
     if (rc) return rc;
-    return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV>, a, LdsB<HQ, HK, HV>::fixed + (size_t)a.NP * 8, st);
+    return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV>, a, ldsb, st);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
