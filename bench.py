@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 # kernel arguments in device memory: shortens the dispatch of back-to-back kernels (a step is ~330 launches);
 # measured +3.3 % images/s in a same-box A/B.  Must be in the environment before the HIP runtime initialises.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# RCCL between the ranks of a node shares device memory through dmabuf handles; the host driver of these boxes has no
+# legacy IPC (without this, multi-process runs fail with `hipIpcGetMemHandle: invalid argument`)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

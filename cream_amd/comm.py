@@ -353,6 +353,7 @@ def init_distributed(backend=None):
             # CREAM_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
             backend = os.environ.get("CREAM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks of a node (see bench.py)
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
