@@ -139,3 +139,18 @@ def test_new_entry_points_validate_arguments_without_launching():
     # table-gradient partials of the attention backward: one per persistent workgroup, never more than the (b, h) items
     assert lib.cream_attn_rpe2d_dtab_parts(0, 6) == 0 and lib.cream_attn_rpe2d_dtab_parts(2, 3) == 6
     assert 1 <= lib.cream_attn_rpe2d_dtab_parts(128, 6) <= 768
+
+
+def test_shape_predicates_and_switches_without_a_device():
+    """Entry points that take no device pointers: the supported-shape predicate of the fused projection + LayerNorm kernel
+    and the process-wide switches of the block driver (each returns the previous value)."""
+    from cream_amd import _lib
+    lib = _lib.load()
+    assert lib.cream_linear_add_ln_supported(384, 384) and lib.cream_linear_add_ln_supported(448, 1792)
+    assert lib.cream_linear_add_ln_supported(192, 32) and lib.cream_linear_add_ln_supported(512, 64)
+    assert not lib.cream_linear_add_ln_supported(216, 384)        # supernet-T widths: not a multiple of 64
+    assert not lib.cream_linear_add_ln_supported(576, 384)        # wider than one workgroup's row tile
+    assert not lib.cream_linear_add_ln_supported(384, 40)         # K not a multiple of 32
+    prev = lib.cream_block_fuse_ln(1)
+    assert lib.cream_block_fuse_ln(prev) == 1
+    assert lib.cream_block_fuse_ln(prev) == prev

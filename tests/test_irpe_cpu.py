@@ -314,3 +314,22 @@ def test_model_zoo_checkpoints_fit():
     assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
     with pytest.raises(AssertionError, match="not provided"):
         R.create_zoo_model("deit_tiny_patch16_224_ctx_product_50_shared_qkv")
+
+
+def test_dropout_keep_mask_restatement_is_deterministic_and_unbiased():
+    """The numpy restatement of the kernels' keep mask (csrc/irpe_attn.hip drop_key / drop_keep): a pure function of
+    (seed, b, h, i, j), the requested keep fraction, independent between heads and seeds."""
+    import numpy as np
+    from cream_amd import irpe_fused
+    h1 = irpe_fused.dropout_keep_mask(7, 2, 3, 64)
+    assert h1.shape == (2, 3, 64, 64) and h1.dtype == np.uint32
+    assert np.array_equal(h1, irpe_fused.dropout_keep_mask(7, 2, 3, 64))
+    assert np.array_equal(h1[:, :, :32, :32], irpe_fused.dropout_keep_mask(7, 2, 3, 32))      # does not depend on L
+    for rate in (0.1, 0.5, 0.9):
+        keep = h1 >= np.uint32(irpe_fused.dropout_threshold(rate))
+        assert abs(keep.mean() - (1 - rate)) < 4.5 * (rate * (1 - rate) / keep.size) ** 0.5
+    other = irpe_fused.dropout_keep_mask(8, 2, 3, 64)
+    agree = ((h1 >> 31) == (other >> 31)).mean()                                               # top bits: 50 % agreement
+    assert 0.47 < agree < 0.53
+    assert 0.47 < ((h1[0, 0] >> 31) == (h1[0, 1] >> 31)).mean() < 0.53
+    assert irpe_fused.dropout_threshold(0.5) == 2 ** 31 and irpe_fused.dropout_threshold(1e-12) == 1
