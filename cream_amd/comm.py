@@ -33,11 +33,25 @@ import torch
 import torch.distributed as dist
 
 
-def autoformer_active_slice(name, p, config):
+def attention_layout(model):
+    """{block index: (change_qkv, super_embed_dim)} read off the modules: with `change_qkv=False`
+    (multihead_super.py:81-84, 104-106) the qkv projection is a LinearSuper whose sampled output is ALWAYS
+    3 * super_embed_dim and the output projection reads super_embed_dim columns — the head count does not slice them."""
+    out = {}
+    for i, blk in enumerate(getattr(model, "blocks", [])):
+        attn = getattr(blk, "attn", None)
+        if attn is not None and hasattr(attn, "change_qkv"):
+            out[i] = (bool(attn.change_qkv), int(getattr(attn, "super_embed_dim", 0)))
+    return out
+
+
+def autoformer_active_slice(name, p, config, layout=None):
     """(rows, cols) of the part of parameter `name` (viewed as (numel / last dim, last dim); the patch-embedding
     convolution as (out, C*ph*pw)) that a sub-network with `config` can write — the slicing rules of
     Linear_super.py:71-81, qkv_super.py:72-83 (rows 3 i + j, i < Q = rows [0, 3 Q)), layernorm_super.py:26-37,
-    embedding_super.py:33-40 and supernet_transformer.py:147-172.  Unknown names: the whole tensor."""
+    embedding_super.py:33-40 and supernet_transformer.py:147-172.  `layout` = attention_layout(model): blocks built
+    with `change_qkv=False` keep the whole qkv output / projection input (multihead_super.py:104-106); without a
+    layout the attention projections are sent whole (always correct).  Unknown names: the whole tensor."""
     E = config["embed_dim"][0]
     last = p.shape[-1] if p.dim() > 1 else p.numel()
     full = (p.numel() // last, last)
@@ -46,9 +60,15 @@ def autoformer_active_slice(name, p, config):
         i = int(parts[1])
         if i >= config["layer_num"]:
             return (0, 0)
-        Q = 64 * config["num_heads"][i]
         F_ = int(E * config["mlp_ratio"][i])
         leaf = ".".join(parts[2:])
+        change_qkv, super_e = (layout or {}).get(i, (None, 0))
+        if change_qkv is None:                                # layout unknown: never drop a written element
+            if leaf in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight"):
+                return full
+            Q = 0
+        else:
+            Q = 64 * config["num_heads"][i] if change_qkv else super_e
         rule = {"attn.qkv.weight": (3 * Q, E), "attn.qkv.bias": (1, 3 * Q), "attn.proj.weight": (E, Q),
                 "attn.proj.bias": (1, E), "fc1.weight": (F_, E), "fc1.bias": (1, F_), "fc2.weight": (E, F_),
                 "fc2.bias": (1, E), "attn_layer_norm.weight": (1, E), "attn_layer_norm.bias": (1, E),
@@ -74,6 +94,7 @@ class GradReducer:
         assert mode in ("allreduce", "rs_ag")
         self.mode = mode
         self.slice_of = slice_of              # None: always send whole buckets
+        self.layout = attention_layout(model)  # change_qkv / super_embed_dim per block, from the modules themselves
         self.stage = None                     # staging arena of the packed messages (allocated on first use)
         self._slice_tables = {}
         self.msg = {}
@@ -214,7 +235,7 @@ class GradReducer:
     def _slice_plan(self, b, config):
         """-> (message view into the staging arena, pack / unpack plan) of bucket b for this configuration; cached per
         (bucket, slice signature) — the S search space has 27 signatures per block."""
-        sig = tuple(self.slice_of(n, p, config) for n, p in self.members[b])
+        sig = tuple(self.slice_of(n, p, config, self.layout) for n, p in self.members[b])
         key = (b, sig)
         plan = self._slice_tables.get(key)
         if plan is None:

@@ -147,7 +147,7 @@ const char* const kProfNames[K_COUNT] = {"ln_fwd", "gemm_nt", "gemm_nt_gelu", "g
 // projection + residual add + LayerNorm as one kernel where the shapes allow (cream_block_fuse_ln)
 std::atomic<int> g_fuse_ln{0};
 struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_free;
@@ -161,17 +161,24 @@ struct ProfScope {
     ProfRec r{};
     hipStream_t st;
     bool on;
-    ProfScope(int kind, hipStream_t s, double flops, double bytes) : st(s), on(g_prof_on) {
+    ProfScope(int kind, hipStream_t s, double flops, double bytes) : st(s), on(g_prof_on.load(std::memory_order_relaxed)) {
         if (!on) return;
         std::lock_guard<std::mutex> lock(g_prof_mu);
         r.kind = kind; r.flops = flops; r.bytes = bytes;
         r.a = prof_event(); r.b = prof_event();
         on = r.a && r.b && hipEventRecord(r.a, st) == hipSuccess;
+        if (!on) give_back();
+    }
+    void give_back() {                       // (caller holds g_prof_mu) events of a failed scope return to the pool
+        if (r.a) g_prof_free.push_back(r.a);
+        if (r.b) g_prof_free.push_back(r.b);
+        r.a = r.b = nullptr;
     }
     ~ProfScope() {
         if (!on) return;
         std::lock_guard<std::mutex> lock(g_prof_mu);
         if (hipEventRecord(r.b, st) == hipSuccess) g_prof_recs.push_back(r);
+        else give_back();
     }
 };
 #define PTRY(kind, st, flops, bytes, call) do { ProfScope ps_((kind), (hipStream_t)(st), (double)(flops), (double)(bytes)); TRY(call); } while (0)

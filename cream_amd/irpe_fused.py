@@ -60,9 +60,12 @@ def _term(rpe, L, device):
     return w, hs, asis, tr, rpe.num_buckets, bias
 
 
-def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active=False):
-    """(attention dropout no longer excludes the fused path: the kernels regenerate the keep mask from a seed)"""
+def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active=False, dropout_p=0.0):
+    """(attention dropout no longer excludes the fused path: the kernels regenerate the keep mask from a seed;
+    `nn.Dropout(p=1.0)` is legal and stays on the composed path — the C ABI rejects dropout_p >= 1)"""
     if os.environ.get("CREAM_IRPE_FUSED", "1") == "0":
+        return False
+    if dropout_p >= 1.0:
         return False
     if device.type != "cuda" or qkv_dtype != torch.bfloat16 or head_dim != 64 or L > 2048:
         return False
@@ -138,8 +141,19 @@ def dropout_threshold(p):
     return int(min(max(thr, 1.0), 4294967295.0))
 
 
+_seed_gen = None
+
+
 def _new_seed():
-    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())      # host generator: follows torch.manual_seed
+    """Seeds of the in-kernel keep masks come from a DEDICATED host generator seeded from torch.initial_seed(): they
+    follow torch.manual_seed without consuming numbers of the global host stream (Mixup / the config sampler draw from
+    it between layers)."""
+    global _seed_gen
+    if _seed_gen is None or _seed_gen[0] != torch.initial_seed():
+        g = torch.Generator()
+        g.manual_seed(torch.initial_seed() ^ 0x5DEECE66D)
+        _seed_gen = (torch.initial_seed(), g)
+    return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=_seed_gen[1]).item())
 
 
 def _flops(B, H, L, n_terms, bwd):

@@ -94,7 +94,8 @@ class MiniAttention(nn.Module):
         hd = C // self.num_heads
         qkv = self.qkv(x)
         rq, rk, rv = (_current(m) if m is not None else None for m in (self.rpe_q, self.rpe_k, self.rpe_v))
-        if self.conv_l is None and irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (rq, rk, rv)):
+        if self.conv_l is None and irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (rq, rk, rv),
+                                                     dropout_p=self.attn_drop.p if self.training else 0.0):
             out = irpe_fused.attention(qkv.view(B, N, 3, self.num_heads, hd), self.scale, rq, rk, rv,
                                        dropout_p=self.attn_drop.p if self.training else 0.0)
             return self.proj_drop(self.proj(out))

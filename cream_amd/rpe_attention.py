@@ -71,7 +71,8 @@ class RPEAttention(nn.Module):
         B, N, C = x.shape
         qkv = self.qkv(x)
         hd = C // self.num_heads
-        if irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (self.rpe_q, self.rpe_k, self.rpe_v)):
+        if irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (self.rpe_q, self.rpe_k, self.rpe_v),
+                             dropout_p=self.attn_drop.p if self.training else 0.0):
             # one launch forward, two backward; no (B, H, L, L) tensor exists (csrc/irpe_attn.hip); attn_drop (:86) is
             # applied inside the kernels from a seed
             out = irpe_fused.attention(qkv.view(B, N, 3, self.num_heads, hd), self.scale, self.rpe_q, self.rpe_k,

@@ -497,7 +497,8 @@ typedef struct cream_block_desc {
                                        first F_valid hidden units exist (the fc1 epilogue writes zeros for the rest, which
                                        makes every product over the padded columns vanish); 0: F itself is exact */
     float eps1, eps2, attn_scale;
-    float reserved_f;
+    float reserved_f;             /* MUST be 0: every field of this struct is meaningful or reserved-as-zero — zero-initialise the
+                                     struct (memset / `= {0}`) before filling it; `inference` above was a reserved field until r3 */
     /* bf16 operand copies of the SUPER weights (written by cream_adamw_step), read in place:
      * w* = (out x in) row stride ld_*, w*_t = transposed (in x out) row stride ld_*_t;
      * qkv: three de-interleaved parts [q | k | v], seg_qkv / seg_qkv_t elements apart */

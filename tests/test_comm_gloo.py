@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
     E, depth = cfg["embed_dim"][0], cfg["layer_num"]
     want_bytes = 0
     for n, p in model.named_parameters():
-        r, c = comm.autoformer_active_slice(n, p, cfg)
+        r, c = comm.autoformer_active_slice(n, p, cfg, comm.attention_layout(model))
         want_bytes += 4 * r * c
         g2 = p.grad.reshape(-1, p.shape[-1] if p.dim() > 1 else p.numel())
         if n == "patch_embed_super.proj.weight":
@@ -127,3 +127,46 @@ def test_grad_reducer_world2_gloo():
         assert n_inactive == 3 - depth                          # dead blocks are not sent
         assert sent <= full                                     # (== only for the largest sub-network of the space)
     assert res[0][3] == res[1][3]                               # same sub-network on both ranks
+
+
+def test_active_slice_covers_every_written_gradient_for_each_constructor_flag():
+    """the slice rule must follow the modules — with `change_qkv=False` (the Vision_TransformerSuper default,
+    multihead_super.py:81-84) the qkv output and the projection input are NOT cut by the head count.  For every
+    supported flag combination the gradient outside the announced slice is exactly zero, and a reducer built on the
+    model announces exactly that slice."""
+    import random
+    from cream_amd import comm
+    from cream_amd.autoformer import engine
+    for change_qkv in (True, False):
+        for rel in (True, False):
+            torch.manual_seed(3)
+            embed, heads = (128, 2)
+            model = engine.build_supernet("T", drop_path_rate=0.0, img_size=32, depth=2, embed_dim=embed, num_heads=heads,
+                                          change_qkv=change_qkv, relative_position=rel)
+            # change_qkv=False: head dim = super_embed_dim / sampled heads must equal the tables' 64 (the reference has
+            # the same constraint, multihead_super.py:104-112), so that space cannot vary the head count
+            nh = [1, 1] if change_qkv else [heads, heads]
+            cfg = dict(layer_num=2, embed_dim=[64, 64], num_heads=nh, mlp_ratio=[3.5, 4.0])
+            model.set_sample_config(cfg)
+            x = torch.randn(2, 3, 32, 32)
+            model(x).square().sum().backward()
+            layout = comm.attention_layout(model)
+            assert layout == {0: (change_qkv, embed), 1: (change_qkv, embed)}
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                for lay in (layout, None):                      # None: layout unknown -> attention projections whole
+                    r, c = comm.autoformer_active_slice(n, p, cfg, lay)
+                    g2 = p.grad.reshape(-1, p.shape[-1] if p.dim() > 1 else p.numel())
+                    if n == "patch_embed_super.proj.weight":
+                        g2 = p.grad.reshape(p.shape[0], -1)
+                    assert float(g2[r:].abs().sum()) == 0.0 and float(g2[:, c:].abs().sum()) == 0.0, (change_qkv, rel, n, r, c)
+            if not change_qkv:                                  # the case the old rule got wrong: rows beyond 3 * 64 * heads ARE written
+                g = model.blocks[0].attn.qkv.weight.grad
+                assert float(g[3 * 64:, :64].abs().sum()) > 0.0
+            red = comm.GradReducer(model, world=2)
+            red.prepare(cfg)
+            for b in red.active:
+                sig = [comm.autoformer_active_slice(n, p, cfg, red.layout) for n, p in red.members[b]]
+                assert red.msg[b][3] == sum(r * c for r, c in sig)
+            red.close()

@@ -67,7 +67,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         in_sync = bool(torch.equal(allp[0], allp[1]))
         full = sum(buf.numel() * 4 for b, buf in reducer.flat.items() if not (b.startswith("block") and int(b[5:]) >= cfg["layer_num"]))
         # active-slice messages (csrc/slices.hip on the device): exactly the elements this configuration can write
-        active = sum(4 * r * c for r, c in (comm.autoformer_active_slice(n, p, cfg) for n, p in model.named_parameters()))
+        active = sum(4 * r * c for r, c in (comm.autoformer_active_slice(n, p, cfg, comm.attention_layout(model)) for n, p in model.named_parameters()))
         assert sent == active, (sent, active)
         assert reducer.use_avg == (backend == "nccl")          # RCCL: one AVG all-reduce per message
         q.put((rank, err, in_sync, sent, full, float(loss.detach()), None))
