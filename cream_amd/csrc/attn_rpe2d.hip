@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 
 #include "attn_common.hpp"
 #include "cream_amd.h"
@@ -1435,10 +1437,48 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+#include "attn_rpe2d_bwd1.hpp"
+
+// 1: the one-pass backward (attn_rpe2d_bwd1.hpp) for the AutoFormer geometry in bf16; 0: the two-launch backward.
+// CREAM_ATTN_BWD1 in the environment sets the initial value; cream_attn_rpe2d_bwd_mode() switches it (A/B runs).
+std::atomic<int> g_bwd_onepass{-1};
+int bwd_onepass_mode() {
+    int m = g_bwd_onepass.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_ATTN_BWD1");
+        m = e ? (atoi(e) != 0) : 0;
+        g_bwd_onepass.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+// the side buffer `dlt` of the two-launch path (B*H*64*NP elements, far more than the 32 KB needed) carries the bf16
+// operand images of the four tables
+int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v2::attn_rpe2d_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    BwdArgs aa = a;
+    aa.nitems = B * a.H;
+    short* img = reinterpret_cast<short*>(a.dlt);
+    hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, img, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
+    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    hipLaunchKernelGGL(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, (const short*)img);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 template <typename T>
 int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
-        if (fast_geometry(a.G)) return launch_bwd_impl<T, true>(a, B, st);
+        if (fast_geometry(a.G)) {
+            if (bwd_onepass_mode() && (size_t)B * a.H * 64 * a.NP >= (size_t)v2::IMG_ELEMS) return launch_bwd1(a, B, st);
+            return launch_bwd_impl<T, true>(a, B, st);
+        }
     }
     return launch_bwd_impl<T, false>(a, B, st);
 }
@@ -1453,6 +1493,13 @@ bool geom_ok(int N, int gh, int gw, int mr, int nb) {
 extern "C" {
 
 int cream_attn_rpe2d_padded_len(int N) { return N <= 0 ? 0 : ((N + 31) / 32) * 32; }
+
+int cream_attn_rpe2d_bwd_mode(int onepass)
+{
+    const int prev = bwd_onepass_mode();
+    if (onepass >= 0) g_bwd_onepass.store(onepass != 0, std::memory_order_relaxed);
+    return prev;
+}
 
 int cream_attn_rpe2d_dtab_parts(int B, int H)
 {

@@ -1,0 +1,475 @@
+// attn_rpe2d_bwd1.hpp — ONE-PASS backward of the fused attention for the AutoFormer geometry (N = 197, 14 x 14 grid,
+// max_relative_position 14, bf16).  Included by attn_rpe2d.hip inside its anonymous namespace (uses BwdArgs and the
+// helpers of attn_common.hpp); reference semantics: AutoFormer/model/module/multihead_super.py:133-160, SURVEY App. B.
+//
+// Why one pass.  The two-launch backward (attn_rpe2d_bwd_q / _bwd_kv) computes the score tile and dP twice (38 MFMAs per
+// (query tile, key tile) pair against 26 here), re-reads q, k, v, dO in both launches and hands slot extensions / bucket
+// gradients / delta from the first launch to the second through HBM (354 MB per launch pair against ~155 MB algorithmic).
+// Here one workgroup (7 waves) owns one (b, h) with K, V, Q and dO WHOLE in LDS (4 x 28 KB, XOR-swizzled, no padding),
+// and every wave plays two roles:
+//   * OWNER OF QUERY TILE w ("producer"): in step s it takes key tile j = (w + s) mod 7, computes S^T and dP^T
+//     (12 MFMAs, lanes own queries), P and dS in registers, accumulates dQx^T += Kx_j^T dS^T (6 MFMAs) and publishes
+//     P and dS as two 32 x 32 bf16 tiles in LDS ([query][key] rows);
+//   * OWNER OF KEY TILE w ("consumer"): it picks up the pair of tiles published for its key tile in the previous step
+//     and accumulates dV_w^T += dO^T P and dK_w^T += Q^T dS (8 MFMAs; both operands through ds_read_b64_tr_b16, the
+//     products contract over queries).
+// The rotation (w + s) mod 7 gives every key tile exactly one tile pair per step, so the exchange buffer is 7 slots, and
+// no gradient is ever reduced across waves: dQ lives in its query owner's registers, dK / dV in their key owner's.
+// Everything a launch used to hand to the next one stays on chip: delta, lse and the slot extensions are per-lane
+// registers of the query owner; the bucket gradients dL' go through the exchange slots to the table-gradient jobs.
+// The table gradients are accumulated per workgroup in global memory (read-modify-write by the owning lanes, fixed
+// order: bit-reproducible), so no accumulator registers are pinned across items.
+//
+// LDS (161,280 B, one workgroup per CU):
+//   K | V | Q | dO      4 x [224][64] bf16, 16-byte chunks XOR-swizzled with swz128(row)
+//   OH                  [224][32] bf16 one-hot slot rows of the keys (chunk ^ ((row >> 2) & 3))
+//   7 exchange slots    4608 B each: P tile | dS tile ([32 q][32 keys] bf16, 8-byte columns ^ ((q >> 1) & 7));
+//                       the slot of wave w doubles as its shift scratch ([32][72] bf16) in the item prologue /
+//                       epilogue and carries its dL' tile ([32 q][64 buckets] bf16) to the table-gradient jobs.
+// The bucket tables are read from bf16 operand images in global memory (table_images_kernel below; 32 KB, L2 /
+// L1 resident) — LDS is full.
+#pragma once
+
+namespace v2 {
+
+constexpr int NT = 7, N14 = 197, NP14 = 224, THREADS = 448;
+constexpr int MAT_B = NP14 * 128;                    // one [224][64] bf16 matrix
+constexpr int OFF_K = 0, OFF_V = MAT_B, OFF_Q = 2 * MAT_B, OFF_D = 3 * MAT_B;
+constexpr int OFF_OH = 4 * MAT_B, OH_B = NP14 * 64;
+constexpr int OFF_X = OFF_OH + OH_B;
+constexpr int SLOT_B = 4608, XT_B = 2048;            // slot = P tile | dS tile | pad  (scratch rows: 72 bf16 = 144 B)
+constexpr int LDS_B = OFF_X + NT * SLOT_B;
+constexpr int SCRP = 72;                             // shift scratch pitch (bf16 elements)
+static_assert(LDS_B <= 160 * 1024, "LDS budget");
+static_assert(32 * SCRP * 2 <= SLOT_B, "shift scratch fits the wave's exchange slot");
+
+// image layout (bf16 elements): key rows [64 u'][64 d] | key^T [64 d][64 u'] | value rows | value^T,
+// u' = bucket of the vertical table (0..31) or 32 + bucket of the horizontal table; rows >= nb are zero
+constexpr int IMG_KR = 0, IMG_KT = 4096, IMG_VR = 8192, IMG_VT = 12288, IMG_ELEMS = 16384;
+
+__global__ __launch_bounds__(256) void table_images_kernel(short* img, const float* tkv, const float* tkh, const float* tvv,
+                                                           const float* tvh, int ldt, int nb) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 4096; i += gridDim.x * blockDim.x) {
+        const int pair = i >> 12, e = i & 4095, u2 = e >> 6, d = e & 63, u = u2 & 31;
+        const float* t = pair == 0 ? (u2 < 32 ? tkv : tkh) : (u2 < 32 ? tvv : tvh);
+        const short x = u < nb ? f2bf(t[(int64_t)u * ldt + d]) : (short)0;
+        img[pair * 8192 + u2 * 64 + d] = x;                  // rows
+        img[pair * 8192 + 4096 + d * 64 + u2] = x;           // transposed
+    }
+}
+
+__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(p)));
+}
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 lds_b128(const unsigned char* p) {
+    union { u32x4v v; bf16x8 f; } u;
+    u.v = *reinterpret_cast<const u32x4v*>(p);
+    return u.f;
+}
+__device__ __forceinline__ bf16x8 mk8(const short (&x)[8]) { return bf16x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}; }
+__device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// per-lane LDS offsets (bytes) that do not depend on the tile: computed once per kernel
+struct LaneOffs {
+    int row[4];        // A / B operand rows of a [32][64] tile: lane = row c32, k-step ks -> 16 bytes
+    int ohrow[2];      // the same for a [32][32] one-hot tile
+    int tr[2][2];      // ds_read_b64_tr_b16 of a [32][64] tile: [dt][h] (+ 2048 per k-step of 16 tokens)
+    int ohtr[2];       // the same for a [32][32] one-hot tile     (+ 1024 per k-step)
+    int xr[2];         // the same for an exchange tile            (+ 1024 per k-step)
+    int xw[2][2];      // exchange tile write: [st][h], 8 bytes
+};
+__device__ __forceinline__ LaneOffs lane_offs(int lane) {
+    LaneOffs o;
+    const int c32 = lane & 31, g = lane >> 5, gi = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o.row[ks] = c32 * 128 + (((2 * ks + g) ^ swz128(c32)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) o.ohrow[ks] = c32 * 64 + (((2 * ks + g) ^ ((c32 >> 2) & 3)) << 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rh = 4 * g + (gi >> 2) + 8 * h;                  // token row inside a 16-token k-step
+        const int inner = 8 * (gi & 1), c0 = 2 * (q4 & 1) + ((gi & 3) >> 1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o.tr[dt][h] = rh * 128 + (((4 * dt + c0) ^ swz128(rh)) << 4) + inner;
+        o.ohtr[h] = rh * 64 + ((c0 ^ ((rh >> 2) & 3)) << 4) + inner;
+        o.xr[h] = rh * 64 + (((4 * (q4 & 1) + (gi & 3)) ^ ((rh >> 1) & 7)) << 3);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o.xw[st][h] = c32 * 64 + (((4 * st + 2 * h + g) ^ ((c32 >> 1) & 7)) << 3);
+    }
+    return o;
+}
+
+struct Mat4 { u32x4v v[4]; };                        // 224 x 64 bf16 = 1792 chunks of 16 B / 448 threads
+__device__ __forceinline__ void mat4_load(Mat4& r, const short* src, int64_t rs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * THREADS, row = c >> 3, cc = c & 7;
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (int64_t)min(row, N14 - 1) * rs + cc * 8);
+        r.v[i] = row < N14 ? v : u32x4v{0, 0, 0, 0};
+    }
+}
+__device__ __forceinline__ void mat4_store(const Mat4& r, unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * THREADS, row = c >> 3, cc = c & 7;
+        *reinterpret_cast<u32x4v*>(dst + row * 128 + ((cc ^ swz128(row)) << 4)) = r.v[i];
+    }
+}
+
+// one-hot slot rows of the keys (geometry only): OH[j][c] = 1 iff key j sits in slot c
+__device__ __forceinline__ void fill_onehot_swz(unsigned char* oh) {
+    const RelGeom G{N14, G14, G14, G14};
+    for (int i = threadIdx.x; i < NP14 * 4; i += THREADS) {
+        const int j = i >> 2, cc = i & 3;
+        // keys >= N carry slot 15 (unused by the geometry): the query extension holds -2^15 there, so their
+        // probabilities underflow to exactly 0 without a select per score (slot 15 of every gradient stays exactly 0)
+        const uint32_t m = (key_mask(j, G) | (j >= N14 ? 1u << 15 : 0u)) >> (8 * cc);
+        u32x4v w;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) w[p] = ((m >> (2 * p)) & 1u) * 0x3F80u + ((m >> (2 * p + 1)) & 1u) * 0x3F800000u;
+        *reinterpret_cast<u32x4v*>(oh + j * 64 + ((cc ^ ((j >> 2) & 3)) << 4)) = w;
+    }
+}
+
+// ---- slot <-> bucket shifts through the wave's bf16 scratch ([32 queries][SCRP]) ---------------------------------
+// lookups^T (buckets x queries) of the vertical / horizontal table against this lane's row fragments xb, then the
+// window shift of attn_common.hpp (ext_window14) -> slot extension fragments xe[2] (B operand, lane = query).
+// `rows` = bf16 image [64 u'][64 d] in global memory.  Rounding the lookups to bf16 before the shift gives the same
+// bits as rounding the shifted values (the shift is a permutation); the class-token value is summed in fp32 first.
+// slot15 = raw bf16 placed in the unused slot 15 (0, or -2^15 for the key-side extension: padding-key mask)
+__device__ __forceinline__ void lookups_ext14(bf16x8 (&xe)[2], const bf16x8 (&xb)[4], const short* rows, unsigned char* scr,
+                                              int lane, bool tile0, int qr, int qc, short slot15) {
+    const int c32 = lane & 31, g = lane >> 5;
+    f32x16 av = {}, ah = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 tv = *reinterpret_cast<const bf16x8*>(rows + c32 * 64 + ks * 16 + g * 8);
+        const bf16x8 th = *reinterpret_cast<const bf16x8*>(rows + (32 + c32) * 64 + ks * 16 + g * 8);
+        av = mma16(tv, xb[ks], av);
+        ah = mma16(th, xb[ks], ah);
+    }
+    unsigned char* row = scr + c32 * (SCRP * 2);
+    // buckets acc_row(4i + e, g) = 8i + 4g + e: four consecutive bf16 per store
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<u32x2v*>(row + (8 * i + 4 * g) * 2) =
+            u32x2v{f2bf_pair(av[4 * i], av[4 * i + 1]), f2bf_pair(av[4 * i + 2], av[4 * i + 3])};
+        *reinterpret_cast<u32x2v*>(row + (32 + 8 * i + 4 * g) * 2) =
+            u32x2v{f2bf_pair(ah[4 * i], ah[4 * i + 1]), f2bf_pair(ah[4 * i + 2], ah[4 * i + 3])};
+    }
+    if (g == 0) *reinterpret_cast<float*>(row + 128) = av[0] + ah[0];          // bucket 0 of both tables (fp32)
+    wave_lds_fence();
+    const short cls = f2bf(*reinterpret_cast<const float*>(row + 128));
+    if (tile0) {                                                               // class-token query (attn_common.hpp: ext_fix_query0)
+        if (c32 == 0 && g == 0) {
+            short* r = reinterpret_cast<short*>(row);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { r[15 + u] = cls; r[32 + 15 + u] = 0; }
+        }
+        wave_lds_fence();
+    }
+    const short* r = reinterpret_cast<const short*>(row);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const short* p = r + (kh == 0 ? 15 - qr : 32 + 15 - qc) + 8 * g;
+        short x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = p[e];
+        x[6] = g ? (kh == 0 ? cls : (short)0) : x[6];
+        x[7] = g ? (kh == 0 ? slot15 : (short)0) : x[7];
+        xe[kh] = mk8(x);
+    }
+    wave_lds_fence();
+}
+
+// adjoint: slot tile (accumulator: this lane holds slots acc_row(r, g) of its query) -> the 32 bucket values of table g
+// (0 vertical / 1 horizontal) of this lane's query as four bf16 operand fragments bk[ks] = buckets 8 ks .. 8 ks + 7
+// (attn_common.hpp: slots_to_buckets14; the class-token query's sum is taken in fp32 from the registers)
+__device__ __forceinline__ void slots_to_buckets14_bf16(bf16x8 (&bk)[4], unsigned char* scr, const f32x16& x, int lane,
+                                                        bool tile0, int qr, int qc) {
+    const int c32 = lane & 31, g = lane >> 5;
+    unsigned char* rowb = scr + c32 * (SCRP * 2);
+    short* row = reinterpret_cast<short*>(rowb);
+    {
+        // zero pads: lane group 0 writes [0,14) and [28,42), lane group 1 [56,70) and (again) [28,42)
+        uint32_t* z = reinterpret_cast<uint32_t*>(rowb + (g ? 112 : 0));
+        uint32_t* z2 = reinterpret_cast<uint32_t*>(rowb + 56);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { z[i] = 0u; z2[i] = 0u; }
+    }
+    wave_lds_fence();
+    {
+        // vertical half: slots c = c0 + 4g, c0 = (r & 3) + 8 (r >> 2), r < 8  -> index 14 + c; slot 14 (c0 = 10, g = 1)
+        // is the class-token key slot (index 70), slot 15 is exactly 0
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const int r0 = 2 * rp, c0 = (r0 & 3) + 8 * (r0 >> 2);
+            float lo = x[r0], hi = x[r0 + 1];
+            if (c0 == 10) { lo = g ? 0.f : lo; hi = g ? 0.f : hi; }
+            *reinterpret_cast<uint32_t*>(rowb + (14 + c0 + 4 * g) * 2) = f2bf_pair(lo, hi);
+        }
+        if (g) row[70] = f2bf(x[6]);
+        // horizontal half: slots 16 + c', r >= 8 -> index 42 + c - 16 (slots 30, 31 are exactly 0 and land in the pad)
+#pragma unroll
+        for (int rp = 4; rp < 8; ++rp) {
+            const int r0 = 2 * rp, c0 = (r0 & 3) + 8 * (r0 >> 2);      // 16,18,24,26
+            *reinterpret_cast<uint32_t*>(rowb + (42 - 16 + c0 + 4 * g) * 2) = f2bf_pair(x[r0], x[r0 + 1]);
+        }
+    }
+    wave_lds_fence();
+    short b[32];
+    {
+        const short* p = row + (g ? 28 + qc : qr);
+        b[0] = row[70];
+#pragma unroll
+        for (int u = 1; u < 30; ++u) b[u] = p[u - 1];
+        b[30] = 0;
+        b[31] = 0;
+    }
+    if (tile0) {                                    // class-token query: bucket 0 collects every key (row slots + cls slot)
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += x[r];    // slots 0..15 of the vertical half (slot 15 is exactly 0)
+        sum += __shfl_xor(sum, 32);
+        const bool q0 = c32 == 0;
+        const short s16 = f2bf(sum);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) b[u] = q0 ? (u == 0 ? s16 : (short)0) : b[u];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        bk[ks] = bf16x8{b[8 * ks], b[8 * ks + 1], b[8 * ks + 2], b[8 * ks + 3], b[8 * ks + 4], b[8 * ks + 5], b[8 * ks + 6], b[8 * ks + 7]};
+    wave_lds_fence();                               // the slot is reused by the caller
+}
+
+__global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs a, const short* img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const LaneOffs lo = lane_offs(lane);
+    const int qi = wave * 32 + c32;                  // this lane's query (producer role) and key (consumer role)
+    const bool tok_ok = qi < N14;
+    const int qcl = min(qi, N14 - 1);
+    const int qr = qi > 0 ? (qi - 1) / G14 : 0, qc = qi > 0 ? (qi - 1) - qr * G14 : 0;
+    unsigned char* myslot = smem + OFF_X + wave * SLOT_B;
+    const float sc = a.scale * LOG2E;
+    const int64_t orow = (int64_t)a.H * 64;
+
+    fill_onehot_swz(smem + OFF_OH);
+
+    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        const int b = item / a.H, h = item - b * a.H;
+        const int64_t bh = (int64_t)b * a.H + h;
+        const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
+        const short* qp = reinterpret_cast<const short*>(a.q) + base;
+        const short* kpg = reinterpret_cast<const short*>(a.k) + base;
+        const short* vpg = reinterpret_cast<const short*>(a.v) + base;
+        const short* dop = reinterpret_cast<const short*>(a.dout) + ((int64_t)b * N14 * a.H + h) * 64;
+        const short* outp = reinterpret_cast<const short*>(a.out) + ((int64_t)b * N14 * a.H + h) * 64;
+
+        // ---- the item's four matrices -> LDS -----------------------------------------------------------------
+        {
+            Mat4 mk, mv, mq, md;
+            mat4_load(mk, kpg, a.sn);
+            mat4_load(mv, vpg, a.sn);
+            mat4_load(mq, qp, a.sn);
+            mat4_load(md, dop, orow);
+            __syncthreads();                         // previous item: table-gradient jobs are done with Q, dO and the slots
+            mat4_store(mk, smem + OFF_K);
+            mat4_store(mv, smem + OFF_V);
+            mat4_store(mq, smem + OFF_Q);
+            mat4_store(md, smem + OFF_D);
+        }
+        // this lane's row of O (for delta) and the softmax statistics travel meanwhile
+        bf16x8 ob[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(outp + (int64_t)qcl * orow + ks * 16 + g * 8);
+        const float m2 = tok_ok ? a.lse[bh * N14 + qi] * LOG2E : INFINITY;     // padding queries: P = 0
+        __syncthreads();
+
+        // ---- query-owner prologue: delta, slot extensions of q and dO ----------------------------------------
+        bf16x8 qe[2], de[2];
+        float dsc;                                   // scale * delta_i
+        {
+            bf16x8 qb[4], dob[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qb[ks] = lds_b128(smem + OFF_Q + wave * 4096 + lo.row[ks]);
+                dob[ks] = lds_b128(smem + OFF_D + wave * 4096 + lo.row[ks]);
+            }
+            float delta = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) delta += bf2f(dob[ks][e]) * bf2f(ob[ks][e]);
+            delta += __shfl_xor(delta, 32);
+            dsc = tok_ok ? delta * a.scale : 0.f;
+            lookups_ext14(qe, qb, img + IMG_KR, myslot, lane, wave == 0, qr, qc, (short)0xC700);
+            lookups_ext14(de, dob, img + IMG_VR, myslot, lane, wave == 0, qr, qc, (short)0);
+        }
+
+        f32x16 dq[2] = {f32x16{}, f32x16{}}, dx = {};
+        f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
+
+        // consumer: the tile pair published for key tile `wave` by the owner of query tile qt
+        auto consume = [&](int qt) {
+            const unsigned char* xp = myslot;                               // P tile, then dS tile
+            const unsigned char* dt_ = smem + OFF_D + qt * 4096;
+            const unsigned char* qt_ = smem + OFF_Q + qt * 4096;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pb = tr_pair(xp + st * 1024 + lo.xr[0], xp + st * 1024 + lo.xr[1]);
+                const bf16x8 db = tr_pair(xp + XT_B + st * 1024 + lo.xr[0], xp + XT_B + st * 1024 + lo.xr[1]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = mma16(tr_pair(dt_ + st * 2048 + lo.tr[dt][0], dt_ + st * 2048 + lo.tr[dt][1]), pb, dv[dt]);
+                    dk[dt] = mma16(tr_pair(qt_ + st * 2048 + lo.tr[dt][0], qt_ + st * 2048 + lo.tr[dt][1]), db, dk[dt]);
+                }
+            }
+        };
+
+#pragma unroll 1
+        for (int s = 0; s < NT; ++s) {
+            const int j = wave + s < NT ? wave + s : wave + s - NT;         // this step's key tile (wave-uniform)
+            // tiles published in step s - 1 for key tile `wave` come from the owner of query tile (wave - (s - 1)) mod 7
+            if (s > 0) consume(wave - (s - 1) >= 0 ? wave - (s - 1) : wave - (s - 1) + NT);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- producer: S^T and dP^T of (key tile j, query tile wave) ---------------------------------------
+            const unsigned char* kt = smem + OFF_K + j * 4096;
+            const unsigned char* vt = smem + OFF_V + j * 4096;
+            const unsigned char* oh = smem + OFF_OH + j * 2048;
+            const unsigned char* qrow = smem + OFF_Q + wave * 4096;
+            const unsigned char* drow = smem + OFF_D + wave * 4096;
+            f32x16 sacc = {}, pacc = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = mma16(lds_b128(kt + lo.row[ks]), lds_b128(qrow + lo.row[ks]), sacc);
+                pacc = mma16(lds_b128(vt + lo.row[ks]), lds_b128(drow + lo.row[ks]), pacc);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 o1 = lds_b128(oh + lo.ohrow[ks]);
+                sacc = mma16(o1, qe[ks], sacc);
+                pacc = mma16(o1, de[ks], pacc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // P = exp2(S sc - m2), dS = P (dP scale - delta scale); keys >= N: P = 0 through slot 15 (fill_onehot_swz)
+            uint32_t pw[8], dw[8];                   // bf16 pairs: operand fragments AND the published tiles
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m2));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r + 1], sc, -m2));
+                pw[r >> 1] = f2bf_pair(p0, p1);
+                dw[r >> 1] = f2bf_pair(p0 * __builtin_fmaf(pacc[r], a.scale, -dsc), p1 * __builtin_fmaf(pacc[r + 1], a.scale, -dsc));
+            }
+            bf16x8 pb[2], db[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                pb[st] = __builtin_bit_cast(bf16x8, (u32x4v{pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]}));
+                db[st] = __builtin_bit_cast(bf16x8, (u32x4v{dw[4 * st], dw[4 * st + 1], dw[4 * st + 2], dw[4 * st + 3]}));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // dQx^T += Kx_j^T dS^T
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                dq[0] = mma16(tr_pair(kt + st * 2048 + lo.tr[0][0], kt + st * 2048 + lo.tr[0][1]), db[st], dq[0]);
+                dq[1] = mma16(tr_pair(kt + st * 2048 + lo.tr[1][0], kt + st * 2048 + lo.tr[1][1]), db[st], dq[1]);
+                dx = mma16(tr_pair(oh + st * 1024 + lo.ohtr[0], oh + st * 1024 + lo.ohtr[1]), db[st], dx);
+            }
+            __syncthreads();                         // every consumer has read the tiles of step s - 1
+            // publish P and dS for the owner of key tile j: [32 q][32 keys], lane = query row, four runs of 4 keys
+            {
+                unsigned char* xs = smem + OFF_X + j * SLOT_B;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        *reinterpret_cast<u32x2v*>(xs + lo.xw[st][hh]) = u32x2v{pw[4 * st + 2 * hh], pw[4 * st + 2 * hh + 1]};
+                        *reinterpret_cast<u32x2v*>(xs + XT_B + lo.xw[st][hh]) = u32x2v{dw[4 * st + 2 * hh], dw[4 * st + 2 * hh + 1]};
+                    }
+            }
+            __syncthreads();
+        }
+        consume(wave + 1 < NT ? wave + 1 : 0);       // step 6's tiles: query tile (wave - 6) mod 7
+
+        // ---- epilogue ------------------------------------------------------------------------------------------
+        if (tok_ok) {                                // key-owner results: rows of dK, dV
+            const int64_t off = (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh;
+            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dk) + off, dk, g);
+            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dv) + off, dv, g);
+        }
+        {
+            bf16x8 bk[4];
+            slots_to_buckets14_bf16(bk, myslot, dx, lane, wave == 0, min(qr, G14 - 1), qc);
+            // dq^T += [Tkv; Tkh]^T dL'^T : lane group g supplies the buckets of table g (order of the contraction index is free)
+            const short* kt_img = img + IMG_KT;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = mma16(*reinterpret_cast<const bf16x8*>(kt_img + (c32 + 32 * dt) * 64 + g * 32 + ks * 8), bk[ks], dq[dt]);
+            // dL' tile [32 q][64 u'] for the table-gradient jobs (chunks 4g + ks of row q)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { bf16x8 f; u32x4v v; } u;
+                u.f = bk[ks];
+                *reinterpret_cast<u32x4v*>(myslot + c32 * 128 + (((4 * g + ks) ^ swz128(c32)) << 4)) = u.v;
+            }
+        }
+        if (tok_ok)
+            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dq) + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh, dq, g);
+        __syncthreads();                             // all dL' tiles are in place
+
+        // ---- table gradients: job = tab * 2 + dt;  dT^T (64 d x 32 u) = X^T (d x q) . R (q x u)
+        //      tab 0 / 1: X = Q, R = dL' (vertical / horizontal);  tab 2 / 3: X = dO, R = S' (bucket sums of the forward)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int job = wave + jj * NT;
+            if (job < 8) {
+                const int tab = job >> 1, dt = job & 1;
+                f32x16 acc = {};
+                const unsigned char* xbase = smem + (tab < 2 ? OFF_Q : OFF_D);
+                const short* spr = reinterpret_cast<const short*>(a.sp) + (bh * 64 + (tab & 1) * 32 + c32) * NP14;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const unsigned char* xt = xbase + t * 4096 + st * 2048;
+                        const bf16x8 xa = tr_pair(xt + lo.tr[dt][0], xt + lo.tr[dt][1]);
+                        bf16x8 rb;
+                        if (tab < 2) {
+                            const unsigned char* dl = smem + OFF_X + t * SLOT_B + st * 2048;
+                            rb = tr_pair(dl + lo.tr[tab & 1][0], dl + lo.tr[tab & 1][1]);
+                        } else {
+                            rb = Tr<hip_bfloat16>::load_perm(spr + t * 32, st, g);
+                        }
+                        acc = mma16(xa, rb, acc);
+                    }
+                }
+                // lane = bucket u (column), registers = d rows; partial of THIS workgroup, accumulated over its items
+                float* dst = a.dtab + (((int64_t)blockIdx.x * 4 + tab) * 32 + c32) * 64 + dt * 32;
+                const bool first = item == (int)blockIdx.x;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4v v = f32x4v{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                    float* d4 = dst + 8 * r4 + 4 * g;
+                    if (!first) {
+                        const f32x4v old = *reinterpret_cast<const f32x4v*>(d4);
+                        v = f32x4v{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+                    }
+                    *reinterpret_cast<f32x4v*>(d4) = v;
+                }
+            }
+        }
+    }   // items
+}
+
+}  // namespace v2

@@ -88,6 +88,14 @@ int cream_attn_rpe2d_padded_len(int N);
  * one per persistent workgroup of its dK/dV kernel, min(B*H, compute units). */
 int cream_attn_rpe2d_dtab_parts(int B, int H);
 
+/* Which backward runs for the AutoFormer geometry (N = 197, 14 x 14 grid, max_relative_position 14) in bf16:
+ * 1 = the one-pass kernel (csrc/attn_rpe2d_bwd1.hpp: K, V, Q, dO of one (b, h) whole in LDS, P / dS exchanged between
+ * the query-tile and key-tile owners through LDS; the side buffers dlt / qe / de / delta are not used as such —
+ * the first 32 KB of dlt carry the bf16 operand images of the tables), 0 = the two-launch backward.  onepass < 0
+ * only queries.  Returns the previous setting; the initial one comes from CREAM_ATTN_BWD1 in the environment.
+ * (What autograd derives for multihead_super.py:135-154 either way; a switch for same-box A/B measurements.) */
+int cream_attn_rpe2d_bwd_mode(int onepass);
+
 /* The attention core of AttentionSuper.forward between the qkv and proj GEMMs
  * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
  * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
