@@ -21,7 +21,7 @@ Extra objects on the line:
                   from the committed rocprofv3 PMC passes under profiles/ (counters cannot be read in-process);
   rpe_index_config4 — the rpe_index gather / scatter-add at BASELINE config 4 (B=64, H=12, L=577, 50 buckets), fp32 and
                   bf16: algorithmic GB/s and fraction of the 8 TB/s HBM peak (HIP events, median of 20 launches);
-  roofline_step — whole-step algorithmic rate: 28.6 GFLOP per image (SURVEY 8d) x images/s / 2.5 PF;
+  roofline_step — whole-step algorithmic rate: FLOPs of the sub-networks sampled in the timed region (SURVEY 8d formula) / time / 2.5 PF;
   per_embed_dim — mean GPU ms per step by sampled embed dim (events between steps, no host sync);
   host_unstalled — the same step at batch 4 (host-bound: same launches, ~30x less device work): what the host needs to
                   enqueue a step when the launch queue is never full (`host_enqueue_ms_per_step` of the timed region
@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the tiny-batch pass that measures the unstalled host cost of a step")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-wgrad-stream", action="store_true", help="weight-gradient GEMMs on the main stream")
+    ap.add_argument("--comm-mode", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (all 7 xGMI links at once)")
     ap.add_argument("--subnet", default=None, choices=["T", "S"],
                     help="train ONE fixed published sub-network of that supernet (BASELINE config 2: T)")
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
@@ -90,6 +92,19 @@ SUBNETS = {
               mlp_ratio=[3.0, 3.5, 3.0, 3.5, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 3.5, 4.0],
               num_heads=[6, 6, 5, 7, 5, 5, 5, 6, 6, 7, 7, 6, 7]),
 }
+
+
+def step_flops_per_image(cfg, n_tokens=197, patch_in=768, num_classes=1000):
+    """Algorithmic FLOPs of ONE train step per image for a sampled sub-network: forward =
+    2*196*768*E (patch) + sum over layers [2 N E 3Q (qkv) + 4 H N^2 64 (QK^T, PV) + 4 N Q 60 (bucketed RPE, both sides)
+    + 2 N Q E (proj) + 4 N E F (fc1 + fc2)] + 2 E 1000 (head), Q = 64 H, F = int(E R); train = 3 x forward."""
+    N, E = n_tokens, cfg["embed_dim"][0]
+    f = 2.0 * (N - 1) * patch_in * E + 2.0 * E * num_classes
+    for i in range(cfg["layer_num"]):
+        H = cfg["num_heads"][i]
+        Q, F = 64 * H, int(E * cfg["mlp_ratio"][i])
+        f += 2.0 * N * E * 3 * Q + 4.0 * H * N * N * 64 + 4.0 * N * Q * 60 + 2.0 * N * Q * E + 4.0 * N * E * F
+    return 3.0 * f
 
 
 def cpu_model():
@@ -137,10 +152,62 @@ def cpu_irpe_leg(seconds, threads=0):
                        "gather; oracle/irpe_oracle.py)")
 
 
+REFERENCE_AUTOFORMER = "/root/reference/AutoFormer"
+
+
+def cpu_baseline_reference(size, seconds, threads=0, B=64):
+    """kind "reference": the reference's OWN modules (AutoFormer/model/supernet_transformer.py Vision_TransformerSuper and
+    supernet_engine.py sample_configs, imported read-only through tests/refshim.py) doing the step on the host cores —
+    only where the reference checkout exists (the build container; the GPU box has none and times the port).  The loss
+    and the optimizer are torch's (timm is not vendored): soft-target CE and AdamW as in cpu_baseline."""
+    import random
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import refshim
+    from cream_amd.autoformer import engine
+    if threads > 0:
+        torch.set_num_threads(threads)
+    ns = refshim.load_autoformer_reference()
+    sample_configs = refshim.reference_sample_configs()
+    space = engine.SEARCH_SPACES[size]
+    torch.manual_seed(0)
+    model = ns.Vision_TransformerSuper(img_size=224, patch_size=16, embed_dim=space["embed_dim"], depth=space["depth"],
+                                       num_heads=space["num_heads"], mlp_ratio=space["mlp_ratio"], qkv_bias=True, drop_rate=0.0,
+                                       drop_path_rate=0.0, gp=True, num_classes=1000, max_relative_position=14,
+                                       relative_position=True, change_qkv=True, abs_pos=True).float()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4 * B / 512, weight_decay=0.05)
+    images = torch.randn(B, 3, 224, 224)
+    target = torch.zeros(B, 1000).scatter_(1, torch.randint(0, 1000, (B, 1)), 1.0)
+    random.seed(0)
+    n, t0, elapsed = 0, None, 0.0
+    while True:
+        cfg = sample_configs(choices=space["choices"])
+        model.set_sample_config(config=cfg)
+        opt.zero_grad(set_to_none=False)
+        loss = torch.sum(-target * torch.nn.functional.log_softmax(model(images), dim=-1), dim=-1).mean()
+        loss.backward()
+        opt.step()
+        if t0 is None:
+            t0 = time.perf_counter()
+            continue
+        n += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= seconds or n >= 50:
+            break
+    return dict(value=round(n * B / elapsed, 2), unit="images/sec", cores=torch.get_num_threads(), kind="reference",
+                sample=f"{n} AutoFormer-{size} supernet steps of batch {B} (fp32) on the reference's own Vision_TransformerSuper + "
+                       "sample_configs (imported read-only via tests/refshim.py); soft-target CE / AdamW from torch (timm not vendored)")
+
+
 def cpu_baseline(size, seconds, threads=0, B=64):
     """Reference step restated on the CPU (oracle/autoformer_oracle.py), fp32, `threads` intra-op
     threads (0 = torch's default = all cores), batch B, random sub-networks from the same draw
-    sequence, AdamW over the full supernet.  Bounded: warm-up 1 step, then steps until `seconds`."""
+    sequence, AdamW over the full supernet.  Bounded: warm-up 1 step, then steps until `seconds`.
+    Where the reference checkout exists its own modules are timed instead (cpu_baseline_reference)."""
+    if os.path.isdir(REFERENCE_AUTOFORMER) and os.environ.get("CREAM_CPU_BASELINE", "") != "port":
+        try:
+            return cpu_baseline_reference(size, seconds, threads, B)
+        except Exception as e:                   # (an import shim that no longer fits): the port still gives a line
+            sys.stderr.write(f"[bench] reference CPU leg failed ({e}); timing the port\n")
     import random
     from oracle import autoformer_oracle as AO
     from cream_amd.autoformer import engine
@@ -420,7 +487,7 @@ def main():
         if hasattr(m, "attention_impl"):
             m.attention_impl = a.impl
     opt = engine.build_optimizer(model, lr=5e-4, batch_size=a.batch, world_size=world)
-    reducer = comm.GradReducer(model)
+    reducer = comm.GradReducer(model, mode=a.comm_mode)
     amp = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     trainer = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES[a.supernet]["choices"], reducer, amp_dtype=amp)
     if a.subnet:                                              # BASELINE config 2: one fixed sub-network
@@ -450,11 +517,13 @@ def main():
         loss = trainer.step(images, target)
     sync()
     marks, dims = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)], []
+    flops_timed = 0.0                        # algorithmic FLOPs per image summed over the configs ACTUALLY sampled in the timed region
     t0 = time.perf_counter()
     for i in range(a.steps):
         marks[i].record()                    # (asynchronous: no host sync inside the timed region)
         loss = trainer.step(images, target)
         dims.append(trainer.config["embed_dim"][0])
+        flops_timed += step_flops_per_image(trainer.config)
     marks[a.steps].record()
     t_issue = time.perf_counter() - t0       # host time to ENQUEUE the steps (== dt when launch-bound)
     sync()
@@ -567,13 +636,21 @@ def main():
                        "comm": {"world": world, "backend": (dist.get_backend() if dist.is_initialized() else "none"),
                                 "devices": devices, "grad_bytes_per_step_last": reducer.bytes_sent,
                                 "grad_bytes_full_buckets": int(reducer.arena.numel() * 4),
-                                "message": "active slices of the sampled sub-network per block bucket (csrc/slices.hip), side stream"},
+                                "message": "active slices of the sampled sub-network per block bucket (csrc/slices.hip), side stream",
+                                "mode": a.comm_mode,
+                                # what RCCL was told (unset = library defaults): read a SCALE record against these
+                                "rccl_env": {k: os.environ[k] for k in sorted(os.environ)
+                                             if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG")}},
                        "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp), no vendor GEMM library"},
             "roofline": roof,
-            "roofline_step": ({"achieved": round(28.6e9 * ips / world / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(28.6e9 * ips / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-                               "flops_per_image": "28.6 GFLOP (3 x 9.53 fwd, mean over the S search space, SURVEY 8d)"}
-                              if a.supernet == "S" and not a.subnet and a.dtype == "bf16" else None),
+            # whole-step algorithmic rate PER GPU from the FLOPs of the sub-networks actually sampled in the timed region
+            # (SURVEY 8d formula, step_flops_per_image), not from the search-space mean
+            "roofline_step": ({"achieved": round(flops_timed * a.batch / dt / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(flops_timed * a.batch / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "gflop_per_image_timed_mean": round(flops_timed / a.steps / 1e9, 2),
+                               "flops_per_image": "sum over the timed steps of 3 x forward FLOPs of the sampled config (SURVEY 8d); "
+                                                  "search-space mean for reference: 28.6 GFLOP"}
+                              if a.dtype == "bf16" else None),
             "per_embed_dim": per_e,
             "parity_unpinned": "AdamW parameter-group rule, soft-target CE, Mixup (timm, not vendored in the reference)",
             "cpu_baseline": cpu,

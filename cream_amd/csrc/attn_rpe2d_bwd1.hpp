@@ -30,6 +30,34 @@
 // L1 resident) — LDS is full.
 #pragma once
 
+// phase stamps for tools/probes/attn_bwd1_probe.hip (compiled out of the library): 20 slots per wave
+#ifdef ATTN_PROFILE
+#define V2_PROF_DECL long long prof_t[20]; int prof_n = 0;
+#define V2_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0 && g_attn_prof) { \
+        long long* d_ = g_attn_prof + ((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 20; \
+        for (int i_ = 0; i_ < 20; ++i_) d_[i_] = i_ < prof_n ? prof_t[i_] : 0; } } while (0)
+#else
+#define V2_PROF_DECL
+#define V2_PROF_FLUSH() do {} while (0)
+#endif
+#ifdef ATTN_PROFILE_STEPS                    // sub-phase stamps inside step 3 of the one-pass backward
+#define PROF_STEP(s) do { if ((s) == 3) PROF_MARK(); } while (0)
+#else
+#define PROF_STEP(s) do {} while (0)
+#endif
+
+#ifndef BWD1_PREFETCH
+#define BWD1_PREFETCH 0
+#endif
+// timing experiments of tools/probes/attn_bwd1_probe.hip (results are WRONG with either switch): leave out the global
+// stores of dq / dk / dv, or the loads of the next item's matrices (the LDS keeps the first item's)
+#ifndef BWD1_EXP_NOSTORE
+#define BWD1_EXP_NOSTORE 0
+#endif
+#ifndef BWD1_EXP_NOLOAD
+#define BWD1_EXP_NOLOAD 0
+#endif
+
 namespace v2 {
 
 constexpr int NT = 7, N14 = 197, NP14 = 224, THREADS = 448;
@@ -38,7 +66,8 @@ constexpr int OFF_K = 0, OFF_V = MAT_B, OFF_Q = 2 * MAT_B, OFF_D = 3 * MAT_B;
 constexpr int OFF_OH = 4 * MAT_B, OH_B = NP14 * 64;
 constexpr int OFF_X = OFF_OH + OH_B;
 constexpr int SLOT_B = 4608, XT_B = 2048;            // slot = P tile | dS tile | pad  (scratch rows: 72 bf16 = 144 B)
-constexpr int LDS_B = OFF_X + NT * SLOT_B;
+constexpr int OFF_SINK = OFF_X + NT * SLOT_B;        // 1 KB landing zone of the L2 prefetch (never read)
+constexpr int LDS_B = OFF_SINK + 1024;
 constexpr int SCRP = 72;                             // shift scratch pitch (bf16 elements)
 static_assert(LDS_B <= 160 * 1024, "LDS budget");
 static_assert(32 * SCRP * 2 <= SLOT_B, "shift scratch fits the wave's exchange slot");
@@ -107,19 +136,43 @@ __device__ __forceinline__ LaneOffs lane_offs(int lane) {
     return o;
 }
 
+__device__ __forceinline__ void launder_offs(LaneOffs& o) {
+    int* p = reinterpret_cast<int*>(&o);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(LaneOffs) / sizeof(int)); ++i) asm volatile("" : "+v"(p[i]));
+}
+
+// workgroup barrier for LDS traffic only: ds operations are retired (lgkmcnt), global loads and the prefetch DMA stay in
+// flight across it (__syncthreads() would also drain vmcnt)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// one 1 KB global -> LDS DMA read (16 bytes per lane, LDS destination = wave-uniform `lds_dst` + 16 lane) as INLINE ASM:
+// hipcc orders every later ds_read behind a builtin LDS-DMA with s_waitcnt vmcnt(0) (it is a pending LDS write), which
+// would drain the prefetch at every step; an asm statement is outside its bookkeeping (cdna_hip_programming.md 5.7).
+// Nothing ever reads the destination, so no wait belongs to it; M0 is restored.
+__device__ __forceinline__ void prefetch_dma(const short* src, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst));
+}
+
 struct Mat4 { u32x4v v[4]; };                        // 224 x 64 bf16 = 1792 chunks of 16 B / 448 threads
-__device__ __forceinline__ void mat4_load(Mat4& r, const short* src, int64_t rs) {
+__device__ __forceinline__ void mat4_load(Mat4& r, const short* src, int64_t rs, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = threadIdx.x + i * THREADS, row = c >> 3, cc = c & 7;
+        const int c = tid + i * THREADS, row = c >> 3, cc = c & 7;
         const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (int64_t)min(row, N14 - 1) * rs + cc * 8);
         r.v[i] = row < N14 ? v : u32x4v{0, 0, 0, 0};
     }
 }
-__device__ __forceinline__ void mat4_store(const Mat4& r, unsigned char* dst) {
+__device__ __forceinline__ void mat4_store(const Mat4& r, unsigned char* dst, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = threadIdx.x + i * THREADS, row = c >> 3, cc = c & 7;
+        const int c = tid + i * THREADS, row = c >> 3, cc = c & 7;
         *reinterpret_cast<u32x4v*>(dst + row * 128 + ((cc ^ swz128(row)) << 4)) = r.v[i];
     }
 }
@@ -144,18 +197,11 @@ __device__ __forceinline__ void fill_onehot_swz(unsigned char* oh) {
 // window shift of attn_common.hpp (ext_window14) -> slot extension fragments xe[2] (B operand, lane = query).
 // `rows` = bf16 image [64 u'][64 d] in global memory.  Rounding the lookups to bf16 before the shift gives the same
 // bits as rounding the shifted values (the shift is a permutation); the class-token value is summed in fp32 first.
-// slot15 = raw bf16 placed in the unused slot 15 (0, or -2^15 for the key-side extension: padding-key mask)
-__device__ __forceinline__ void lookups_ext14(bf16x8 (&xe)[2], const bf16x8 (&xb)[4], const short* rows, unsigned char* scr,
-                                              int lane, bool tile0, int qr, int qc, short slot15) {
+// one lookup set -> scratch -> window shift (attn_common.hpp: ext_window14).  slot15 = raw bf16 placed in the unused slot 15
+// (0, or -2^15 for the key-side extension: padding-key mask)
+__device__ __forceinline__ void ext_from_lookups14(bf16x8 (&xe)[2], const f32x16& av, const f32x16& ah, unsigned char* scr, int lane,
+                                                   bool tile0, int qr, int qc, short slot15) {
     const int c32 = lane & 31, g = lane >> 5;
-    f32x16 av = {}, ah = {};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 tv = *reinterpret_cast<const bf16x8*>(rows + c32 * 64 + ks * 16 + g * 8);
-        const bf16x8 th = *reinterpret_cast<const bf16x8*>(rows + (32 + c32) * 64 + ks * 16 + g * 8);
-        av = mma16(tv, xb[ks], av);
-        ah = mma16(th, xb[ks], ah);
-    }
     unsigned char* row = scr + c32 * (SCRP * 2);
     // buckets acc_row(4i + e, g) = 8i + 4g + e: four consecutive bf16 per store
 #pragma unroll
@@ -188,6 +234,34 @@ __device__ __forceinline__ void lookups_ext14(bf16x8 (&xe)[2], const bf16x8 (&xb
         xe[kh] = mk8(x);
     }
     wave_lds_fence();
+}
+
+// slot extensions of q (key tables) and of dO (value tables): lookups^T (buckets x queries) of the vertical / horizontal
+// table against this lane's row fragments, then the window shifts through the wave's scratch.  `img` = the bf16 images
+// in global memory; all 16 row fragments are requested before the first MFMA.  Rounding the lookups to bf16 before the
+// shift gives the same bits as rounding the shifted values (the shift is a permutation); the class-token value is
+// summed in fp32 first.
+__device__ __forceinline__ void lookups_ext14_pair(bf16x8 (&qe)[2], bf16x8 (&de)[2], const bf16x8 (&qb)[4], const bf16x8 (&dob)[4],
+                                                   const short* img, unsigned char* scr, int lane, bool tile0, int qr, int qc) {
+    const int c32 = lane & 31, g = lane >> 5;
+    bf16x8 tk[2][4], tv[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            tk[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_KR + (32 * t + c32) * 64 + ks * 16 + g * 8);
+            tv[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_VR + (32 * t + c32) * 64 + ks * 16 + g * 8);
+        }
+    f32x16 kv = {}, kh = {}, vv = {}, vh = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kv = mma16(tk[0][ks], qb[ks], kv);
+        kh = mma16(tk[1][ks], qb[ks], kh);
+        vv = mma16(tv[0][ks], dob[ks], vv);
+        vh = mma16(tv[1][ks], dob[ks], vh);
+    }
+    ext_from_lookups14(qe, kv, kh, scr, lane, tile0, qr, qc, (short)0xC700);
+    ext_from_lookups14(de, vv, vh, scr, lane, tile0, qr, qc, (short)0);
 }
 
 // adjoint: slot tile (accumulator: this lane holds slots acc_row(r, g) of its query) -> the 32 bucket values of table g
@@ -250,50 +324,113 @@ __device__ __forceinline__ void slots_to_buckets14_bf16(bf16x8 (&bk)[4], unsigne
     wave_lds_fence();                               // the slot is reused by the caller
 }
 
+// accumulator tile (lane = token row c32 of this wave's 32-token tile, 64 d-values) -> global rows, COALESCED: the tile goes
+// through a wave-private 4 KB LDS stage ([32][128 B], chunks ^ swz128) and leaves as whole 128-byte rows (8 lanes x 16 B
+// per row, 8 rows per wave instruction).  Storing straight from the accumulator layout (a lane owns a row, 32 rows at a
+// 2.3 KB stride per instruction, 32 bytes each) made the write-back of dq / dk / dv the slowest phase of an item: vmcnt
+// retires in order, so the first load consumer behind those stores waited ~20k cycles for them (ablation in
+// tools/probes/attn_bwd1_probe: an item 81k -> 52k cycles without the stores).
+// The two lane groups of a row hold alternating runs of 4 d-values; one v_permlane32_swap per dword pairs them up into
+// 16-byte pieces (cdna_hip_programming.md T21).  `tile_row0` = first token of the tile; rows >= N14 are not written.
+__device__ __forceinline__ void store_tile_staged(unsigned char* stage, short* gbase, int64_t rs, int tile_row0,
+                                                  const f32x16 (&o)[2], int lane) {
+    const int c32 = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+            uint32_t ax = f2bf_pair(o[dt][4 * k], o[dt][4 * k + 1]), ay = f2bf_pair(o[dt][4 * k + 2], o[dt][4 * k + 3]);
+            uint32_t bx = f2bf_pair(o[dt][4 * k + 4], o[dt][4 * k + 5]), by = f2bf_pair(o[dt][4 * k + 6], o[dt][4 * k + 7]);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            // lanes 0-31: [own run k | partner's run k] = d 8k .. 8k+7 (chunk 4 dt + k);  lanes 32-63: chunk 4 dt + k + 1
+            *reinterpret_cast<u32x4v*>(stage + c32 * 128 + (((4 * dt + k + g) ^ swz128(c32)) << 4)) = u32x4v{rx[0], ry[0], rx[1], ry[1]};
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + (lane >> 3), cc = lane & 7;
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(stage + row * 128 + ((cc ^ swz128(row)) << 4));
+        if (tile_row0 + row < N14) *reinterpret_cast<u32x4v*>(gbase + (int64_t)row * rs + cc * 8) = v;
+    }
+    wave_lds_fence();                               // the stage may be rewritten by the caller
+}
+
 __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs a, const short* img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
-    const LaneOffs lo = lane_offs(lane);
-    const int qi = wave * 32 + c32;                  // this lane's query (producer role) and key (consumer role)
-    const bool tok_ok = qi < N14;
-    const int qcl = min(qi, N14 - 1);
-    const int qr = qi > 0 ? (qi - 1) / G14 : 0, qc = qi > 0 ? (qi - 1) - qr * G14 : 0;
-    unsigned char* myslot = smem + OFF_X + wave * SLOT_B;
     const float sc = a.scale * LOG2E;
     const int64_t orow = (int64_t)a.H * 64;
 
+    struct Item {
+        const short *qp, *kpg, *vpg, *dop, *outp;
+        int64_t bh;
+        int b, h;
+    };
+    auto item_of = [&](int item) {
+        Item I;
+        I.b = item / a.H;
+        I.h = item - I.b * a.H;
+        I.bh = (int64_t)I.b * a.H + I.h;
+        const int64_t base = (int64_t)I.b * a.sb + (int64_t)I.h * a.sh;
+        I.qp = reinterpret_cast<const short*>(a.q) + base;
+        I.kpg = reinterpret_cast<const short*>(a.k) + base;
+        I.vpg = reinterpret_cast<const short*>(a.v) + base;
+        I.dop = reinterpret_cast<const short*>(a.dout) + ((int64_t)I.b * N14 * a.H + I.h) * 64;
+        I.outp = reinterpret_cast<const short*>(a.out) + ((int64_t)I.b * N14 * a.H + I.h) * 64;
+        return I;
+    };
+
     fill_onehot_swz(smem + OFF_OH);
 
-    for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
-        const int b = item / a.H, h = item - b * a.H;
-        const int64_t bh = (int64_t)b * a.H + h;
-        const int64_t base = (int64_t)b * a.sb + (int64_t)h * a.sh;
-        const short* qp = reinterpret_cast<const short*>(a.q) + base;
-        const short* kpg = reinterpret_cast<const short*>(a.k) + base;
-        const short* vpg = reinterpret_cast<const short*>(a.v) + base;
-        const short* dop = reinterpret_cast<const short*>(a.dout) + ((int64_t)b * N14 * a.H + h) * 64;
-        const short* outp = reinterpret_cast<const short*>(a.out) + ((int64_t)b * N14 * a.H + h) * 64;
-
-        // ---- the item's four matrices -> LDS -----------------------------------------------------------------
-        {
-            Mat4 mk, mv, mq, md;
-            mat4_load(mk, kpg, a.sn);
-            mat4_load(mv, vpg, a.sn);
-            mat4_load(mq, qp, a.sn);
-            mat4_load(md, dop, orow);
-            __syncthreads();                         // previous item: table-gradient jobs are done with Q, dO and the slots
-            mat4_store(mk, smem + OFF_K);
-            mat4_store(mv, smem + OFF_V);
-            mat4_store(mq, smem + OFF_Q);
-            mat4_store(md, smem + OFF_D);
-        }
-        // this lane's row of O (for delta) and the softmax statistics travel meanwhile
-        bf16x8 ob[4];
+    // ---- software pipeline over the workgroup's items: the NEXT item's operands are requested during the epilogue of
+    // the current one (K, V as soon as the step loop is over — their LDS regions are dead then —, Q, dO, this lane's
+    // row of O and its softmax statistic before the table-gradient jobs), so an item starts with its loads landed.
+    // All workgroups of a launch run in lockstep: without this every CU asked HBM for its 112 KB at the same moment and
+    // the load phase was 20k of an item's 90k cycles (phase stamps, tools/probes/attn_bwd1_probe).
+    int item = blockIdx.x;
+    if (item >= a.nitems) return;
+    Item I = item_of(item);
+    Mat4 mq, md;
+    bf16x8 ob[4];
+    float lse_r;
+    {
+        const int tid0 = threadIdx.x, l0 = tid0 & 63, q0 = min((tid0 >> 6) * 32 + (l0 & 31), N14 - 1);
+        Mat4 mk, mv;
+        mat4_load(mk, I.kpg, a.sn, tid0);
+        mat4_load(mv, I.vpg, a.sn, tid0);
+        mat4_load(mq, I.qp, a.sn, tid0);
+        mat4_load(md, I.dop, orow, tid0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(outp + (int64_t)qcl * orow + ks * 16 + g * 8);
-        const float m2 = tok_ok ? a.lse[bh * N14 + qi] * LOG2E : INFINITY;     // padding queries: P = 0
+        for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(I.outp + (int64_t)q0 * orow + ks * 16 + (l0 >> 5) * 8);
+        lse_r = a.lse[I.bh * N14 + q0];
+        mat4_store(mk, smem + OFF_K, tid0);
+        mat4_store(mv, smem + OFF_V, tid0);
+    }
+
+    for (;;) {
+        V2_PROF_DECL
+        PROF_MARK();
+        // Everything derived from the thread index is recomputed per item from an OPAQUE copy: the compiler would
+        // otherwise hoist every LDS / global address of the loop body out of the item loop as an invariant — hundreds of
+        // address registers, spilled around every phase (the first build: 160 spilled VGPRs, reloads in the epilogue).
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63, g = lane >> 5, c32 = lane & 31;
+        const LaneOffs lo = lane_offs(lane);
+        const int qi = wave * 32 + c32;              // this lane's query (producer role) and key (consumer role)
+        const bool tok_ok = qi < N14;
+        const int qcl = min(qi, N14 - 1);
+        const int qr = qi > 0 ? (qi - 1) / G14 : 0, qc = qi > 0 ? (qi - 1) - qr * G14 : 0;
+        unsigned char* myslot = smem + OFF_X + wave * SLOT_B;
+        __syncthreads();                             // previous item: the table-gradient jobs are done with Q, dO and the slots
+        mat4_store(mq, smem + OFF_Q, tid);
+        mat4_store(md, smem + OFF_D, tid);
+        const float m2 = tok_ok ? lse_r * LOG2E : INFINITY;                    // padding queries: P = 0
+        const int b = I.b, h = I.h;
+        const int64_t bh = I.bh;
         __syncthreads();
+        PROF_MARK();
 
         // ---- query-owner prologue: delta, slot extensions of q and dO ----------------------------------------
         bf16x8 qe[2], de[2];
@@ -312,10 +449,10 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 for (int e = 0; e < 8; ++e) delta += bf2f(dob[ks][e]) * bf2f(ob[ks][e]);
             delta += __shfl_xor(delta, 32);
             dsc = tok_ok ? delta * a.scale : 0.f;
-            lookups_ext14(qe, qb, img + IMG_KR, myslot, lane, wave == 0, qr, qc, (short)0xC700);
-            lookups_ext14(de, dob, img + IMG_VR, myslot, lane, wave == 0, qr, qc, (short)0);
+            lookups_ext14_pair(qe, de, qb, dob, img, myslot, lane, wave == 0, qr, qc);
         }
 
+        PROF_MARK();
         f32x16 dq[2] = {f32x16{}, f32x16{}}, dx = {};
         f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
 
@@ -336,11 +473,38 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
             }
         };
 
+        // L2 PREFETCH of the next item.  Its K, V, Q, dO and O rows cannot land anywhere while this item runs (LDS and
+        // registers are full), but all workgroups run in lockstep, so without help every CU asks HBM for its 137 KB in the
+        // same few microseconds after the step loop (the loads were 30k of a middle item's 82k cycles).  During the step
+        // loop — when HBM is otherwise idle — every wave therefore issues three 1 KB global -> LDS DMA reads per step
+        // into a sink that is never read: the lines are in L2 / the memory-side cache when the real loads come.
+        const int next = item + (int)gridDim.x;
+        const bool more = next < a.nitems;
+        Item In = I;
+        if (more) In = item_of(next);
+        const int pf_row = lane >> 3, pf_col = (lane & 7) * 8;
+        const uint32_t sink = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem + OFF_SINK));
+
 #pragma unroll 1
         for (int s = 0; s < NT; ++s) {
             const int j = wave + s < NT ? wave + s : wave + s - NT;         // this step's key tile (wave-uniform)
+            PROF_STEP(s);
+            if (BWD1_PREFETCH && more) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int p = (s * NT + wave) * 3 + i;                  // 0 .. 146: 25 pieces of 8 rows per matrix (5 matrices)
+                    const int m = p / 25, piece = p - m * 25;
+                    if (m < 5) {
+                        const short* base = m == 0 ? In.kpg : m == 1 ? In.vpg : m == 2 ? In.qp : m == 3 ? In.dop : In.outp;
+                        const int64_t rs = m < 3 ? a.sn : orow;
+                        const short* src = base + (int64_t)min(piece * 8 + pf_row, N14 - 1) * rs + pf_col;
+                        prefetch_dma(src, sink);
+                    }
+                }
+            }
             // tiles published in step s - 1 for key tile `wave` come from the owner of query tile (wave - (s - 1)) mod 7
             if (s > 0) consume(wave - (s - 1) >= 0 ? wave - (s - 1) : wave - (s - 1) + NT);
+            PROF_STEP(s);
             __builtin_amdgcn_sched_barrier(0);
             // ---- producer: S^T and dP^T of (key tile j, query tile wave) ---------------------------------------
             const unsigned char* kt = smem + OFF_K + j * 4096;
@@ -360,6 +524,7 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 sacc = mma16(o1, qe[ks], sacc);
                 pacc = mma16(o1, de[ks], pacc);
             }
+            PROF_STEP(s);
             __builtin_amdgcn_sched_barrier(0);
             // P = exp2(S sc - m2), dS = P (dP scale - delta scale); keys >= N: P = 0 through slot 15 (fill_onehot_swz)
             uint32_t pw[8], dw[8];                   // bf16 pairs: operand fragments AND the published tiles
@@ -376,6 +541,7 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 pb[st] = __builtin_bit_cast(bf16x8, (u32x4v{pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]}));
                 db[st] = __builtin_bit_cast(bf16x8, (u32x4v{dw[4 * st], dw[4 * st + 1], dw[4 * st + 2], dw[4 * st + 3]}));
             }
+            PROF_STEP(s);
             __builtin_amdgcn_sched_barrier(0);
             // dQx^T += Kx_j^T dS^T
 #pragma unroll
@@ -384,7 +550,9 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 dq[1] = mma16(tr_pair(kt + st * 2048 + lo.tr[1][0], kt + st * 2048 + lo.tr[1][1]), db[st], dq[1]);
                 dx = mma16(tr_pair(oh + st * 1024 + lo.ohtr[0], oh + st * 1024 + lo.ohtr[1]), db[st], dx);
             }
-            __syncthreads();                         // every consumer has read the tiles of step s - 1
+            PROF_STEP(s);
+            lds_barrier();                           // every consumer has read the tiles of step s - 1
+            PROF_STEP(s);
             // publish P and dS for the owner of key tile j: [32 q][32 keys], lane = query row, four runs of 4 keys
             {
                 unsigned char* xs = smem + OFF_X + j * SLOT_B;
@@ -396,16 +564,33 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                         *reinterpret_cast<u32x2v*>(xs + XT_B + lo.xw[st][hh]) = u32x2v{dw[4 * st + 2 * hh], dw[4 * st + 2 * hh + 1]};
                     }
             }
-            __syncthreads();
+            PROF_STEP(s);
+            lds_barrier();
+            PROF_STEP(s);
         }
-        consume(wave + 1 < NT ? wave + 1 : 0);       // step 6's tiles: query tile (wave - 6) mod 7
+        PROF_MARK();
 
         // ---- epilogue ------------------------------------------------------------------------------------------
-        if (tok_ok) {                                // key-owner results: rows of dK, dV
-            const int64_t off = (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh;
-            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dk) + off, dk, g);
-            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dv) + off, dv, g);
+        // K and V are dead (every wave is past its last producer phase): the next item's K, V start travelling now
+        // vmcnt retires in issue order: a load issued behind this epilogue's stores would make its consumer wait for the
+        // stores' write-back as well, so every load group goes out BEFORE the stores that follow it in time
+        Mat4 mk, mv;
+        if (more && !BWD1_EXP_NOLOAD) {
+            mat4_load(mk, In.kpg, a.sn, tid);
+            mat4_load(mv, In.vpg, a.sn, tid);
         }
+        consume(wave + 1 < NT ? wave + 1 : 0);       // step 6's tiles: query tile (wave - 6) mod 7
+        PROF_MARK();
+        // key-owner results: the rows of dK, dV of key tile `wave`, staged in this wave's (dead) K rows
+        unsigned char* stage = smem + OFF_K + wave * 4096;
+        const int64_t goff = (int64_t)b * a.dsb + (int64_t)(wave * 32) * a.dsn + (int64_t)h * a.dsh;
+        if (!BWD1_EXP_NOSTORE) {
+            store_tile_staged(stage, reinterpret_cast<short*>(a.dk) + goff, a.dsn, wave * 32, dk, lane);
+            store_tile_staged(stage, reinterpret_cast<short*>(a.dv) + goff, a.dsn, wave * 32, dv, lane);
+        }
+        PROF_MARK();
+        // operands of the table-gradient job(s) of this wave that come from global memory: requested now, used after the barrier
+        const int job0 = wave, job1 = wave + NT;     // job = tab * 2 + dt; only wave 0 has a second one (job 7)
         {
             bf16x8 bk[4];
             slots_to_buckets14_bf16(bk, myslot, dx, lane, wave == 0, min(qr, G14 - 1), qc);
@@ -424,51 +609,76 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 *reinterpret_cast<u32x4v*>(myslot + c32 * 128 + (((4 * g + ks) ^ swz128(c32)) << 4)) = u.v;
             }
         }
-        if (tok_ok)
-            store_rows_64<hip_bfloat16>(reinterpret_cast<short*>(a.dq) + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh, dq, g);
-        __syncthreads();                             // all dL' tiles are in place
+        if (more && !BWD1_EXP_NOLOAD) {              // next Q, dO, O row, lse -> registers (before the dq stores: in-order vmcnt)
+            mat4_load(mq, In.qp, a.sn, tid);
+            mat4_load(md, In.dop, orow, tid);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(In.outp + (int64_t)qcl * orow + ks * 16 + g * 8);
+            lse_r = a.lse[In.bh * N14 + qcl];
+        }
+        if (!BWD1_EXP_NOSTORE) store_tile_staged(stage, reinterpret_cast<short*>(a.dq) + goff, a.dsn, wave * 32, dq, lane);
+        PROF_MARK();
+        __syncthreads();                             // all dL' tiles are in place; nobody reads the staged rows any more
+        if (more && !BWD1_EXP_NOLOAD) {              // next K, V -> LDS
+            mat4_store(mk, smem + OFF_K, tid);
+            mat4_store(mv, smem + OFF_V, tid);
+        }
+        PROF_MARK();
 
         // ---- table gradients: job = tab * 2 + dt;  dT^T (64 d x 32 u) = X^T (d x q) . R (q x u)
         //      tab 0 / 1: X = Q, R = dL' (vertical / horizontal);  tab 2 / 3: X = dO, R = S' (bucket sums of the forward)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int job = wave + jj * NT;
+            const int job = jj == 0 ? job0 : job1;
             if (job < 8) {
                 const int tab = job >> 1, dt = job & 1;
+                // lane = bucket u (column), registers = d rows; partial of THIS workgroup, accumulated over its items
+                float* dst = a.dtab + (((int64_t)blockIdx.x * 4 + tab) * 32 + c32) * 64 + dt * 32 + 4 * g;
+                const bool first = item == (int)blockIdx.x;
+                f32x4v old[4];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) old[r4] = first ? f32x4v{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4v*>(dst + 8 * r4);
                 f32x16 acc = {};
                 const unsigned char* xbase = smem + (tab < 2 ? OFF_Q : OFF_D);
-                const short* spr = reinterpret_cast<const short*>(a.sp) + (bh * 64 + (tab & 1) * 32 + c32) * NP14;
+                if (tab < 2) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        const unsigned char* xt = xbase + t * 4096 + st * 2048;
-                        const bf16x8 xa = tr_pair(xt + lo.tr[dt][0], xt + lo.tr[dt][1]);
-                        bf16x8 rb;
-                        if (tab < 2) {
+                        for (int st = 0; st < 2; ++st) {
+                            const unsigned char* xt = xbase + t * 4096 + st * 2048;
                             const unsigned char* dl = smem + OFF_X + t * SLOT_B + st * 2048;
-                            rb = tr_pair(dl + lo.tr[tab & 1][0], dl + lo.tr[tab & 1][1]);
-                        } else {
-                            rb = Tr<hip_bfloat16>::load_perm(spr + t * 32, st, g);
+                            acc = mma16(tr_pair(xt + lo.tr[dt][0], xt + lo.tr[dt][1]), tr_pair(dl + lo.tr[tab & 1][0], dl + lo.tr[tab & 1][1]), acc);
                         }
-                        acc = mma16(xa, rb, acc);
-                    }
-                }
-                // lane = bucket u (column), registers = d rows; partial of THIS workgroup, accumulated over its items
-                float* dst = a.dtab + (((int64_t)blockIdx.x * 4 + tab) * 32 + c32) * 64 + dt * 32;
-                const bool first = item == (int)blockIdx.x;
+                } else {
+                    const short* spr = reinterpret_cast<const short*>(a.sp) + (bh * 64 + (tab & 1) * 32 + c32) * NP14;
+                    bf16x8 rb[NT][2];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4v v = f32x4v{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-                    float* d4 = dst + 8 * r4 + 4 * g;
-                    if (!first) {
-                        const f32x4v old = *reinterpret_cast<const f32x4v*>(d4);
-                        v = f32x4v{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-                    }
-                    *reinterpret_cast<f32x4v*>(d4) = v;
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) rb[t][st] = Tr<hip_bfloat16>::load_perm(spr + t * 32, st, g);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            const unsigned char* xt = xbase + t * 4096 + st * 2048;
+                            acc = mma16(tr_pair(xt + lo.tr[dt][0], xt + lo.tr[dt][1]), rb[t][st], acc);
+                        }
                 }
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    *reinterpret_cast<f32x4v*>(dst + 8 * r4) = f32x4v{old[r4][0] + acc[4 * r4], old[r4][1] + acc[4 * r4 + 1],
+                                                                      old[r4][2] + acc[4 * r4 + 2], old[r4][3] + acc[4 * r4 + 3]};
             }
         }
+        PROF_MARK();
+#ifdef ATTN_PROFILE_ITEM1
+        if (item == (int)(blockIdx.x + gridDim.x)) V2_PROF_FLUSH();          // the SECOND item: one with a predecessor and a successor
+#else
+        V2_PROF_FLUSH();
+#endif
+        if (!more) break;
+        item = next;
+        I = In;
     }   // items
 }
 

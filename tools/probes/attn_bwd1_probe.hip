@@ -3,6 +3,8 @@
 // gradients (partials summed on the host), then interleaved timing of both (HIP events, median of the rounds).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Icream_amd/csrc \
 //         tools/probes/attn_bwd1_probe.hip -o tools/probes/attn_bwd1_probe && tools/probes/attn_bwd1_probe
+// -DATTN_PROFILE: per-phase cycle stamps of the one-pass kernel (last item of every workgroup); -DATTN_PROFILE_STEPS adds
+// the sub-phases of step 3
 #include "../../cream_amd/csrc/attn_rpe2d.hip"
 #include <algorithm>
 #include <cmath>
@@ -106,6 +108,41 @@ static int run_case(int B, int H, int rounds, float qscale) {
         if (diff || tdiff) fail = 1;
         hipFree(g2); hipFree(tab2);
     }
+#ifdef ATTN_PROFILE
+    if (rounds > 0) {
+        long long* dprof;
+        const int grid = parts;
+        hipMalloc(&dprof, (size_t)grid * 8 * 20 * 8);
+        hipMemset(dprof, 0, (size_t)grid * 8 * 20 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &dprof, sizeof(dprof));
+        bwd(1, g1, tab1); hipDeviceSynchronize();
+        std::vector<long long> hp((size_t)grid * 8 * 20);
+        hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost);
+        long long* nul = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &nul, sizeof(nul));
+#ifdef ATTN_PROFILE_STEPS
+        const char* names[] = {"load+store K,V,Q,dO", "prologue (delta, lookups)", "steps 0-2", "s3 consume", "s3 S,dP mfma", "s3 exp/dS valu",
+                               "s3 dQx mfma", "s3 barrier A", "s3 publish", "s3 barrier B", "steps 4-6", "final consume", "store dk dv",
+                               "shift+dq", "barrier C", "table jobs"};
+        const int np = 16;
+#else
+        const char* names[] = {"load+store K,V,Q,dO", "prologue (delta, lookups)", "7 steps", "final consume", "store dk dv", "shift+dq",
+                               "barrier C", "table jobs"};
+        const int np = 8;
+#endif
+        std::vector<double> sum(np, 0.0); double tot = 0; int cnt = 0;
+        for (int blk = 0; blk < grid; ++blk) for (int w = 0; w < 7; ++w) {
+            long long* d = &hp[((size_t)blk * 8 + w) * 20];
+            if (d[np] <= d[0]) continue;
+            for (int i = 0; i < np; ++i) sum[i] += (double)(d[i + 1] - d[i]);
+            tot += (double)(d[np] - d[0]); ++cnt;
+        }
+        printf("  one-pass kernel, cycles per item and wave (last item of each workgroup, %d waves):\n", cnt);
+        for (int i = 0; i < np; ++i) printf("    %-28s %9.0f\n", names[i], sum[i] / std::max(cnt, 1));
+        printf("    %-28s %9.0f\n", "total", tot / std::max(cnt, 1));
+        hipFree(dprof);
+    }
+#endif
     if (rounds > 0) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         std::vector<float> t[3];
