@@ -69,6 +69,7 @@ SIGNATURES = {
     "cream_colsum": (_i, [_vp, _vp, _i, _i, _vp]),
     "cream_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "cream_block_fuse_ln": (_i, [_i]),
+    "cream_block_wgrad_bf16": (_i, [_i]),
     "cream_linear_add_ln_supported": (_i, [_i, _i]),
     "cream_linear_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
     "cream_colsum128_slabs": (_i, [_i]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "cream_scale_cast_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cream_grad_finalize": (_i, [_vp, _i, _vp]),
     "cream_gemm_rows_per_colsum_slab": (_i, []),
+    "cream_gemm_nt256": (_i, [_i]),
     "cream_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_fwd_seg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_gelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "cream_linear_dgrad_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_wgrad_splits": (_i, [_i, _i, _i]),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
     "cream_soft_ce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -250,20 +250,27 @@ def linear_dgrad_mul(dy, wt, factor, N, K):
     return dh, parts
 
 
-def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None):
-    """-> (parts (S, N, K) fp32, bias_parts (S, N) fp32 or None): partial products dy_s^T x_s over S
+def wgrad_parts_dtype():
+    """bf16 when the library writes the split-K partial tiles of the block's weight gradients as bf16
+    (cream_block_wgrad_bf16: half the partial traffic), else fp32 — the op-by-op path follows the native one."""
+    return torch.bfloat16 if _lib.load().cream_block_wgrad_bf16(-1) else torch.float32
+
+
+def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None, parts_dtype=torch.float32):
+    """-> (parts (S, N, K) fp32 or bf16, bias_parts (S, N) fp32 or None): partial products dy_s^T x_s over S
     slices of the token dimension (S chosen by the library) and, on request, the column sums of dy_s."""
     M, N = dy.shape
     K = x.shape[1]
     lib = _lib.load()
     S = lib.cream_linear_wgrad_splits(M, N, K)
     if out is None:
-        out = torch.empty((S, N, K), dtype=torch.float32, device=dy.device)
+        out = torch.empty((S, N, K), dtype=parts_dtype, device=dy.device)
     if want_bias and bias_out is None:
         bias_out = torch.empty((S, N), dtype=torch.float32, device=dy.device)
+    fn, name = ((lib.cream_linear_wgrad_parts_bf16, "cream_linear_wgrad_parts_bf16") if out.dtype == torch.bfloat16
+                else (lib.cream_linear_wgrad_parts, "cream_linear_wgrad_parts"))
     with timing.region("gemm_tn_wgrad", flops=2 * M * N * K):
-        _lib.check(lib.cream_linear_wgrad_parts(_p(out), _p(bias_out) if want_bias else ctypes.c_void_p(0), _p(dy), _p(x), M, N,
-                                                K, S, _stream()), "cream_linear_wgrad_parts")
+        _lib.check(fn(_p(out), _p(bias_out) if want_bias else ctypes.c_void_p(0), _p(dy), _p(x), M, N, K, S, _stream()), name)
     return out, (bias_out if want_bias else None)
 
 
@@ -290,10 +297,10 @@ def wgrad_parts_async(dy, x, want_bias=False):
     the side stream before the partials are consumed), the operands are complete at this point of
     the caller's stream (event)."""
     if not WGRAD_SIDE_STREAM:
-        return linear_wgrad_parts(dy, x, want_bias)
+        return linear_wgrad_parts(dy, x, want_bias, parts_dtype=wgrad_parts_dtype())
     M, N = dy.shape
     S = _lib.load().cream_linear_wgrad_splits(M, N, x.shape[1])
-    out = torch.empty((S, N, x.shape[1]), dtype=torch.float32, device=dy.device)
+    out = torch.empty((S, N, x.shape[1]), dtype=wgrad_parts_dtype(), device=dy.device)
     bout = torch.empty((S, N), dtype=torch.float32, device=dy.device) if want_bias else None
     main = torch.cuda.current_stream(dy.device)
     side = _side_stream(dy.device)

@@ -1446,7 +1446,7 @@ int bwd_onepass_mode() {
     int m = g_bwd_onepass.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("CREAM_ATTN_BWD1");
-        m = e ? (atoi(e) != 0) : 0;
+        m = e ? (atoi(e) != 0) : 1;              // default ON: same time as the two-launch pair, half its HBM traffic, no side buffers
         g_bwd_onepass.store(m, std::memory_order_relaxed);
     }
     return m;

@@ -14,6 +14,7 @@
 // the byte size of one flat workspace per call and the offsets of the tensors the caller needs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -146,6 +147,22 @@ const char* const kProfNames[K_COUNT] = {"ln_fwd", "gemm_nt", "gemm_nt_gelu", "g
                                          "attn_rpe2d_bwd", "ln_bwd", "grad_finalize", "gemm_nt_add_ln"};
 // projection + residual add + LayerNorm as one kernel where the shapes allow (cream_block_fuse_ln)
 std::atomic<int> g_fuse_ln{0};
+// split-K partial tiles of the weight gradients as bf16 (cream_linear_wgrad_parts_bf16): half the partial traffic
+std::atomic<int> g_wgrad_bf16{-1};
+int wgrad_bf16_mode() {
+    int m = g_wgrad_bf16.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_WGRAD_BF16");
+        m = e ? (atoi(e) != 0) : 1;              // default ON: -2 % step time in a same-box A/B x3 (profiles/r04_step_ab.md)
+        g_wgrad_bf16.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+// the split-K weight-gradient launch in either partial format (the workspace regions are sized for fp32)
+int wgrad_parts(int bf16, float* parts, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S, void* stream) {
+    return bf16 ? cream_linear_wgrad_parts_bf16(parts, bias_parts, dy, x, M, N, K, S, stream)
+                : cream_linear_wgrad_parts(parts, bias_parts, dy, x, M, N, K, S, stream);
+}
 struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
 std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;
@@ -280,17 +297,18 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     //       kernel (cream_wgrad_group) — 25 % less side-stream time standalone, but its long-lived workgroups hold half of
     //       every SIMD's registers for ~200 us and the main chain behind them loses more than the side stream gains.
     const bool grouped = G->wgrad_slabs && G->wgrad_counters;
+    const int wb16 = wgrad_bf16_mode();           // split-K partial tiles as bf16 (half the partial traffic) or fp32
     const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
     if (!grouped) {
         if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // df, g complete on main
-        PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, wgrad_parts(wb16, at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     }
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
     PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
                                  main));
     if (!grouped) {
         if (!fork(main, side)) return CREAM_ERR_LAUNCH;
-        PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, wgrad_parts(wb16, at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
@@ -299,7 +317,7 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     // ---- attention branch -----------------------------------------------------------------------
     if (!grouped) {
         if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // dp complete on main
-        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, wgrad_parts(wb16, at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
@@ -312,7 +330,7 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // dqkv complete on main
     if (!grouped) {
         // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
-        PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, cream_linear_wgrad_parts(at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
+        PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, wgrad_parts(wb16, at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
     } else {
         // all four weight gradients (+ the qkv bias gradient) in ONE launch: their operands are complete on the main stream here
         cream_wgrad_problem W[4] = {
@@ -338,10 +356,10 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         ++n;
     };
     if (!grouped) {
-        job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, 0);
-        job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, 0);
-        job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, 0);
-        job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, 0);
+        job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, wb16);
+        job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, wb16);
+        job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, wb16);
+        job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, wb16);
         job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     }
     job(G->b2, E, pb2, pb2_parts, pb2_pstride, 1, E, 0, 0);
@@ -357,6 +375,13 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));
     return CREAM_OK;
+}
+
+int cream_block_wgrad_bf16(int on)
+{
+    const int prev = wgrad_bf16_mode();
+    if (on >= 0) g_wgrad_bf16.store(on != 0, std::memory_order_relaxed);
+    return prev;
 }
 
 int cream_block_fuse_ln(int on)

@@ -16,6 +16,8 @@
 // the last round (M = 197 x 128 rows against 256 CUs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 
 #include "cream_amd.h"
 #include "gemm_mfma.hpp"
@@ -40,9 +42,42 @@ int num_cus()
 // workgroup's tiles stay on its XCD), or one per tile if there are fewer tiles.  Same-box A/B of the step with
 // the same kernel launched one tile per workgroup: 10.97 -> 10.86 ms; per GEMM against the previous kernel
 // 3-8 % (profiles/r02_gemm_probe.txt)
+// 256 x 256 macro tile (8 waves, 128 x 64 wave tiles, 128 KB of LDS, one persistent workgroup per CU) for the wide
+// outputs (qkv, fc1, fc2 dgrad: N >= 960): half the L2 -> LDS bytes per flop of the 128 x 128 tile.
+// CREAM_GEMM_NT256 in the environment / cream_gemm_nt256() switch it (A/B runs); default: see nt256_mode().
+std::atomic<int> g_nt256{-1};
+int nt256_mode()
+{
+    int m = g_nt256.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_NT256");
+        m = e ? (atoi(e) != 0) : 0;
+        g_nt256.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+template <int EPI>
+int launch_nt256(const NtParams& p, hipStream_t st)
+{
+    constexpr int BM = 256, BN = 256;
+    auto kern = gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
+    constexpr int lds = nt_lds_bytes(BM, BN, 2);
+    static bool attr_done = false;               // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
+    if (p.N >= 960 && nt256_mode()) return launch_nt256<EPI>(p, st);
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
@@ -83,6 +118,13 @@ NtParams plain(void* out, const void* a, const void* b, int M, int N, int K, int
 extern "C" {
 
 int cream_gemm_rows_per_colsum_slab(void) { return 128; }
+
+int cream_gemm_nt256(int on)
+{
+    const int prev = nt256_mode();
+    if (on >= 0) g_nt256.store(on != 0, std::memory_order_relaxed);
+    return prev;
+}
 
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K, int64_t ldw,
                      void* stream)
@@ -174,12 +216,33 @@ int cream_linear_wgrad_splits(int M, int N, int K)
     return s < 1 ? 1 : s;
 }
 
+namespace {
+int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S, void* stream);
+}
+
 int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S,
                              void* stream)
 {
+    if (!parts || !aligned16(parts)) return CREAM_ERR_BAD_ARG;
+    return wgrad_parts_any(parts, nullptr, bias_parts, dy, x, M, N, K, S, stream);
+}
+
+int cream_linear_wgrad_parts_bf16(void* parts_bf16, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S,
+                                  void* stream)
+{
+    if (!parts_bf16 || !aligned16(parts_bf16)) return CREAM_ERR_BAD_ARG;
+    return wgrad_parts_any(nullptr, (uint16_t*)parts_bf16, bias_parts, dy, x, M, N, K, S, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S,
+                    void* stream)
+{
     if (M <= 0 || N <= 0 || K <= 0 || S <= 0 || N % 8 || K % 8) return CREAM_ERR_BAD_ARG;
-    if (!parts || !dy || !x || !aligned16(dy) || !aligned16(x) || !aligned16(parts)) return CREAM_ERR_BAD_ARG;
-    TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts};
+    if (!dy || !x || !aligned16(dy) || !aligned16(x)) return CREAM_ERR_BAD_ARG;
+    TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts, parts16};
     const int grid = ((N + 127) / 128) * ((K + 127) / 128) * S;
     // the bias-free instantiation has no bias accumulators (126 instead of 165 VGPRs: room for two more waves of the main chain's
     // kernels per SIMD next to two of these — measured neutral on the step, 10.76 vs 10.75 ms in a same-box A/B x3: the two
@@ -188,6 +251,9 @@ int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, co
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 64, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
+}  // namespace
+
+extern "C" {
 
 /* ---- all weight gradients of a block in one launch (stream-K ranges, in-kernel fixed-order reduction) ---- */
 int cream_wgrad_group_slots(void) { return 2 * num_cus() / 8 * 8; }          /* ranges = workgroups per launch: 2 per CU */

@@ -116,6 +116,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // requested before the epilogue of the current one — into stage 0, while the epilogue takes the accumulators
 // through the LDS of stage 1 in two half-tile passes (XOR-swizzled fp32 rows without padding: 64 rows x BN
 // floats are exactly one stage) — so its latency hides behind the epilogue instead of idling the workgroup.
+// LDS of a kernel instantiation: a static array up to 64 KB, the dynamic segment above (the 256 x 256 macro tile needs
+// 128 KB: the launcher raises hipFuncAttributeMaxDynamicSharedMemorySize and passes the size).  ONE object either way.
+template <int BYTES, bool DYN = (BYTES > 65536)> struct LdsBlock {
+    static __device__ __forceinline__ char* get() {
+        __shared__ __attribute__((aligned(1024))) char s[BYTES];
+        return s;
+    }
+};
+template <int BYTES> struct LdsBlock<BYTES, true> {
+    static __device__ __forceinline__ char* get() {
+        extern __shared__ __attribute__((aligned(1024))) char dyn_lds[];
+        return dyn_lds;
+    }
+};
+
 template <int BM, int BN, int WM, int WN, int NST, int EPI, int OCC>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const NtParams p)
 {
@@ -125,12 +140,18 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     constexpr int TM = WTM / 32, TN = WTN / 32;                 // MFMA tiles per wave
     constexpr int STAGE = (BM + BN) * BK;                       // bf16 elements per stage
     constexpr int NPIECE = (BM + BN) / 8 / NW;                  // 1-KB pieces (8 rows) per wave and stage
-    constexpr int HM = BM / 2;                                  // rows of one epilogue pass
     constexpr int NCH = BN / 4;                                 // 4-float chunks per epilogue row
+    // the epilogue takes the fp32 tile through ONE stage's LDS in passes of HM rows: as many 32-row MFMA tiles of a wave
+    // row as fit (128 x 128, 128 x 64: 64 rows = a whole wave row, two passes; 256 x 256: 64 of a wave's 128 rows, four)
+    constexpr int HM_FIT = (STAGE * 2) / (BN * 4) / 32 * 32;
+    constexpr int HM = HM_FIT < WTM ? HM_FIT : WTM;             // rows of one epilogue pass
+    constexpr int NPASS = BM / HM, TMP = HM / 32;               // passes per tile, MFMA row tiles per pass
+    constexpr int SLAB = 128;                                   // rows of one column-sum slab (cream_gemm_rows_per_colsum_slab)
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
     static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
-    static_assert(WM == 2 && HM * BN * 4 <= STAGE * 2, "one epilogue pass = the rows of one wave row, inside one stage");
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE * 2];
+    static_assert(HM >= 32 && WTM % HM == 0 && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles of one wave row, inside one stage");
+    static_assert(EPI != EPI_MUL_COLSUM || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
+    char* const smem = LdsBlock<NST * STAGE * 2>::get();
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
     float* const ctile = reinterpret_cast<float*>(smem + STAGE * 2);           // stage 1
 
@@ -303,7 +324,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         }
         float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NPASS; ++half) {
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int wm_of_pass = (half * HM) / WTM, tm0 = ((half * HM) % WTM) / 32;     // which wave row / MFMA tiles hold these rows
             // side inputs of this thread's chunks are requested before the LDS round trip of the accumulators
             u32x4v auxv[EPI == EPI_MUL_COLSUM ? NJ : 1];
             if constexpr (EPI == EPI_MUL_COLSUM) {
@@ -313,18 +336,19 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     auxv[j] = (m < p.M && ncol_ok) ? *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n) : u32x4v{0, 0, 0, 0};
                 }
             }
-            if (half) __syncthreads();                          // pass 0 has been read
-            if (wm == half) {
+            if (half) __syncthreads();                          // the previous pass has been read
+            if (wm == wm_of_pass) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        const int ml = tm * 32 + c32;
+                    for (int tmp = 0; tmp < TMP; ++tmp) {
+                        const int ml = tmp * 32 + c32;
+                        const f32x16& av = acc[tn][tm0 + tmp];
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int ch = (wn * WTN + tn * 32 + 8 * r4 + 4 * g) >> 2;
                             *reinterpret_cast<f32x4v*>(ctile + ml * BN + ((ch ^ (ml & (NCH - 1))) << 2)) =
-                                f32x4v{acc[tn][tm][4 * r4], acc[tn][tm][4 * r4 + 1], acc[tn][tm][4 * r4 + 2], acc[tn][tm][4 * r4 + 3]};
+                                f32x4v{av[4 * r4], av[4 * r4 + 1], av[4 * r4 + 2], av[4 * r4 + 3]};
                         }
                     }
             }
@@ -380,18 +404,25 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     *reinterpret_cast<u32x4v*>(o) = db;
                 }
             }
-        }
-        if constexpr (EPI == EPI_MUL_COLSUM) {
-            __syncthreads();                                    // the fp32 half tile has been consumed
-            float* red = ctile;                                 // [RPP][BN]
+            if constexpr (EPI == EPI_MUL_COLSUM) {
+                if (((half + 1) * HM) % SLAB == 0) {            // a 128-row slab is complete: its column sums leave
+                    __syncthreads();                            // the fp32 pass has been consumed
+                    float* red = ctile;                         // [RPP][BN]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[r0 * BN + cc * 8 + e] = cs[e];
-            __syncthreads();
-            if (tid < BN && cur_n0 + tid < p.N) {
-                float sum = 0.f;
+                    for (int e = 0; e < 8; ++e) { red[r0 * BN + cc * 8 + e] = cs[e]; cs[e] = 0.f; }
+                    __syncthreads();
+                    const int slab = (cur_m0 + (half + 1) * HM) / SLAB - 1;
+                    if (slab * SLAB < p.M) {
+                        for (int c = tid; c < BN; c += NT) {
+                            if (cur_n0 + c < p.N) {
+                                float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < RPP; ++r) sum += red[r * BN + tid];   // fixed order
-                p.colsum[(int64_t)(cur_m0 / BM) * p.N + cur_n0 + tid] = sum;
+                                for (int r = 0; r < RPP; ++r) sum += red[r * BN + c];     // fixed order
+                                p.colsum[(int64_t)slab * p.N + cur_n0 + c] = sum;
+                            }
+                        }
+                    }
+                }
             }
         }
         GPROF(3);
@@ -424,6 +455,7 @@ struct TnParams {
     int M, N, K, S;         // S splits of the token dimension (in 64-token steps, as even as possible)
     float* parts;           // [S][N][K] fp32
     float* bias_parts;      // [S][N] fp32 or nullptr
+    uint16_t* parts16;      // non-null: the partial tiles leave as bf16 [S][N][K] instead (half the partial traffic; `parts` unused)
 };
 
 __device__ __forceinline__ bf16x4 tr16(const uint16_t* p) {
@@ -621,6 +653,25 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
             }
     }
     __syncthreads();
+    if (p.parts16) {
+        // bf16 partials: every split's sum over its ~M / S tokens is rounded once (the reference's autocast backward rounds the
+        // whole weight gradient to bf16 once, Linear_super.py:71-81 under torch.autocast); cream_grad_finalize adds them in fp32
+        uint16_t* out = p.parts16 + (int64_t)split * p.N * p.K;
+        const int c8 = (tid & 15) * 8, r0 = tid >> 4;
+        if (k0 + c8 < p.K) {                                               // K % 8 == 0: an 8-chunk is all in or all out
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = n0 + r0 + 16 * i;
+                if (n < p.N) {
+                    const f32x4v lo = *reinterpret_cast<const f32x4v*>(ct + (r0 + 16 * i) * BT + c8);
+                    const f32x4v hi = *reinterpret_cast<const f32x4v*>(ct + (r0 + 16 * i) * BT + c8 + 4);
+                    *reinterpret_cast<u32x4v*>(out + (int64_t)n * p.K + k0 + c8) =
+                        u32x4v{f2bf_pair(lo[0], lo[1]), f2bf_pair(lo[2], lo[3]), f2bf_pair(hi[0], hi[1]), f2bf_pair(hi[2], hi[3])};
+                }
+            }
+        }
+        return;
+    }
     float* out = p.parts + (int64_t)split * p.N * p.K;
     const int c4 = (tid & 31) * 4, r0 = tid >> 5;
     if (k0 + c4 < p.K) {                                                   // K % 8 == 0: a 4-chunk is all in or all out

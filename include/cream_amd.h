@@ -92,7 +92,7 @@ int cream_attn_rpe2d_dtab_parts(int B, int H);
  * 1 = the one-pass kernel (csrc/attn_rpe2d_bwd1.hpp: K, V, Q, dO of one (b, h) whole in LDS, P / dS exchanged between
  * the query-tile and key-tile owners through LDS; the side buffers dlt / qe / de / delta are not used as such —
  * the first 32 KB of dlt carry the bf16 operand images of the tables), 0 = the two-launch backward.  onepass < 0
- * only queries.  Returns the previous setting; the initial one comes from CREAM_ATTN_BWD1 in the environment.
+ * only queries.  Returns the previous setting; the initial one comes from CREAM_ATTN_BWD1 in the environment (default 1).
  * (What autograd derives for multihead_super.py:135-154 either way; a switch for same-box A/B measurements.) */
 int cream_attn_rpe2d_bwd_mode(int onepass);
 
@@ -354,6 +354,12 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
  *                             same kernel (NULL: not wanted).  cream_linear_wgrad_splits gives the S
  *                             this library uses for a problem (~1 workgroup per CU, at most 16). */
 int cream_gemm_rows_per_colsum_slab(void);
+
+/* Tile choice of the NT products with wide outputs (N >= 960: qkv_super / fc1 forward, fc2 dgrad — Linear_super.py:38-54,
+ * qkv_super.py:45-55): 1 = the 256 x 256 macro tile (8 waves, one persistent workgroup per CU), 0 = 128 x 128 tiles
+ * (two workgroups per CU).  on < 0 only queries; returns the previous setting; the initial one comes from
+ * CREAM_GEMM_NT256 in the environment.  A switch for same-box A/B measurements — results are identical. */
+int cream_gemm_nt256(int on);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
 int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
@@ -372,6 +378,12 @@ int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const 
 int cream_linear_wgrad_splits(int M, int N, int K);
 int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N,
                              int K, int S, void* stream);
+/* The same with the partial tiles written as bf16 [S][N][K] (half the partial traffic: 113 instead of 226 MB per
+ * transformer block through HBM, written here and read by cream_grad_finalize with src_bf16 = 1).  Every split's sum over
+ * its ~M / S tokens is rounded to bf16 once — what torch.autocast's backward does to the WHOLE gradient of the bf16 weight
+ * copy (Linear_super.py:71-81 under autocast); the bias partials stay fp32. */
+int cream_linear_wgrad_parts_bf16(void* parts_bf16, float* bias_parts, const void* dy, const void* x, int M, int N,
+                                  int K, int S, void* stream);
 
 /* ---- parameter update + operand copies ------------------------------------------------------
  * torch.optim.AdamW as created by timm's create_optimizer (AutoFormer/supernet_train.py:294-296;
@@ -560,6 +572,9 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const
  * ffn_layer_norm as ONE kernel (cream_linear_add_ln_fwd) where cream_linear_add_ln_supported says so.
  * Results are identical either way. */
 int cream_block_fuse_ln(int on);
+/* cream_block_bwd writes the split-K partial tiles of the four weight gradients as bf16 (1) or fp32 (0); returns the
+ * previous setting; on < 0 only queries.  Initial value: CREAM_WGRAD_BF16 in the environment, else 1. */
+int cream_block_wgrad_bf16(int on);
 
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).

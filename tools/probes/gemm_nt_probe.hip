@@ -74,13 +74,17 @@ struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtPar
 static const Variant VARIANTS[] = {
     V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3),
     V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_MUL_COLSUM, 2),
+    // round 4: the 256 x 256 macro tile (8 waves, 128 KB of dynamic LDS, one workgroup per CU)
+    V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
 };
-static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 256 ? 2 : 3; }
+static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 512 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
     const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, tiles = ntn * ntm;
     static const int persist = getenv("GEMM_ONE_TILE_PER_WG") ? 0 : 1;
     const int slots = occ_of(v) * 256;
-    hipLaunchKernelGGL(v.kern, dim3(persist && tiles > slots ? slots : tiles), dim3(v.nt), 0, st, p);
+    const int lds = nt_lds_bytes(v.bm, v.bn, 2) > 65536 ? nt_lds_bytes(v.bm, v.bn, 2) : 0;
+    if (lds) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(v.kern, dim3(persist && tiles > slots ? slots : tiles), dim3(v.nt), lds, st, p);
 }
 
 // phase timestamps of one variant on one shape: per workgroup start -> first data -> end of K loop -> end
@@ -337,7 +341,7 @@ int main(int argc, char** argv)
             CK(hipMemset(dmax, 0, 16));
             launch(v, p);
             check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
-            if (v.epi == EPI_MUL_COLSUM) check_colsum<<<(((s.M + v.bm - 1) / v.bm) * s.N + 255) / 256, 256>>>(dmax, p, v.bm);
+            if (v.epi == EPI_MUL_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
             for (int i = 0; i < 3; ++i) launch(v, p);
