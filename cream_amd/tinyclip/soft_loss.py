@@ -61,6 +61,46 @@ def gather_features_with_grad(image_features, text_features, with_grad=True, gro
     return allf[:, :d], allf[:, d:]
 
 
+class _SimilarityNT(torch.autograd.Function):
+    """S (M, N) = A (M, D) . B (N, D)^T in bf16 on the framework's OWN matrix-core GEMMs (csrc/gemm_mfma.hpp) — the four
+    similarity products of ClipSoftLoss (clip_soft_loss.py:34-52), forward and both gradients (dA = dS . B through the NT
+    kernel on B^T, dB = dS^T . A through the split-K TN kernel): no vendor GEMM library on this path either."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from ..autoformer import block as K
+        a16, b16 = a.to(torch.bfloat16).contiguous(), b.to(torch.bfloat16).contiguous()
+        ctx.save_for_backward(a16, b16)
+        ctx.dtypes = (a.dtype, b.dtype)
+        with torch.cuda.device(a.device):
+            return K.linear_fwd(a16, b16, None, b16.shape[0], a16.shape[1])
+
+    @staticmethod
+    def backward(ctx, ds):
+        from ..autoformer import block as K
+        a16, b16 = ctx.saved_tensors
+        ds = ds.to(torch.bfloat16).contiguous()
+        da = db = None
+        with torch.cuda.device(ds.device):
+            if ctx.needs_input_grad[0]:
+                da = K.linear_dgrad(ds, b16.t().contiguous(), b16.shape[0], a16.shape[1]).to(ctx.dtypes[0])
+            if ctx.needs_input_grad[1]:
+                db = K.wgrad(ds, a16).to(ctx.dtypes[1])
+        return da, db
+
+
+def similarity(a, b):
+    """a (M, D) . b (N, D)^T.  Device tensors go through the own kernels: bf16 under autocast (what `@` would compute in),
+    exact fp32 otherwise (csrc/gemm_f32.hip); host tensors (tests, the gloo runs) keep the framework product."""
+    if a.is_cuda and a.shape[1] % 8 == 0 and b.shape[0] % 8 == 0:
+        if torch.is_autocast_enabled("cuda") or a.dtype == torch.bfloat16:
+            return _SimilarityNT.apply(a, b)
+        from ..autoformer import native_fp32
+        if native_fp32.usable(a, b):
+            return native_fp32.linear(a, b, None, b.shape[0], a.shape[1])
+    return a @ b.T
+
+
 class ClipSoftLoss(nn.Module):
     """Same constructor flags and forward signature as the reference's ClipSoftLoss
     (clip_soft_loss.py:11-32, :54-88); `use_horovod` is accepted and must be False (RCCL only)."""
@@ -75,7 +115,7 @@ class ClipSoftLoss(nn.Module):
 
     def compute_sim(self, image_features, text_features, with_grad):
         all_image, all_text = gather_features_with_grad(image_features, text_features, with_grad, self.group)
-        return image_features @ all_text.T, text_features @ all_image.T
+        return similarity(image_features, all_text), similarity(text_features, all_image)
 
     def forward(self, image_features, text_features, logit_scale, teacher_image_features, teacher_text_features,
                 teacher_logit_scale, average_two_losses=True, labels=None):

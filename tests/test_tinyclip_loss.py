@@ -47,13 +47,30 @@ def test_soft_loss_on_the_device_matches_reference_values(amp):
     z = np.load(os.path.join(GOLDEN, "tinyclip_soft_loss.npz"))
     dev = torch.device("cuda:0")
     feats = [f.to(dev) for f in _features()]
+
+    # the four similarity products and their gradients run on the framework's own GEMM kernels: the framework's matrix
+    # products (= the vendor library) are forbidden on device tensors for the duration of the loss and its backward
+    def _forbidden(*a, **k):
+        raise AssertionError("framework matmul on a device tensor inside ClipSoftLoss")
+    import unittest.mock as mock
+    real_mm, real_matmul, real_linear = torch.mm, torch.matmul, torch.nn.functional.linear
+
+    def _guard(real):
+        def f(*a, **k):
+            if any(isinstance(t, torch.Tensor) and t.is_cuda for t in a):
+                _forbidden()
+            return real(*a, **k)
+        return f
     for avg in (True, False):
         img, txt = feats[0].clone().requires_grad_(), feats[1].clone().requires_grad_()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            res = ClipSoftLoss()(img, txt, torch.tensor(50.0, device=dev), feats[2], feats[3], torch.tensor(100.0, device=dev),
-                                 average_two_losses=avg)
-            tot = res if avg else res[0] + 2 * res[1]
-        tot.float().backward()
+        with mock.patch.object(torch, "mm", _guard(real_mm)), mock.patch.object(torch, "matmul", _guard(real_matmul)), \
+                mock.patch.object(torch.nn.functional, "linear", _guard(real_linear)), \
+                mock.patch.object(torch.Tensor, "__matmul__", _guard(torch.Tensor.__matmul__)):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                res = ClipSoftLoss()(img, txt, torch.tensor(50.0, device=dev), feats[2], feats[3], torch.tensor(100.0, device=dev),
+                                     average_two_losses=avg)
+                tot = res if avg else res[0] + 2 * res[1]
+            tot.float().backward()
         got = (res.reshape(1) if avg else torch.stack(list(res))).detach().float().cpu().numpy()
         want, di, dt = z[f"avg{int(avg)}|loss"], z[f"avg{int(avg)}|dimage"], z[f"avg{int(avg)}|dtext"]
         gi, gt = img.grad.float().cpu().numpy(), txt.grad.float().cpu().numpy()
