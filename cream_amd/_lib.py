@@ -70,6 +70,7 @@ SIGNATURES = {
     "cream_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "cream_block_fuse_ln": (_i, [_i]),
     "cream_block_wgrad_bf16": (_i, [_i]),
+    "cream_block_gelu_recompute": (_i, [_i]),
     "cream_linear_add_ln_supported": (_i, [_i, _i]),
     "cream_linear_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
     "cream_colsum128_slabs": (_i, [_i]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "cream_linear_dgrad_seg": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_dgrad_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_wgrad_splits": (_i, [_i, _i, _i]),
+    "cream_linear_dgrad_gelugrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp]),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),

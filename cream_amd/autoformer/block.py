@@ -256,6 +256,27 @@ def wgrad_parts_dtype():
     return torch.bfloat16 if _lib.load().cream_block_wgrad_bf16(-1) else torch.float32
 
 
+def gelu_recompute(E):
+    """True when the library recomputes gelu'(h) inside the fc2 dgrad for this embed dim (cream_block_gelu_recompute;
+    E % 64 == 0): the forward then stores gelu(h) only."""
+    return bool(_lib.load().cream_block_gelu_recompute(-1)) and E % 64 == 0
+
+
+def linear_dgrad_gelugrad(dy, wt, x, w, bias, N, K, Kvalid=None):
+    """dh (M, K) = (dy (M, N) . W2[:N, :K]) * gelu'(float(h)), h = bf16(x (M, N) . W1[:K, :N]^T + bias[:K]), and the
+    per-slab column sums of dh (fc1 bias partials): the fc2 dgrad with the GELU derivative recomputed from the saved
+    LayerNorm output x instead of read from HBM.  wt: the transposed fc2 operand (K rows, ld); w: the fc1 operand."""
+    M = dy.shape[0]
+    lib = _lib.load()
+    dh = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
+    parts = torch.empty((lib.cream_colsum128_slabs(M), K), dtype=torch.float32, device=dy.device)
+    with timing.region("gemm_nt_mul", flops=4 * M * N * K):
+        _lib.check(lib.cream_linear_dgrad_gelugrad(_p(dh), _p(parts), _p(dy), _p(wt), _p(x), _p(w), _p(bias), M, N, K,
+                                                   K if Kvalid is None else Kvalid, wt.stride(0), w.stride(0), _stream()),
+                   "cream_linear_dgrad_gelugrad")
+    return dh, parts
+
+
 def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None, parts_dtype=torch.float32):
     """-> (parts (S, N, K) fp32 or bf16, bias_parts (S, N) fp32 or None): partial products dy_s^T x_s over S
     slices of the token dimension (S chosen by the library) and, on request, the column sums of dy_s."""
@@ -988,7 +1009,7 @@ def _block_forward(blk, x2d, pend, dp1, B, N):
     o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
     p = linear_fwd(o.view(M, Q), wproj, bproj, E, Q)
     x1, c, mean2, rstd2 = add_ln_fwd(x, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
-    h, g = linear_gelu_fwd(c, w1, b1, F_, E)
+    h, g = linear_gelu_fwd(c, w1, b1, F_, E, want_grad=not gelu_recompute(E))      # h = gelu'(pre-activation) or None
     f = linear_fwd(g, w2, b2, E, F_)
     dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
     return x1, f, dims, (x, mean1, rstd1, a, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
@@ -1017,7 +1038,11 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
         jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
         extra.append(pw2)
     jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
-    dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)           # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
+    if h is None:                                            # gelu'(h) recomputed in the kernel from c and the fc1 operand
+        ops_ = operands(blk)
+        dh, pb1 = linear_dgrad_gelugrad(df, w2_t, c, ops_.w[2], ops_.b[2], E, F_)
+    else:
+        dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)       # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
     if not grouped:
         pw1, _ = wgrad_parts_async(dh, c)
         jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)

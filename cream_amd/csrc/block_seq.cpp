@@ -158,6 +158,20 @@ int wgrad_bf16_mode() {
     }
     return m;
 }
+// fc1 stores gelu(h) only and the fc2 dgrad recomputes gelu'(h) from a second product (cream_linear_dgrad_gelugrad): 116 MB
+// less through HBM per block at E = 384, F = 1344.  Needs E % 64 == 0 (else the stored-derivative path runs).
+std::atomic<int> g_gelu_recompute{-1};
+int gelu_recompute_mode() {
+    int m = g_gelu_recompute.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GELU_RECOMPUTE");
+        m = e ? (atoi(e) != 0) : 0;
+        g_gelu_recompute.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+bool gelu_recompute_for(const cream_block_desc* d) { return gelu_recompute_mode() && d->E % 64 == 0 && !d->inference; }
+
 // the split-K weight-gradient launch in either partial format (the workspace regions are sized for fp32)
 int wgrad_parts(int bf16, float* parts, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S, void* stream) {
     return bf16 ? cream_linear_wgrad_parts_bf16(parts, bias_parts, dy, x, M, N, K, S, stream)
@@ -261,7 +275,7 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
                              at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
     }
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
-    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(d->inference ? nullptr : at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
+    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad((d->inference || gelu_recompute_for(d)) ? nullptr : at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
                                   d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
     PTRY(K_GEMM_NT, stream, 2.0 * M * E * F, 0, cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
@@ -304,8 +318,12 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, wgrad_parts(wb16, at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     }
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
-    PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
-                                 main));
+    if (gelu_recompute_for(d))
+        PTRY(K_GEMM_NT_MUL, main, 4.0 * M * E * F, 0, cream_linear_dgrad_gelugrad(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.c), d->w1, d->b1,
+                                     M, E, F, d->F_valid > 0 ? d->F_valid : F, d->ld_w2_t, d->ld_w1, main));
+    else
+        PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+                                     main));
     if (!grouped) {
         if (!fork(main, side)) return CREAM_ERR_LAUNCH;
         PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, wgrad_parts(wb16, at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
@@ -375,6 +393,13 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));
     return CREAM_OK;
+}
+
+int cream_block_gelu_recompute(int on)
+{
+    const int prev = gelu_recompute_mode();
+    if (on >= 0) g_gelu_recompute.store(on != 0, std::memory_order_relaxed);
+    return prev;
 }
 
 int cream_block_wgrad_bf16(int on)

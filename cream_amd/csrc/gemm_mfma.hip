@@ -77,7 +77,9 @@ int launch_nt256(const NtParams& p, hipStream_t st)
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
-    if (p.N >= 960 && nt256_mode()) return launch_nt256<EPI>(p, st);
+    if constexpr (EPI != EPI_GELUGRAD_COLSUM) {                  // (two accumulator sets do not fit the macro tile's registers)
+        if (p.N >= 960 && nt256_mode()) return launch_nt256<EPI>(p, st);
+    }
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
@@ -198,6 +200,25 @@ int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const 
     p.aux = (const uint16_t*)factor; p.ldaux = K;
     p.colsum = colsum_parts;
     return launch_nt<EPI_MUL_COLSUM>(p, (hipStream_t)stream);
+}
+
+int cream_linear_dgrad_gelugrad(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* x, const void* w,
+                                const void* bias, int M, int N, int K, int Kvalid, int64_t ldwt, int64_t ldw, void* stream)
+{
+    // dh(M x K) = (dy(M x N) . W2(N x K)) * gelu'(h),  h = bf16(x(M x N) . W1(K x N)^T + bias): both NT products over the same
+    // (M x K) output tile, contraction N
+    const int rc = check_nt(dh, dy, wt, M, K, N, ldwt, N);
+    if (rc) return rc < 0 ? rc : CREAM_OK;
+    if (!colsum_parts || !x || !w || !bias || !aligned16(x) || !aligned16(w) || ldw < N || ldw % 8 || N % 64 || Kvalid <= 0 || Kvalid > K)
+        return CREAM_ERR_BAD_ARG;
+    NtParams p = plain(dh, dy, wt, M, K, N, ldwt);
+    p.colsum = colsum_parts;
+    p.A2 = (const uint16_t*)x; p.lda2 = N;
+    p.B2 = (const uint16_t*)w; p.ldb2 = ldw;
+    p.K2 = N;
+    p.bias = (const uint16_t*)bias;
+    p.nvalid = Kvalid;
+    return launch_nt<EPI_GELUGRAD_COLSUM>(p, (hipStream_t)stream);
 }
 
 int cream_linear_wgrad_splits(int M, int N, int K)

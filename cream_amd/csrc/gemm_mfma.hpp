@@ -47,7 +47,7 @@
 namespace cream {
 namespace gemm {
 
-enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3 };
+enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3, EPI_GELUGRAD_COLSUM = 4 };
 
 // Phase timestamps for tools/probes/gemm_nt_probe.hip (compiled out of the library)
 #ifdef GEMM_PROFILE
@@ -71,6 +71,13 @@ struct NtParams {
     int64_t ldaux;
     float* colsum;          // EPI_MUL_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
     int nvalid;             // EPI_BIAS_GELU: columns n >= nvalid are written as zeros (N padded up to a multiple of 8)
+    // EPI_GELUGRAD_COLSUM (fc2 dgrad with the GELU derivative RECOMPUTED instead of read): a second product over the same
+    // output tile, H = A2 (M x K2) . B2 (N x K2)^T (the fc1 forward: A2 = LN2 output, B2 = W1), h = bf16(H + bias);
+    // out = (A . B^T) * gelu'(h) (0 for n >= nvalid) + per-slab column sums.  K2 == K, K % 64 == 0, plain operands (no segments).
+    const uint16_t* A2;
+    const uint16_t* B2;
+    int64_t lda2, ldb2;
+    int K2;
 };
 
 // erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
     static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
     static_assert(HM >= 32 && WTM % HM == 0 && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles of one wave row, inside one stage");
-    static_assert(EPI != EPI_MUL_COLSUM || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
+    static_assert((EPI != EPI_MUL_COLSUM && EPI != EPI_GELUGRAD_COLSUM) || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
     char* const smem = LdsBlock<NST * STAGE * 2>::get();
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
     float* const ctile = reinterpret_cast<float*>(smem + STAGE * 2);           // stage 1
@@ -169,6 +176,14 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         const int row = (wave + NW * i) * 8 + (lane >> 3);
         cch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
     }
+    auto sources2 = [&](const uint16_t* (&src)[NPIECE], int m0, int n0) {      // the second product: plain operands
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int piece = wave + NW * i, row = piece * 8 + (lane >> 3);
+            if (row < BM) src[i] = p.A2 + (int64_t)min(m0 + row, p.M - 1) * p.lda2 + cch[i];
+            else src[i] = p.B2 + (int64_t)min(n0 + row - BM, p.N - 1) * p.ldb2 + cch[i];
+        }
+    };
     auto sources = [&](const uint16_t* (&src)[NPIECE], int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
@@ -207,12 +222,13 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     };
 
     f32x16 acc[TN][TM];
+    f32x16 acc2[EPI == EPI_GELUGRAD_COLSUM ? TN : 1][EPI == EPI_GELUGRAD_COLSUM ? TM : 1];      // the second product (pre-activation)
 
     // one K-step from stage `buf`; vc = valid 8-wide chunks (8 unless TAIL).  Fragments are double
     // buffered in registers: the reads of sub-step ks+1 are issued BEFORE the MFMAs of sub-step ks
     // (pinned with sched_group_barrier), so LDS latency hides behind matrix work instead of being
     // paid four times per K-step by an in-order wave.
-    auto step = [&](int buf, int vc, auto tail) {
+    auto step_into = [&](f32x16 (&acc)[TN][TM], int buf, int vc, auto tail) {
         constexpr bool T = decltype(tail)::value;
         const uint16_t* At = lds + buf * STAGE;
         const uint16_t* Bt = At + BM * BK;
@@ -250,9 +266,12 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             }
         }
     };
+    auto step = [&](int buf, int vc, auto tail) { step_into(acc, buf, vc, tail); };
     using No = std::integral_constant<bool, false>;
     using Yes = std::integral_constant<bool, true>;
     const int nfull = K / BK, rem = K % BK, nk = nfull + (rem ? 1 : 0);
+    const int nk2 = EPI == EPI_GELUGRAD_COLSUM ? p.K2 / BK : 0;          // steps of the second product (no tail)
+    const uint16_t* src2[EPI == EPI_GELUGRAD_COLSUM ? NPIECE : 1];
 
     // epilogue geometry: a thread owns an 8-column chunk of rows r0, r0 + RPP, ... of each half tile
     constexpr int CPR = BN / 8;                                 // chunks per tile row
@@ -265,6 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     int t = xcd_remap(orig, ntiles);
     int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
     sources(src, m0, n0);
+    if constexpr (EPI == EPI_GELUGRAD_COLSUM) sources2(src2, m0, n0);
     if (nk > 0) { if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{}); }
 
     for (;;) {
@@ -282,6 +302,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s + 1 < nk) { if (s + 1 < nfull) issue(src, (s + 1) * BK, (s + 1) & 1, No{}); else issue(src, (s + 1) * BK, (s + 1) & 1, Yes{}); }
+            else if constexpr (EPI == EPI_GELUGRAD_COLSUM) {    // the stream of K-steps continues with the second product
+                if (s + 1 == nk) { kb = 0; kin = 0; }           // the B-side K offset restarts with the second product
+                if (s + 1 < nk + nk2) issue(src2, (s + 1 - nk) * BK, (s + 1) & 1, No{});
+            }
         };
         for (int s = 0; s < nfull; ++s) {                       // (the tail step lives outside the loop: one
             top_of_step(s);                                     //  accumulator live range, no phi copies)
@@ -292,6 +316,39 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         if (rem) {
             top_of_step(nfull);
             step(nfull & 1, rem >> 3, Yes{});
+        }
+        if constexpr (EPI == EPI_GELUGRAD_COLSUM) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc2[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = nk; s < nk + nk2; ++s) {
+                top_of_step(s);
+                step_into(acc2, s & 1, 8, No{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            // dh = (dy . W2) * gelu'(h), h = bf16(c . W1^T + b1): element-wise in the accumulator layout (a lane owns output
+            // row m and, per 32 x 32 tile, four runs of four columns n) — gelu is evaluated in fp32 ON the bf16 value, as the
+            // forward's epilogue does (supernet_transformer.py:14-16, :276-277); padded columns (n >= nvalid) give 0
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nn = n0 + wn * WTN + tn * 32 + 8 * r4 + 4 * g;
+                    u32x2v braw2 = u32x2v{0, 0};
+                    if (nn < p.N) braw2 = *reinterpret_cast<const u32x2v*>(p.bias + nn);
+                    const float b4[4] = {__uint_as_float(braw2[0] << 16), __uint_as_float(braw2[0] & 0xFFFF0000u),
+                                         __uint_as_float(braw2[1] << 16), __uint_as_float(braw2[1] & 0xFFFF0000u)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool live = nn + e < p.nvalid;
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const float hb = __uint_as_float(((uint32_t)(uint16_t)f2bf(acc2[tn][tm][4 * r4 + e] + b4[e])) << 16);
+                            acc[tn][tm][4 * r4 + e] *= live ? gelu_grad_f(hb) : 0.f;
+                        }
+                    }
+                }
         }
         GPROF(2);
 
@@ -307,6 +364,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             t = xcd_remap(orig, ntiles);
             m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
             sources(src, m0, n0);
+            if constexpr (EPI == EPI_GELUGRAD_COLSUM) sources2(src2, m0, n0);
             kb = 0; kin = 0;
             if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{});
         }
@@ -392,6 +450,15 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     }
                     if (p.out) *reinterpret_cast<u32x4v*>(o) = pb;          // (no gelu' without a backward: inference, frozen teacher)
                     *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
+                } else if constexpr (EPI == EPI_GELUGRAD_COLSUM) {
+                    u32x4v db;                                  // (the factor is already in the accumulators)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        db[e] = f2bf_pair(v[2 * e], v[2 * e + 1]);
+                        cs[2 * e] += __uint_as_float(db[e] << 16);
+                        cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
+                    }
+                    *reinterpret_cast<u32x4v*>(o) = db;
                 } else {   // EPI_MUL_COLSUM
                     const u32x4v fb = auxv[j];
                     u32x4v db;
@@ -404,7 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     *reinterpret_cast<u32x4v*>(o) = db;
                 }
             }
-            if constexpr (EPI == EPI_MUL_COLSUM) {
+            if constexpr (EPI == EPI_MUL_COLSUM || EPI == EPI_GELUGRAD_COLSUM) {
                 if (((half + 1) * HM) % SLAB == 0) {            // a 128-row slab is complete: its column sums leave
                     __syncthreads();                            // the fp32 pass has been consumed
                     float* red = ctile;                         // [RPP][BN]

@@ -375,6 +375,13 @@ int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int 
                            int kseg, int64_t kseg_stride, void* stream);
 int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* factor,
                              int M, int N, int K, int64_t ldwt, void* stream);
+/* fc2 dgrad with the GELU derivative RECOMPUTED instead of read (supernet_transformer.py:275-285 backward): the kernel forms
+ * BOTH dy . W2 and the fc1 pre-activation h = bf16(x . W1^T + bias) for an output tile (x = the LayerNorm output the forward
+ * fed to fc1, w = the fc1 operand (K rows, ld ldw)) and writes dh = (dy . W2) * gelu'(float(h)) (0 for columns >= Kvalid) and
+ * its per-slab column sums — the forward then stores gelu(h) only: 68 MB less written and 48 MB less read per block at
+ * E = 384, F = 1344 for 26 GFLOP of matrix-core work that the HBM-bound kernel has to spare.  N % 64 == 0. */
+int cream_linear_dgrad_gelugrad(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* x, const void* w,
+                                const void* bias, int M, int N, int K, int Kvalid, int64_t ldwt, int64_t ldw, void* stream);
 int cream_linear_wgrad_splits(int M, int N, int K);
 int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N,
                              int K, int S, void* stream);
@@ -575,6 +582,11 @@ int cream_block_fuse_ln(int on);
 /* cream_block_bwd writes the split-K partial tiles of the four weight gradients as bf16 (1) or fp32 (0); returns the
  * previous setting; on < 0 only queries.  Initial value: CREAM_WGRAD_BF16 in the environment, else 1. */
 int cream_block_wgrad_bf16(int on);
+/* 1: cream_block_fwd stores gelu(h) only and cream_block_bwd recomputes gelu'(h) inside the fc2 dgrad
+ * (cream_linear_dgrad_gelugrad) for blocks with E % 64 == 0; 0: the forward also stores gelu'(h).  Returns the previous
+ * setting; on < 0 only queries.  The setting must not change between a forward and its backward.  Initial value:
+ * CREAM_GELU_RECOMPUTE in the environment, else 0. */
+int cream_block_gelu_recompute(int on);
 
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).

@@ -154,3 +154,14 @@ def test_shape_predicates_and_switches_without_a_device():
     prev = lib.cream_block_fuse_ln(1)
     assert lib.cream_block_fuse_ln(prev) == 1
     assert lib.cream_block_fuse_ln(prev) == prev
+
+
+def test_library_has_no_undefined_kernel_stubs():
+    """Every kernel instantiation the host code launches must have its host stub in the library: clang silently drops the stub
+    of a __global__ template whose body fails a DEFERRED host-side check (round 4: a target builtin inside a lambda called under
+    `if constexpr`), the shared object still links — and the first launch dies with an unresolved symbol on the GPU box."""
+    import subprocess
+    from cream_amd import build
+    out = subprocess.run(["nm", "-D", "--undefined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    bad = [l for l in out.splitlines() if "__device_stub__" in l or " cream_" in l]
+    assert not bad, bad

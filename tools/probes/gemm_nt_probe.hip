@@ -36,6 +36,15 @@ __global__ void ref_nt(float* out, NtParams p) {
         s += bfv(p.A[(int64_t)m * p.lda + k]) * bfv(b[(int64_t)(k / p.kseg) * p.kseg_stride + k % p.kseg]);
     out[i] = s;
 }
+__global__ void ref_nt2(float* out, NtParams p) {                 // the second product of EPI_GELUGRAD_COLSUM (plain operands)
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float s = 0.f;
+    for (int k = 0; k < p.K2; ++k) s += bfv(p.A2[(int64_t)m * p.lda2 + k]) * bfv(p.B2[(int64_t)n * p.ldb2 + k]);
+    out[i] = s;
+}
+__device__ const float* g_ref2 = nullptr;
 // expected outputs of an epilogue from the fp32 reference product; max error against what the kernel wrote
 __global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, int bm) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -54,6 +63,10 @@ __global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, 
         (void)hb;
         err = fabsf(g - got2) / (1.f + fabsf(g));
         atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
+    } else if (epi == EPI_GELUGRAD_COLSUM) {
+        const float h = g_ref2[i] + bfv(p.bias[n]);
+        uint32_t hb = __float_as_uint(h); hb += 0x7FFF + ((hb >> 16) & 1); hb &= 0xFFFF0000u;      // bf16 round to nearest even
+        want = n < p.nvalid ? v * gelu_grad_f(__uint_as_float(hb)) : 0.f;
     } else want = v * bfv(p.aux[(int64_t)m * p.ldaux + n]);
     err = fabsf(want - got) / (1.f + fabsf(want));
     atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(err == err ? err : 1e30f));
@@ -69,6 +82,7 @@ __global__ void check_colsum(float* maxerr, NtParams p, int bm) {
     atomicMax(reinterpret_cast<int*>(maxerr + 2), __float_as_int(err == err ? err : 1e30f));
 }
 
+
 struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); };
 #define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
 static const Variant VARIANTS[] = {
@@ -76,6 +90,8 @@ static const Variant VARIANTS[] = {
     V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_MUL_COLSUM, 2),
     // round 4: the 256 x 256 macro tile (8 waves, 128 KB of dynamic LDS, one workgroup per CU)
     V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
+    // round 4: fc2 dgrad with the GELU derivative recomputed from a second product over the same tile
+    V(128, 128, 2, 2, 2, EPI_GELUGRAD_COLSUM, 2),
 };
 static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 512 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
@@ -290,6 +306,12 @@ int main(int argc, char** argv)
         p.nseg = s.nseg >= s.N ? s.N : s.nseg; p.nseg_stride = nseg_stride; p.kseg = s.kseg >= s.K ? s.K : s.kseg; p.kseg_stride = kseg_stride;
         p.M = s.M; p.N = s.N; p.K = s.K; p.nvalid = s.N; p.out = dout; p.out2 = dout2; p.ldo = s.N; p.bias = db; p.aux = dh; p.ldaux = s.N; p.colsum = dcs;
         ref_nt<<<(unsigned)((no + 255) / 256), 256>>>(dref, p);
+        // second product of EPI_GELUGRAD_COLSUM: the same activations against the LAST N rows of the weight buffer (a different
+        // matrix), K2 = K rounded down to a multiple of 64
+        float* dref2; CK(hipMalloc(&dref2, no * 4));
+        p.A2 = dx; p.lda2 = s.K; p.B2 = dw + (nw - (size_t)s.N * s.ldb); p.ldb2 = s.ldb; p.K2 = s.K / 64 * 64;
+        ref_nt2<<<(unsigned)((no + 255) / 256), 256>>>(dref2, p);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ref2), &dref2, sizeof(dref2)));
         CK(hipDeviceSynchronize());
         // the library on the same problem (plain layouts only): col-major C(N x M) = W('t', lda = ldb) . x('n', ldb = K) + bias
         double lib_us = -1;
@@ -335,13 +357,14 @@ int main(int argc, char** argv)
         printf("%-38s M=%5d N=%4d K=%4d  library best-of-16 %7.1f us %6.0f TF/s\n", s.what, s.M, s.N, s.K, lib_us, lib_us > 0 ? fl / lib_us / 1e6 : 0.0);
         for (const Variant& v : VARIANTS) {
             if (!plain && v.epi != EPI_BIAS) continue;
+            if (v.epi == EPI_GELUGRAD_COLSUM && (s.K % 64 || p.K2 == 0)) continue;
             if (only_var && !strstr(v.name, only_var)) continue;
             CK(hipMemset(dout, 0xFF, no * 2));
             CK(hipMemset(dout2, 0xFF, no * 2));
             CK(hipMemset(dmax, 0, 16));
             launch(v, p);
             check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
-            if (v.epi == EPI_MUL_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
+            if (v.epi == EPI_MUL_COLSUM || v.epi == EPI_GELUGRAD_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
             for (int i = 0; i < 3; ++i) launch(v, p);
@@ -355,7 +378,7 @@ int main(int argc, char** argv)
                    lib_us > 0 ? lib_us / us : 0.0, hm[0], hm[1], hm[2], bad ? " <-- WRONG" : "");
             if (getenv("GEMM_PHASES")) phase_profile(v, p);
         }
-        hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dh); hipFree(dcs);
+        hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dref2); hipFree(dh); hipFree(dcs);
         fflush(stdout);
     }
     return 0;
