@@ -87,6 +87,7 @@ struct BwdArgs {
     RelGeom G;
     float scale;
     int nitems;                                      // B * H (dQ kernel: persistent workgroups walk them)
+    int stagger;                                     // one-pass kernel: start offset between the 8 phase groups (x 64 cycles)
 };
 
 // ---- pieces shared by forward and backward ---------------------------------------------
@@ -1464,6 +1465,11 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
     }
     BwdArgs aa = a;
     aa.nitems = B * a.H;
+    {
+        static int stagger = -1;                     // CREAM_ATTN_BWD1_STAGGER (x 64 cycles per group); default below
+        if (stagger < 0) { const char* e = getenv("CREAM_ATTN_BWD1_STAGGER"); stagger = e ? atoi(e) : 0; }
+        aa.stagger = aa.nitems > fwd_persistent_grid() ? stagger : 0;      // (a single round of items: nothing to de-phase)
+    }
     short* img = reinterpret_cast<short*>(a.dlt);
     hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, img, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
@@ -1560,7 +1566,7 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
          (uintptr_t)dout | (uintptr_t)out | (uintptr_t)sp | (uintptr_t)dlt | (uintptr_t)qe | (uintptr_t)de |
          (uintptr_t)dtab | (uintptr_t)tkv | (uintptr_t)tkh | (uintptr_t)tvv | (uintptr_t)tvh) % 16)
         return CREAM_ERR_BAD_ARG;
-    BwdArgs a;
+    BwdArgs a{};
     a.q = q; a.k = k; a.v = v; a.sb = sb; a.sn = sn; a.sh = sh;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dsb = dsb; a.dsn = dsn; a.dsh = dsh;
     a.dout = dout; a.out = out; a.lse = lse; a.sp = sp;

@@ -160,6 +160,28 @@ __device__ __forceinline__ void prefetch_dma(const short* src, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(src), "s"(lds_dst));
 }
 
+// ---- the item's matrices travel global -> LDS by DMA (no register staging) --------------------------------------------
+// A register-staged prefetch of the next item does not survive here: with ~230 live registers the compiler waits for every
+// prefetched vector at once and parks it in scratch (round-4 builds: the "prefetch" was a load, a wait, a scratch store and
+// a scratch reload).  LDS-DMA needs no registers: one wave instruction moves 1 KB = 8 rows x 128 B into a lane-linear image;
+// the chunk swizzle of the tile (chunk ^ swz128(row)) is applied to the SOURCE address, rows beyond N come from a zero line.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void dma_1k(const short* src, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+// rows [0, 224) of one matrix (row stride rs elements) into the LDS region at byte address lds_base: 28 pieces, 4 per wave
+__device__ __forceinline__ void mat_dma(const short* src, int64_t rs, uint32_t lds_base, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + NT * i, row = piece * 8 + (lane >> 3), cc = lane & 7;
+        const short* s = row < N14 ? src + (int64_t)row * rs + ((cc ^ swz128(row)) << 3) : reinterpret_cast<const short*>(g_zero_line);
+        dma_1k(s, lds_base + piece * 1024);
+    }
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 struct Mat4 { u32x4v v[4]; };                        // 224 x 64 bf16 = 1792 chunks of 16 B / 448 threads
 __device__ __forceinline__ void mat4_load(Mat4& r, const short* src, int64_t rs, int tid) {
 #pragma unroll
@@ -382,6 +404,15 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
 
     fill_onehot_swz(smem + OFF_OH);
 
+    // STAGGER.  All workgroups of a launch do the same work on equal items, so they ask HBM for their 137 KB and write their
+    // 75 KB at the same moments — a convoy: every memory phase runs at 1 / 256 of the chip's bandwidth while HBM idles
+    // under the step loops.  Eight phase groups (workgroups b, b + 64, ... share an XCD: the groups cut ACROSS the XCDs, so
+    // each XCD's fabric link sees an eighth of its workgroups at a time) start `stagger` x 64 cycles apart.
+    if (a.stagger > 0) {
+        const int grp = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < grp * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+
     // ---- software pipeline over the workgroup's items: the NEXT item's operands are requested during the epilogue of
     // the current one (K, V as soon as the step loop is over — their LDS regions are dead then —, Q, dO, this lane's
     // row of O and its softmax statistic before the table-gradient jobs), so an item starts with its loads landed.
@@ -390,21 +421,13 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
     int item = blockIdx.x;
     if (item >= a.nitems) return;
     Item I = item_of(item);
-    Mat4 mq, md;
-    bf16x8 ob[4];
-    float lse_r;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem));
     {
-        const int tid0 = threadIdx.x, l0 = tid0 & 63, q0 = min((tid0 >> 6) * 32 + (l0 & 31), N14 - 1);
-        Mat4 mk, mv;
-        mat4_load(mk, I.kpg, a.sn, tid0);
-        mat4_load(mv, I.vpg, a.sn, tid0);
-        mat4_load(mq, I.qp, a.sn, tid0);
-        mat4_load(md, I.dop, orow, tid0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(I.outp + (int64_t)q0 * orow + ks * 16 + (l0 >> 5) * 8);
-        lse_r = a.lse[I.bh * N14 + q0];
-        mat4_store(mk, smem + OFF_K, tid0);
-        mat4_store(mv, smem + OFF_V, tid0);
+        const int w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l0 = threadIdx.x & 63;
+        mat_dma(I.kpg, a.sn, lds0 + OFF_K, w0, l0);
+        mat_dma(I.vpg, a.sn, lds0 + OFF_V, w0, l0);
+        mat_dma(I.qp, a.sn, lds0 + OFF_Q, w0, l0);
+        mat_dma(I.dop, orow, lds0 + OFF_D, w0, l0);
     }
 
     for (;;) {
@@ -423,13 +446,16 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
         const int qcl = min(qi, N14 - 1);
         const int qr = qi > 0 ? (qi - 1) / G14 : 0, qc = qi > 0 ? (qi - 1) - qr * G14 : 0;
         unsigned char* myslot = smem + OFF_X + wave * SLOT_B;
-        __syncthreads();                             // previous item: the table-gradient jobs are done with Q, dO and the slots
-        mat4_store(mq, smem + OFF_Q, tid);
-        mat4_store(md, smem + OFF_D, tid);
-        const float m2 = tok_ok ? lse_r * LOG2E : INFINITY;                    // padding queries: P = 0
         const int b = I.b, h = I.h;
         const int64_t bh = I.bh;
-        __syncthreads();
+        // this lane's row of O (for delta) and its softmax statistic
+        bf16x8 ob[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(I.outp + (int64_t)qcl * orow + ks * 16 + g * 8);
+        const float lse_r = a.lse[bh * N14 + qcl];
+        dma_wait_all();                              // this wave's pieces of K, V, Q, dO have landed ...
+        __syncthreads();                             // ... and everybody's
+        const float m2 = tok_ok ? lse_r * LOG2E : INFINITY;                    // padding queries: P = 0
         PROF_MARK();
 
         // ---- query-owner prologue: delta, slot extensions of q and dO ----------------------------------------
@@ -571,25 +597,22 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
         PROF_MARK();
 
         // ---- epilogue ------------------------------------------------------------------------------------------
-        // K and V are dead (every wave is past its last producer phase): the next item's K, V start travelling now
-        // vmcnt retires in issue order: a load issued behind this epilogue's stores would make its consumer wait for the
-        // stores' write-back as well, so every load group goes out BEFORE the stores that follow it in time
-        Mat4 mk, mv;
+        // K and V are dead (every wave is past its last producer phase): the next item's K, V start travelling NOW, by
+        // DMA straight into their LDS regions; Q and dO follow after the table-gradient jobs (their last readers)
         if (more && !BWD1_EXP_NOLOAD) {
-            mat4_load(mk, In.kpg, a.sn, tid);
-            mat4_load(mv, In.vpg, a.sn, tid);
+            mat_dma(In.kpg, a.sn, lds0 + OFF_K, wave, lane);
+            mat_dma(In.vpg, a.sn, lds0 + OFF_V, wave, lane);
         }
         consume(wave + 1 < NT ? wave + 1 : 0);       // step 6's tiles: query tile (wave - 6) mod 7
         PROF_MARK();
-        // key-owner results: the rows of dK, dV of key tile `wave`, staged in this wave's (dead) K rows
-        unsigned char* stage = smem + OFF_K + wave * 4096;
+        // key-owner results: the rows of dK, dV of key tile `wave` leave through this wave's exchange slot (its P / dS tiles
+        // are consumed) as whole 128-byte rows
         const int64_t goff = (int64_t)b * a.dsb + (int64_t)(wave * 32) * a.dsn + (int64_t)h * a.dsh;
         if (!BWD1_EXP_NOSTORE) {
-            store_tile_staged(stage, reinterpret_cast<short*>(a.dk) + goff, a.dsn, wave * 32, dk, lane);
-            store_tile_staged(stage, reinterpret_cast<short*>(a.dv) + goff, a.dsn, wave * 32, dv, lane);
+            store_tile_staged(myslot, reinterpret_cast<short*>(a.dk) + goff, a.dsn, wave * 32, dk, lane);
+            store_tile_staged(myslot, reinterpret_cast<short*>(a.dv) + goff, a.dsn, wave * 32, dv, lane);
         }
         PROF_MARK();
-        // operands of the table-gradient job(s) of this wave that come from global memory: requested now, used after the barrier
         const int job0 = wave, job1 = wave + NT;     // job = tab * 2 + dt; only wave 0 has a second one (job 7)
         {
             bf16x8 bk[4];
@@ -601,6 +624,8 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
                     dq[dt] = mma16(*reinterpret_cast<const bf16x8*>(kt_img + (c32 + 32 * dt) * 64 + g * 32 + ks * 8), bk[ks], dq[dt]);
+            // dq rows out through the slot, THEN the dL' tile takes it (its fragments are still in registers)
+            if (!BWD1_EXP_NOSTORE) store_tile_staged(myslot, reinterpret_cast<short*>(a.dq) + goff, a.dsn, wave * 32, dq, lane);
             // dL' tile [32 q][64 u'] for the table-gradient jobs (chunks 4g + ks of row q)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -609,20 +634,8 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 *reinterpret_cast<u32x4v*>(myslot + c32 * 128 + (((4 * g + ks) ^ swz128(c32)) << 4)) = u.v;
             }
         }
-        if (more && !BWD1_EXP_NOLOAD) {              // next Q, dO, O row, lse -> registers (before the dq stores: in-order vmcnt)
-            mat4_load(mq, In.qp, a.sn, tid);
-            mat4_load(md, In.dop, orow, tid);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(In.outp + (int64_t)qcl * orow + ks * 16 + g * 8);
-            lse_r = a.lse[In.bh * N14 + qcl];
-        }
-        if (!BWD1_EXP_NOSTORE) store_tile_staged(stage, reinterpret_cast<short*>(a.dq) + goff, a.dsn, wave * 32, dq, lane);
         PROF_MARK();
-        __syncthreads();                             // all dL' tiles are in place; nobody reads the staged rows any more
-        if (more && !BWD1_EXP_NOLOAD) {              // next K, V -> LDS
-            mat4_store(mk, smem + OFF_K, tid);
-            mat4_store(mv, smem + OFF_V, tid);
-        }
+        __syncthreads();                             // all dL' tiles are in place
         PROF_MARK();
 
         // ---- table gradients: job = tab * 2 + dt;  dT^T (64 d x 32 u) = X^T (d x q) . R (q x u)
@@ -669,6 +682,11 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                     *reinterpret_cast<f32x4v*>(dst + 8 * r4) = f32x4v{old[r4][0] + acc[4 * r4], old[r4][1] + acc[4 * r4 + 1],
                                                                       old[r4][2] + acc[4 * r4 + 2], old[r4][3] + acc[4 * r4 + 3]};
             }
+        }
+        if (more && !BWD1_EXP_NOLOAD) {
+            __syncthreads();                         // every table-gradient job is done with Q, dO (and the slots)
+            mat_dma(In.qp, a.sn, lds0 + OFF_Q, wave, lane);
+            mat_dma(In.dop, orow, lds0 + OFF_D, wave, lane);
         }
         PROF_MARK();
 #ifdef ATTN_PROFILE_ITEM1
