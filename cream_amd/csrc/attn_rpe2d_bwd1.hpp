@@ -263,17 +263,21 @@ __device__ __forceinline__ void ext_from_lookups14(bf16x8 (&xe)[2], const f32x16
 // in global memory; all 16 row fragments are requested before the first MFMA.  Rounding the lookups to bf16 before the
 // shift gives the same bits as rounding the shifted values (the shift is a permutation); the class-token value is
 // summed in fp32 first.
-__device__ __forceinline__ void lookups_ext14_pair(bf16x8 (&qe)[2], bf16x8 (&de)[2], const bf16x8 (&qb)[4], const bf16x8 (&dob)[4],
-                                                   const short* img, unsigned char* scr, int lane, bool tile0, int qr, int qc) {
+struct TabFrags { bf16x8 tk[2][4], tv[2][4]; };       // row fragments of the key / value table images (vertical, horizontal)
+__device__ __forceinline__ void load_tab_frags(TabFrags& f, const short* img, int lane) {
     const int c32 = lane & 31, g = lane >> 5;
-    bf16x8 tk[2][4], tv[2][4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            tk[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_KR + (32 * t + c32) * 64 + ks * 16 + g * 8);
-            tv[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_VR + (32 * t + c32) * 64 + ks * 16 + g * 8);
+            f.tk[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_KR + (32 * t + c32) * 64 + ks * 16 + g * 8);
+            f.tv[t][ks] = *reinterpret_cast<const bf16x8*>(img + IMG_VR + (32 * t + c32) * 64 + ks * 16 + g * 8);
         }
+}
+__device__ __forceinline__ void lookups_ext14_pair(bf16x8 (&qe)[2], bf16x8 (&de)[2], const bf16x8 (&qb)[4], const bf16x8 (&dob)[4],
+                                                   const TabFrags& tf, unsigned char* scr, int lane, bool tile0, int qr, int qc) {
+    const bf16x8 (&tk)[2][4] = tf.tk;
+    const bf16x8 (&tv)[2][4] = tf.tv;
     f32x16 kv = {}, kh = {}, vv = {}, vh = {};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -453,6 +457,8 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(I.outp + (int64_t)qcl * orow + ks * 16 + g * 8);
         const float lse_r = a.lse[bh * N14 + qcl];
+        TabFrags tf;                                 // (requested here: their round trip runs under the wait for the matrices)
+        load_tab_frags(tf, img, lane);
         dma_wait_all();                              // this wave's pieces of K, V, Q, dO have landed ...
         __syncthreads();                             // ... and everybody's
         const float m2 = tok_ok ? lse_r * LOG2E : INFINITY;                    // padding queries: P = 0
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
                 for (int e = 0; e < 8; ++e) delta += bf2f(dob[ks][e]) * bf2f(ob[ks][e]);
             delta += __shfl_xor(delta, 32);
             dsc = tok_ok ? delta * a.scale : 0.f;
-            lookups_ext14_pair(qe, de, qb, dob, img, myslot, lane, wave == 0, qr, qc);
+            lookups_ext14_pair(qe, de, qb, dob, tf, myslot, lane, wave == 0, qr, qc);
         }
 
         PROF_MARK();
