@@ -682,12 +682,20 @@ def head_operands(head, fresh=True):
     return ops
 
 
+def _no_frozen_parameters(mod):
+    """The native backward of a node writes the gradient of EVERY parameter of that node into `.grad`: a node with
+    frozen parameters that is differentiated through (partial fine-tuning) takes the composed path instead."""
+    if not torch.is_grad_enabled():
+        return True
+    return all(p.requires_grad for p in mod.parameters(recurse=True))
+
+
 def head_supported(head, feat):
     return (NATIVE_ENDS_GRADS and feat.is_cuda and feat.dim() == 2 and feat.dtype == torch.float32
             and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and getattr(head, 'bias', None) is not None and not getattr(head, 'scale', False)
             and head.weight.dtype == torch.float32 and head.sample_in_dim % 8 == 0 and head.sample_out_dim % 8 == 0
-            and head.sample_in_dim == feat.shape[1])
+            and head.sample_in_dim == feat.shape[1] and _no_frozen_parameters(head))
 
 
 # Parameter gradients of the two ends of forward_features and of the classifier are ADDED INTO p.grad by one
@@ -891,6 +899,10 @@ def stem_supported(model, x):
         return False
     if pos is not None and pos.shape[1] != (H // ph) * (W // pw) + 1:
         return False
+    if torch.is_grad_enabled():                     # (see _no_frozen_parameters)
+        ends = [pe.proj.weight, pe.proj.bias, model.cls_token] + ([pos] if pos is not None else [])
+        if not all(p.requires_grad for p in ends):
+            return False
     return not (model.training and (model.sample_dropout or 0.0) > 0.0)
 
 
@@ -973,7 +985,7 @@ def supported(blk, x):
                  or (NATIVE_BLOCK and (blk.sample_ffn_embed_dim_this_layer + 7) // 8 * 8 <= blk.fc1.weight.shape[0]))
             and blk.sample_out_dim == blk.sample_embed_dim
             and a.qkv.bias is not None and a.proj.bias is not None and blk.fc1.bias is not None
-            and blk.fc2.bias is not None)
+            and blk.fc2.bias is not None and _no_frozen_parameters(blk))
 
 
 def _tables(at):

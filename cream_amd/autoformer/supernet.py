@@ -300,7 +300,8 @@ class Vision_TransformerSuper(nn.Module):
                 keep = self._keep_prob(tuple(probs), x.device)
                 scales = torch.floor(keep + torch.rand(len(active), 2, B, device=x.device)) / keep
             if (NATIVE_ENDS and _block.NATIVE_BLOCK and self.pre_norm and self.gp and x.shape[1] > 1
-                    and self.norm.weight.dtype == torch.float32 and self.norm.bias is not None):
+                    and self.norm.weight.dtype == torch.float32 and self.norm.bias is not None
+                    and _block._no_frozen_parameters(self.norm)):
                 # ... and the final LayerNorm + token mean ride on the same node (the last block's output stays pending)
                 return _block.StackFunction.apply(x, scales, active, self.norm.weight, self.norm.bias, self.norm.eps)
             x = _block.StackFunction.apply(x, scales, active, None, None, 1e-5)

@@ -192,6 +192,20 @@ PROVIDED_CHECKPOINTS = {
 }
 
 
+def _load_checkpoint_file(path):
+    """DeiT-style files carry an `argparse.Namespace` (`args`) next to `model`: allow that one class through the
+    tensors-only unpickler; anything else in the file is refused with a message saying what to do instead."""
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise RuntimeError(f"{path}: holds objects the tensors-only unpickler refuses ({e}); load it yourself "
+                           "(torch.load(..., weights_only=False) if you trust the file) and pass the dictionary "
+                           "as `checkpoint`") from e
+
+
 def create_zoo_model(name, checkpoint=None, **kwargs):
     """`register_rpe_model` of rpe_models.py:22-43 without the download: build the named model and, if `checkpoint` (a path
     or the loaded dictionary of a published `<name>.pth`: {'model': state_dict}) is given, load it strictly.  Files are read
@@ -200,7 +214,7 @@ def create_zoo_model(name, checkpoint=None, **kwargs):
     size, rpe_on = PROVIDED_CHECKPOINTS[name]
     model = deit_irpe(size, rpe_on=rpe_on, **kwargs)
     if checkpoint is not None:
-        ckpt = checkpoint if isinstance(checkpoint, dict) else torch.load(checkpoint, map_location='cpu', weights_only=True)
+        ckpt = checkpoint if isinstance(checkpoint, dict) else _load_checkpoint_file(checkpoint)
         model.load_state_dict(ckpt['model'])
     return model
 

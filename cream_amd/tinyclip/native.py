@@ -74,11 +74,26 @@ def operands(blk):
 
 def supported(transformer, x, attn_mask, causal=False):
     """`causal`: the caller vouches that `attn_mask` is the additive upper-triangular -inf mask (TextEncoder's buffer)."""
-    blk = transformer.resblocks[0] if len(transformer.resblocks) else None
-    return (blk is not None and (attn_mask is None or causal) and x.is_cuda and x.dim() == 3
+    if not len(transformer.resblocks):
+        return False
+    if not ((attn_mask is None or causal) and x.is_cuda and x.dim() == 3
             and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-            and transformer.head_dim == 64 and transformer.width % 8 == 0 and x.shape[1] <= 2048
-            and isinstance(blk.mlp.gelu, torch.nn.GELU) and getattr(blk.mlp.gelu, 'approximate', 'none') == 'none'
+            and transformer.head_dim == 64 and transformer.width % 8 == 0 and x.shape[1] <= 2048):
+        return False
+    if not all(_block_supported(blk) for blk in transformer.resblocks):
+        return False
+    if torch.is_grad_enabled():
+        # the native backward writes a `.grad` for every parameter of every block: a tower with frozen parameters that is
+        # differentiated through (a locked tower, partial fine-tuning) keeps the composed path
+        flags = [p.requires_grad for p in transformer.resblocks.parameters()]
+        if (x.requires_grad or any(flags)) and not all(flags):
+            return False
+    return True
+
+
+def _block_supported(blk):
+    """Every block is looked at, not the first alone."""
+    return (isinstance(blk.mlp.gelu, torch.nn.GELU) and getattr(blk.mlp.gelu, 'approximate', 'none') == 'none'
             and isinstance(blk.ln_attn, torch.nn.Identity) and blk.attn.in_proj_weight.dtype == torch.float32
             and blk.mlp.c_fc.weight.shape[0] % 8 == 0)
 

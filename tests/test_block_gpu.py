@@ -326,6 +326,39 @@ def test_fused_block_matches_module_path_and_oracle():
     assert torch.count_nonzero(res[True][1]["blocks.0.fc1.weight"][int(384 * 3.5):]) == 0
 
 
+def test_frozen_parameters_keep_the_composed_path_and_get_no_gradient():
+    """The native nodes write every parameter gradient of the node: with a frozen parameter inside a block (or in the
+    stem / classifier) that node must fall back to the module path, `.grad` of the frozen tensor stays None and the
+    other gradients agree with the all-trainable run."""
+    from cream_amd.autoformer import engine
+    m = _supernet().to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[384, 384], num_heads=[6, 6], mlp_ratio=[3.5, 3.5])
+    m.set_sample_config(cfg)
+    m.train()
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(2, 3, 224, 224, generator=g).to(DEV)
+    target = torch.softmax(torch.randn(2, 1000, generator=g), -1).to(DEV)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = engine.soft_target_cross_entropy(m(images), target)
+        loss.backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    full = run()
+    frozen = ["blocks.1.fc1.weight", "head.bias", "cls_token"]
+    params = dict(m.named_parameters())
+    for k in frozen:
+        params[k].requires_grad_(False)
+    part = run()
+    for k in frozen:
+        assert params[k].grad is None and k not in part
+    assert set(part) == set(full) - set(frozen)
+    worst = max(_rel(part[k], full[k]) for k in part)
+    assert worst < 3e-2, worst
+
+
 def test_block_stack_equals_block_by_block_with_drop_path():
     """The run of blocks as one node (boundary passes merged: residual add on the next LayerNorm,
     fc2-output gradient out of the next LayerNorm's backward) against the same blocks applied one

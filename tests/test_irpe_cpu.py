@@ -314,6 +314,16 @@ def test_model_zoo_checkpoints_fit():
     assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
     with pytest.raises(AssertionError, match="not provided"):
         R.create_zoo_model("deit_tiny_patch16_224_ctx_product_50_shared_qkv")
+    # DeiT-style files: an argparse.Namespace next to the weights loads; arbitrary objects are refused with advice
+    import argparse
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, name + ".pth")
+        torch.save({"model": src.state_dict(), "args": argparse.Namespace(lr=1e-3, model=name), "epoch": 3}, path)
+        dst = R.create_zoo_model(name, path)
+        assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+        torch.save({"model": src.state_dict(), "sched": torch.optim.lr_scheduler.LambdaLR}, path)
+        with pytest.raises(RuntimeError, match="pass the dictionary"):
+            R.create_zoo_model(name, path)
 
 
 def test_dropout_keep_mask_restatement_is_deterministic_and_unbiased():
