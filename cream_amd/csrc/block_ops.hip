@@ -472,52 +472,96 @@ struct GradJobs {
     int njobs;
 };
 
-__device__ __forceinline__ f32x4v load_part4(const void* src, int64_t idx, bool is_bf16) {
-    if (is_bf16) {
-        float f[4];
-        unpack_bf16x4(*reinterpret_cast<const u32x2v*>(reinterpret_cast<const uint16_t*>(src) + idx), f);
-        return f32x4v{f[0], f[1], f[2], f[3]};
+// W = elements per chunk: 4 (fp32 partials, 16-byte loads) or 8 (bf16 partials with cols % 8 == 0: 16-byte loads too —
+// at 4 elements a bf16 load is 8 bytes per lane, which the vector memory path serves at 0.54-0.70x the 16-byte rate)
+template <int W> struct PartChunk;
+template <> struct PartChunk<4> {
+    f32x4v v;
+    __device__ __forceinline__ void zero() { v = f32x4v{0, 0, 0, 0}; }
+    __device__ __forceinline__ void add(const PartChunk& o) { v += o.v; }
+    static __device__ __forceinline__ PartChunk load(const void* src, int64_t idx, bool is_bf16) {
+        PartChunk c;
+        if (is_bf16) {
+            float f[4];
+            unpack_bf16x4(*reinterpret_cast<const u32x2v*>(reinterpret_cast<const uint16_t*>(src) + idx), f);
+            c.v = f32x4v{f[0], f[1], f[2], f[3]};
+        } else {
+            c.v = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(src) + idx);
+        }
+        return c;
     }
-    return *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(src) + idx);
-}
+    __device__ __forceinline__ void add_into(float* d) const {
+        f32x4v o = *reinterpret_cast<f32x4v*>(d);
+        o += v;
+        *reinterpret_cast<f32x4v*>(d) = o;
+    }
+};
+template <> struct PartChunk<8> {                                  // bf16 sources only
+    f32x4v lo, hi;
+    __device__ __forceinline__ void zero() { lo = f32x4v{0, 0, 0, 0}; hi = lo; }
+    __device__ __forceinline__ void add(const PartChunk& o) { lo += o.lo; hi += o.hi; }
+    static __device__ __forceinline__ PartChunk load(const void* src, int64_t idx, bool) {
+        const u32x4v r = *reinterpret_cast<const u32x4v*>(reinterpret_cast<const uint16_t*>(src) + idx);
+        float a[4], b[4];
+        unpack_bf16x4(u32x2v{r[0], r[1]}, a);
+        unpack_bf16x4(u32x2v{r[2], r[3]}, b);
+        PartChunk c;
+        c.lo = f32x4v{a[0], a[1], a[2], a[3]};
+        c.hi = f32x4v{b[0], b[1], b[2], b[3]};
+        return c;
+    }
+    __device__ __forceinline__ void add_into(float* d) const {
+        f32x4v o0 = *reinterpret_cast<f32x4v*>(d), o1 = *reinterpret_cast<f32x4v*>(d + 4);
+        o0 += lo;
+        o1 += hi;
+        *reinterpret_cast<f32x4v*>(d) = o0;
+        *reinterpret_cast<f32x4v*>(d + 4) = o1;
+    }
+};
 
-__device__ __forceinline__ int grad_part_lanes(int nparts) { return nparts <= 16 ? 4 : 16; }
+__host__ __device__ __forceinline__ int grad_part_lanes(int nparts) { return nparts <= 16 ? 4 : 16; }
+__host__ __device__ __forceinline__ int grad_chunk_width(const cream_grad_job& b) { return b.src_bf16 && b.cols % 8 == 0 ? 8 : 4; }
 
-__global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J) {
-    __shared__ f32x4v red[256];
-    int j = 0;
-    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
-    const cream_grad_job jb = J.job[j];
+template <int W>
+__device__ __forceinline__ void grad_finalize_job(const cream_grad_job& jb, int block_in_job, PartChunk<W>* red) {
     const int PL = grad_part_lanes(jb.nparts), CL = 256 / PL;
     const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
-    const int cpr = jb.cols >> 2;                              // chunks per row
+    const int cpr = jb.cols / W;                               // chunks per row
     const int64_t nchunks = (int64_t)jb.rows * cpr;
-    const int64_t chunk = (int64_t)((int)blockIdx.x - J.first_block[j]) * CL + cl;
-    f32x4v acc = {0, 0, 0, 0};
+    const int64_t chunk = (int64_t)block_in_job * CL + cl;
+    PartChunk<W> acc;
+    acc.zero();
     if (chunk < nchunks) {
         const bool bf = jb.src_bf16 != 0;
         int p = pl;
         for (; p + 3 * PL < jb.nparts; p += 4 * PL) {          // four loads in flight
-            const f32x4v a0 = load_part4(jb.src, (int64_t)p * jb.pstride + chunk * 4, bf);
-            const f32x4v a1 = load_part4(jb.src, (int64_t)(p + PL) * jb.pstride + chunk * 4, bf);
-            const f32x4v a2 = load_part4(jb.src, (int64_t)(p + 2 * PL) * jb.pstride + chunk * 4, bf);
-            const f32x4v a3 = load_part4(jb.src, (int64_t)(p + 3 * PL) * jb.pstride + chunk * 4, bf);
-            acc += a0; acc += a1; acc += a2; acc += a3;
+            const PartChunk<W> a0 = PartChunk<W>::load(jb.src, (int64_t)p * jb.pstride + chunk * W, bf);
+            const PartChunk<W> a1 = PartChunk<W>::load(jb.src, (int64_t)(p + PL) * jb.pstride + chunk * W, bf);
+            const PartChunk<W> a2 = PartChunk<W>::load(jb.src, (int64_t)(p + 2 * PL) * jb.pstride + chunk * W, bf);
+            const PartChunk<W> a3 = PartChunk<W>::load(jb.src, (int64_t)(p + 3 * PL) * jb.pstride + chunk * W, bf);
+            acc.add(a0); acc.add(a1); acc.add(a2); acc.add(a3);
         }
-        for (; p < jb.nparts; p += PL) acc += load_part4(jb.src, (int64_t)p * jb.pstride + chunk * 4, bf);
+        for (; p < jb.nparts; p += PL) acc.add(PartChunk<W>::load(jb.src, (int64_t)p * jb.pstride + chunk * W, bf));
     }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (pl == 0 && chunk < nchunks) {
-        f32x4v s = red[cl];
-        for (int l = 1; l < PL; ++l) s += red[l * CL + cl];
-        const int r = (int)(chunk / cpr), c = (int)(chunk - (int64_t)r * cpr) * 4;
+        PartChunk<W> s = red[cl];
+        for (int l = 1; l < PL; ++l) s.add(red[l * CL + cl]);
+        const int r = (int)(chunk / cpr), c = (int)(chunk - (int64_t)r * cpr) * W;
         const int rr = jb.interleave > 0 ? 3 * (r % jb.interleave) + r / jb.interleave : r;
-        float* d = jb.dst + (int64_t)rr * jb.ld + c;
-        f32x4v o = *reinterpret_cast<f32x4v*>(d);
-        o += s;
-        *reinterpret_cast<f32x4v*>(d) = o;
+        s.add_into(jb.dst + (int64_t)rr * jb.ld + c);
     }
+}
+
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J) {
+    __shared__ __attribute__((aligned(16))) char red[256 * sizeof(PartChunk<8>)];
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const cream_grad_job& jb = J.job[j];
+    const int b = (int)blockIdx.x - J.first_block[j];
+    if (grad_chunk_width(jb) == 8) grad_finalize_job<8>(jb, b, reinterpret_cast<PartChunk<8>*>(red));
+    else grad_finalize_job<4>(jb, b, reinterpret_cast<PartChunk<4>*>(red));
 }
 
 int grid_for(int64_t n_items, int per_block) {
@@ -706,11 +750,13 @@ int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream)
         if (!b.dst || !b.src || b.nparts <= 0 || b.rows <= 0 || b.cols <= 0 || b.cols % 4 || b.ld % 4 ||
             b.pstride % 4 || b.interleave < 0 || (b.interleave > 0 && b.rows != 3 * b.interleave))
             return CREAM_ERR_BAD_ARG;
-        if ((uintptr_t)b.dst % 16 || (uintptr_t)b.src % (b.src_bf16 ? 8 : 16)) return CREAM_ERR_BAD_ARG;
+        const int W = grad_chunk_width(b);
+        if ((uintptr_t)b.dst % 16 || (uintptr_t)b.src % (b.src_bf16 && W == 4 ? 8 : 16)) return CREAM_ERR_BAD_ARG;
+        if (W == 8 && b.pstride % 8) return CREAM_ERR_BAD_ARG;
         J.job[j] = b;
         J.first_block[j] = blocks;
-        const int CL = 256 / (b.nparts <= 16 ? 4 : 16);
-        const int64_t nchunks = (int64_t)b.rows * (b.cols / 4);
+        const int CL = 256 / grad_part_lanes(b.nparts);
+        const int64_t nchunks = (int64_t)b.rows * (b.cols / W);
         blocks += (int)((nchunks + CL - 1) / CL);
     }
     J.first_block[njobs] = blocks;

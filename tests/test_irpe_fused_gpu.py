@@ -18,7 +18,7 @@ def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def _restatement(qkv, scale, mods, round_lookups=True, keep=None):
+def _restatement(qkv, scale, mods, round_lookups=True, keep=None, ids=None):
     """round_lookups: the lookups (s q) W leave the reference's autocast matmul as 16-bit values (irpe.py:646 under amp) and the
     kernel keeps them as bf16 rows in LDS; False evaluates the same algebra in pure fp32 (reported next to the asserted comparison)."""
     rnd = (lambda t: t.to(torch.bfloat16).float()) if round_lookups else (lambda t: t)
@@ -28,8 +28,8 @@ def _restatement(qkv, scale, mods, round_lookups=True, keep=None):
     qs = q * scale
     a = qs @ k.transpose(-2, -1)
 
-    def ids_of(m):
-        return m.bucket_ids_for(L, qkv.device).long()
+    def ids_of(m):                                  # `ids`: the oracle's bucket table (config 4) instead of the product's
+        return ids if ids is not None else m.bucket_ids_for(L, qkv.device).long()
 
     def w_of(m):
         w = m.lookup_table_weight.float()
@@ -132,14 +132,14 @@ def test_module_takes_the_fused_path_under_autocast():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in att.parameters())
 
 
-def _restatement_chunked(qkv, gy, scale, mods, chunk, round_lookups=True):
+def _restatement_chunked(qkv, gy, scale, mods, chunk, round_lookups=True, ids=None):
     """The restatement above over batch chunks (an fp32 (B, H, L, L) map at config 4 is 1 GB and autograd keeps several):
     outputs and dq / dk / dv are per image, the table gradients are sums over images — accumulated in fp64."""
     params = [_table(m) for m in mods if m is not None]
     ys, dqkvs, dws = [], [], [torch.zeros_like(p, dtype=torch.float64) for p in params]
     for b0 in range(0, qkv.shape[0], chunk):
         x = qkv[b0:b0 + chunk].detach().clone().requires_grad_()
-        y = _restatement(x, scale, mods, round_lookups)
+        y = _restatement(x, scale, mods, round_lookups, ids=ids)
         g = torch.autograd.grad(y, [x] + params, gy[b0:b0 + chunk].float())
         ys.append(y.detach())
         dqkvs.append(g[0].detach().float())
@@ -173,9 +173,17 @@ def test_fused_irpe_attention_at_config4_matches_restatement(rpe_on):
     got = torch.autograd.grad(y, [qkv] + params, gy)
     assert all(torch.isfinite(t).all() for t in got)
     names = ["dW" + c for c, m in zip("qkv", mods) if m is not None]
+    # the restatement indexes with the ORACLE's bucket table (oracle/irpe_oracle.py, pinned against the reference-made
+    # fixtures), not with ids taken from the product; the product's table must be that table
+    from oracle import irpe_oracle
+    oids, nb = irpe_oracle.product_bucket_ids(24, 24, skip=1, ratio=1.9)
+    oids = torch.from_numpy(oids).to(DEV)
+    for m in mods:
+        if m is not None:
+            assert m.num_buckets == nb and torch.equal(m.bucket_ids_for(L, DEV).long(), oids)
     report = {}
     for rounded in (True, False):
-        ref_y, ref_dqkv, ref_dw = _restatement_chunked(qkv, gy, 0.125, mods, chunk=4, round_lookups=rounded)
+        ref_y, ref_dqkv, ref_dw = _restatement_chunked(qkv, gy, 0.125, mods, chunk=4, round_lookups=rounded, ids=oids)
         errs = dict(y=max_rel(y.float(), ref_y))
         for name, a, b in zip(["dq", "dk", "dv"], got[0].float().unbind(2), ref_dqkv.unbind(2)):
             errs[name] = max_rel(a, b)

@@ -138,5 +138,5 @@ def test_rpe_attention_L577_on_gpu(rpe_on):
     fp32 <= 1e-3 (north_star), bf16 autocast at its documented tolerance."""
     from test_irpe_cpu import run_attention_L577
     w32 = run_attention_L577(rpe_on, DEV, 1e-3)
-    w16 = run_attention_L577(rpe_on, DEV, 3e-2, autocast=True)
+    w16 = run_attention_L577(rpe_on, DEV, 1.7e-2, autocast=True)       # 2x the measured 8.4e-3
     print(f"[L577 {rpe_on}] worst rel err fp32 {w32:.2e}, bf16 {w16:.2e}")

@@ -30,7 +30,8 @@ def run(model, tag, device, autocast=False):
     return fi, ft, scale, {k: p.grad for k, p in model.named_parameters()}
 
 
-def compare(tag, fi, ft, scale, grads, tol):
+def compare(tag, fi, ft, scale, grads, tol, loose=None):
+    """`loose`: {substring of an entry name: its own bound} for entries measured apart from the rest."""
     fix = load_npz("tinyclip_model.npz")
     errs = {"image_features": max_rel(fi.detach().cpu().float(), fix[f"{tag}|image_features"]),
             "text_features": max_rel(ft.detach().cpu().float(), fix[f"{tag}|text_features"]),
@@ -47,7 +48,13 @@ def compare(tag, fi, ft, scale, grads, tol):
             scale_ = ref / max(1.0, g.numel()) ** 0.5
             sample = torch.from_numpy(fix[f"{tag}|{name}|sample"])
             errs[name + "|sample"] = float((g[::TINYCLIP_STRIDE] - sample).abs().max() / scale_) / 10.0
-    bad = {k: e for k, e in errs.items() if not e <= tol}
+    def bound(k):
+        return next((t for sub, t in (loose or {}).items() if sub in k), tol)
+    bad = {k: e for k, e in errs.items() if not e <= bound(k)}
+    if loose:
+        print(f"[{tag}] worst of the entries with their own bound: "
+              f"{max((e for k, e in errs.items() if bound(k) != tol), default=0.0):.2e}; of the rest: "
+              f"{max((e for k, e in errs.items() if bound(k) == tol), default=0.0):.2e}")
     assert not bad, f"{tag}: exceeds {tol}: " + ", ".join(f"{k}={e:.2e}" for k, e in sorted(bad.items(), key=lambda t: -t[1])[:8])
     return max(errs.values())
 
@@ -109,9 +116,10 @@ def test_image_tower_takes_the_fused_attention_under_autocast():
     timing.enable(False)
     s = timing.summary()
     assert "irpe_attn_fwd" in s and "irpe_attn_bwd" in s, set(s)
-    # bf16 operands end to end through 12 + 6 layers; the worst entry is the token-embedding gradient, whose few non-zero
-    # rows are measured against the norm of a 25M-element, almost empty tensor (6e-2; features and tower weights < 2e-2)
-    worst = compare(tag, *out, 1e-1)
+    # bf16 operands end to end through 12 + 6 layers.  The token-embedding gradient is held apart: its few non-zero rows
+    # are measured against the norm of a 25M-element, almost empty tensor (6e-2 measured, bound 1e-1); everything else
+    # (features, logit scale, every tower weight) is held to 2x its measured worst (< 2e-2)
+    worst = compare(tag, *out, 4e-2, loose={"token_embedding": 1e-1})
     print(f"[tinyclip gpu bf16 {tag}] worst {worst:.2e}")
 
 
