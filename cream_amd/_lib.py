@@ -99,6 +99,7 @@ SIGNATURES = {
     "cream_wgrad_group_max_tiles": (_i, []),
     "cream_wgrad_group": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cream_linear_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
+    "cream_bmm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_linear_f32_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
     "cream_linear_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
     "cream_ln_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -16,7 +16,7 @@ import torch
 from .. import _lib
 
 
-CALLS = {"linear": 0, "layer_norm": 0}       # launches through this module (tests assert which path ran)
+CALLS = {"linear": 0, "layer_norm": 0, "matmul": 0}       # launches through this module (tests assert which path ran)
 
 
 def _p(t):
@@ -129,3 +129,66 @@ def layer_norm(x, weight, bias, E, eps):
     assert x.shape[-1] == E
     CALLS["layer_norm"] += 1
     return _LayerNorm.apply(x, weight, bias, int(E), float(eps))
+
+
+# ---- batched products of the attention in parity mode (cream_bmm_f32) --------------------------------------------
+def _bmm_raw(a, b):
+    """a (B0, B1, M, K) . b (B0, B1, K, N) -> fresh contiguous (B0, B1, M, N); any element strides (transposed and
+    expanded views are passed as they are)."""
+    B0, B1, M, K = a.shape
+    N = b.shape[-1]
+    assert b.shape == (B0, B1, K, N), (a.shape, b.shape)
+    lib = _lib.load()
+    c = torch.empty((B0, B1, M, N), dtype=torch.float32, device=a.device)
+    if c.numel() == 0:
+        return c
+    if K == 0:
+        return c.zero_()
+    I4 = ctypes.c_int64 * 4
+    sa = I4(a.stride(2), a.stride(3), a.stride(0), a.stride(1))
+    sb = I4(b.stride(2), b.stride(3), b.stride(0), b.stride(1))
+    sc = I4(c.stride(2), c.stride(3), c.stride(0), c.stride(1))
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cream_bmm_f32(_p(c), _p(a), _p(b), M, N, K, sa, sb, sc, B0, B1, _stream(a.device)), "cream_bmm_f32")
+    return c
+
+
+def _as4(t):
+    while t.dim() < 4:
+        t = t.unsqueeze(0)
+    return t
+
+
+class _Bmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a4, b4 = _as4(a), _as4(b)
+        assert a4.dim() == 4 and b4.dim() == 4, "matmul: at most two batch dimensions"
+        B0, B1 = max(a4.shape[0], b4.shape[0]), max(a4.shape[1], b4.shape[1])
+        ae, be = a4.expand(B0, B1, *a4.shape[2:]), b4.expand(B0, B1, *b4.shape[2:])
+        ctx.save_for_backward(a, b)
+        out = _bmm_raw(ae, be)
+        nd = max(a.dim(), b.dim())
+        return out.reshape(out.shape[4 - nd:]) if nd < 4 else out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        a4, b4, g4 = _as4(a), _as4(b), _as4(g)
+        B0, B1 = g4.shape[0], g4.shape[1]
+        ae, be = a4.expand(B0, B1, *a4.shape[2:]), b4.expand(B0, B1, *b4.shape[2:])
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _bmm_raw(g4, be.transpose(-1, -2)).sum_to_size(a4.shape).reshape(a.shape)
+        if ctx.needs_input_grad[1]:
+            db = _bmm_raw(ae.transpose(-1, -2), g4).sum_to_size(b4.shape).reshape(b.shape)
+        return da, db
+
+
+def matmul(a, b):
+    """torch.matmul(a, b) for fp32 device operands with up to two (broadcastable) batch dimensions, on cream_bmm_f32:
+    q k^T / P v of RPEAttention.forward (rpe_vision_transformer.py:76, :88) and the lookup products of irpe.py:641-644,
+    :683-687.  Batch-broadcast operands (a shared-head lookup table) get their gradient as the fixed-order sum of the
+    per-item products."""
+    CALLS["matmul"] = CALLS.get("matmul", 0) + 1
+    return _Bmm.apply(a, b)

@@ -519,7 +519,10 @@ template <> struct PartChunk<8> {                                  // bf16 sourc
     }
 };
 
-__host__ __device__ __forceinline__ int grad_part_lanes(int nparts) { return nparts <= 16 ? 4 : 16; }
+// part lanes per chunk: a lane walks its parts four loads at a time, so the dependent chain of a job is nparts / (4 PL)
+// round trips — the LayerNorm jobs (1024 slab partials of a few hundred columns) set the kernel's duration at PL = 16
+// (16 round trips on 6 workgroups while the chip idles): 64 lanes there
+__host__ __device__ __forceinline__ int grad_part_lanes(int nparts) { return nparts <= 16 ? 4 : (nparts <= 64 ? 16 : 64); }
 __host__ __device__ __forceinline__ int grad_chunk_width(const cream_grad_job& b) { return b.src_bf16 && b.cols % 8 == 0 ? 8 : 4; }
 
 template <int W>
@@ -545,9 +548,20 @@ __device__ __forceinline__ void grad_finalize_job(const cream_grad_job& jb, int 
     }
     red[threadIdx.x] = acc;
     __syncthreads();
+    if (PL == 64) {                                            // two levels (fixed order): 8 groups of 8 lanes, then the 8 sums
+        if (pl < 8) {
+            PartChunk<W> s = red[(8 * pl) * CL + cl];
+            for (int l = 1; l < 8; ++l) s.add(red[(8 * pl + l) * CL + cl]);
+            acc = s;
+        }
+        __syncthreads();
+        if (pl < 8) red[pl * CL + cl] = acc;
+        __syncthreads();
+    }
+    const int nl = PL == 64 ? 8 : PL;
     if (pl == 0 && chunk < nchunks) {
         PartChunk<W> s = red[cl];
-        for (int l = 1; l < PL; ++l) s.add(red[l * CL + cl]);
+        for (int l = 1; l < nl; ++l) s.add(red[l * CL + cl]);
         const int r = (int)(chunk / cpr), c = (int)(chunk - (int64_t)r * cpr) * W;
         const int rr = jb.interleave > 0 ? 3 * (r % jb.interleave) + r / jb.interleave : r;
         s.add_into(jb.dst + (int64_t)rr * jb.ld + c);

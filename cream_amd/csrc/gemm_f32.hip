@@ -89,6 +89,62 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Gemm p)
     }
 }
 
+// ---- strided batched product (the attention products of the iRPE parity mode) -------------------------------------
+// C_z(M x N) = A_z(M x K) . B_z(K x N) for z = (z0, z1) in nb0 x nb1, every operand addressed through ELEMENT strides
+// (transposes, head-interleaved (B, L, 3, H, d) layouts and broadcast operands — batch stride 0 — are views, not copies):
+//   q k^T, P v of RPEAttention.forward (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:76, :88), the lookup products
+//   x W of irpe.py:641-644 / :683-687, and what autograd derives for them.  Same 64 x 64 tile, 16-deep LDS images and
+//   exact-fp32 matrix-core accumulation as gemm_f32_kernel; the loader picks the memory-contiguous index of each
+//   operand as its fast thread index.
+struct F32Bmm {
+    const float* A; int64_t sam, sak, sa0, sa1;
+    const float* B; int64_t sbk, sbn, sb0, sb1;
+    float* C; int64_t scm, scn, sc0, sc1;
+    int M, N, K, nb1;
+};
+
+__global__ __launch_bounds__(256) void bmm_f32_kernel(const F32Bmm p)
+{
+    __shared__ float As[BK][LDT], Bs[BK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
+    const float* A = p.A + z0 * p.sa0 + z1 * p.sa1;
+    const float* B = p.B + z0 * p.sb0 + z1 * p.sb1;
+    float* C = p.C + z0 * p.sc0 + z1 * p.sc1;
+    const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
+    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            const int gm = m0 + m, gk = k0 + k;
+            As[k][m] = (gm < p.M && gk < p.K) ? A[(int64_t)gm * p.sam + (int64_t)gk * p.sak] : 0.f;
+            int n, kb;
+            if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+            const int gn = n0 + n, gkb = k0 + kb;
+            Bs[kb][n] = (gn < p.N && gkb < p.K) ? B[(int64_t)gkb * p.sbk + (int64_t)gn * p.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= p.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + acc_row(r, lane >> 5);
+        if (m < p.M) C[(int64_t)m * p.scm + (int64_t)n * p.scn] = acc[r];
+    }
+}
+
 // column sums of an (M x C) fp32 matrix, one thread per column, rows in ascending order (fixed order)
 __global__ __launch_bounds__(64) void colsum_f32_kernel(float* __restrict__ out, const float* __restrict__ a, int M, int C, int64_t ld)
 {
@@ -143,6 +199,27 @@ int cream_linear_f32_wgrad(float* dw, float* dbias, const float* dy, const float
     const int rc = launch(p, (hipStream_t)stream);
     if (rc != CREAM_OK || !dbias) return rc;
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, dbias, dy, M, N, (int64_t)N);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int cream_bmm_f32(float* c, const float* a, const float* b, int M, int N, int K, const int64_t* a_strides,
+                  const int64_t* b_strides, const int64_t* c_strides, int nb0, int nb1, void* stream)
+{
+    if (M < 0 || N < 0 || K < 0 || nb0 < 0 || nb1 < 0) return CREAM_ERR_BAD_ARG;
+    if (M == 0 || N == 0 || nb0 == 0 || nb1 == 0) return CREAM_OK;
+    if (!c || !a_strides || !b_strides || !c_strides || (K > 0 && (!a || !b))) return CREAM_ERR_BAD_ARG;
+    if ((int64_t)nb0 * nb1 > 65535) return CREAM_ERR_TOO_LARGE;
+    for (int i = 0; i < 4; ++i)
+        if (a_strides[i] < 0 || b_strides[i] < 0 || c_strides[i] < 0) return CREAM_ERR_BAD_ARG;
+    // the output must not alias itself: no zero stride on an extent > 1
+    if ((c_strides[0] == 0 && M > 1) || (c_strides[1] == 0 && N > 1) || (c_strides[2] == 0 && nb0 > 1) ||
+        (c_strides[3] == 0 && nb1 > 1))
+        return CREAM_ERR_BAD_ARG;
+    F32Bmm p{a, a_strides[0], a_strides[1], a_strides[2], a_strides[3],
+             b, b_strides[0], b_strides[1], b_strides[2], b_strides[3],
+             c, c_strides[0], c_strides[1], c_strides[2], c_strides[3], M, N, K, nb1};
+    hipLaunchKernelGGL(bmm_f32_kernel, dim3((N + BT - 1) / BT, (M + BT - 1) / BT, nb0 * nb1), dim3(256), 0,
+                       (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

@@ -183,7 +183,8 @@ class iRPE(nn.Module):
         if self.mode == 'bias':
             return self.lookup_table_bias[:, rp_bucket.flatten().long()].view(1, self.num_heads, Lq, Lk)
         w = self.lookup_table_weight                                     # (H', d, nb)
-        lookup = torch.matmul(x, w[0]) if w.shape[0] == 1 else torch.matmul(x, w.unsqueeze(0))
+        mm = _matmul_for(x, w)
+        lookup = mm(x, w[0]) if w.shape[0] == 1 else mm(x, w.unsqueeze(0))
         return rpe_gather(lookup, rp_bucket)
 
     def forward_rpe_no_transpose(self, x, rp_bucket):
@@ -191,11 +192,19 @@ class iRPE(nn.Module):
         assert self.mode == 'contextual', "Only support contextual version in non-transposed version"
         w = self.lookup_table_weight                                     # (H', nb, d)
         s = rpe_scatter(x, rp_bucket, self.num_buckets).to(w.dtype)      # (B, H, L, nb)
-        return torch.matmul(s, w[0]) if w.shape[0] == 1 else torch.matmul(s, w.unsqueeze(0))
+        mm = _matmul_for(s, w)
+        return mm(s, w[0]) if w.shape[0] == 1 else mm(s, w.unsqueeze(0))
 
     def __repr__(self):
         return ('iRPE(head_dim={r.head_dim}, num_heads={r.num_heads}, mode="{r.mode}", method={r.method}, '
                 'transposed={r.transposed}, num_buckets={r.num_buckets}, rpe_config={r.rpe_config})').format(r=self)
+
+
+def _matmul_for(x, w):
+    """The lookup products of irpe.py:641-644 / :683-687: fp32 device tensors outside autocast multiply on the own
+    exact-fp32 kernel (cream_bmm_f32, 4-D inputs), everything else on the framework's matmul."""
+    from .autoformer import native_fp32
+    return native_fp32.matmul if x.dim() == 4 and native_fp32.usable(x, w) else torch.matmul
 
 
 class iRPE_Cross(nn.Module):

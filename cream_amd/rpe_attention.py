@@ -52,6 +52,21 @@ class PatchEmbed(nn.Module):
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
+def _matmul_for(x):
+    """fp32 device tensors outside autocast (the "within 1e-3 of the reference" configuration) multiply on
+    cream_bmm_f32; everything else (host tensors, autocast fallbacks) keeps the framework's matmul."""
+    from .autoformer import native_fp32
+    return native_fp32.matmul if native_fp32.usable(x) else torch.matmul
+
+
+def _linear(mod, x):
+    """nn.Linear of the layer (qkv / proj, rpe_vision_transformer.py:61-64) — in parity mode on cream_linear_f32_*."""
+    from .autoformer import native_fp32
+    if native_fp32.usable(x, mod.weight, mod.bias):
+        return native_fp32.linear(x, mod.weight, mod.bias, mod.out_features, mod.in_features)
+    return mod(x)
+
+
 class RPEAttention(nn.Module):
     """rpe_vision_transformer.py:45-97.  With s = head_dim^-0.5:
         A = (s q) k^T + rpe_k(s q) + rpe_q(s k)^T ;  P = dropout(softmax(A)) ;  out = P v + rpe_v(P)"""
@@ -69,7 +84,7 @@ class RPEAttention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x)
+        qkv = _linear(self.qkv, x)
         hd = C // self.num_heads
         if irpe_fused.usable(qkv.dtype, qkv.device, hd, N, (self.rpe_q, self.rpe_k, self.rpe_v),
                              dropout_p=self.attn_drop.p if self.training else 0.0):
@@ -80,16 +95,17 @@ class RPEAttention(nn.Module):
             return self.proj_drop(self.proj(out))
         q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
         q = q * self.scale                                   # (the reference scales q in place, :73)
-        attn = q @ k.transpose(-2, -1)
+        mm = _matmul_for(q)                                  # fp32 on the device: the own exact-fp32 kernel, not the library
+        attn = mm(q, k.transpose(-2, -1))
         if self.rpe_k is not None:
             attn = attn + self.rpe_k(q)                      # :78-79
         if self.rpe_q is not None:
             attn = attn + self.rpe_q(k * self.scale).transpose(2, 3)     # :82-83
         attn = self.attn_drop(attn.softmax(dim=-1))
-        out = attn @ v
+        out = mm(attn, v)
         if self.rpe_v is not None:
             out = out + self.rpe_v(attn)                     # :91-92 (post-dropout probabilities)
-        return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, C)))
+        return self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B, N, C)))
 
 
 class RPEBlock(nn.Module):

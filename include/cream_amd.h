@@ -488,6 +488,15 @@ int cream_linear_f32_dgrad(float* dx, const float* dy, const float* w, int M, in
                            void* stream);
 int cream_linear_f32_wgrad(float* dw, float* dbias, const float* dy, const float* x, int M, int N, int K, int64_t ldx,
                            int64_t lddw, int seg, int step, void* stream);
+/* cream_bmm_f32  C_z (M x N) = A_z (M x K) . B_z (K x N) for the nb0 x nb1 batch items z = (z0, z1): the attention
+ *   products of the iRPE parity mode on the same exact-fp32 matrix-core kernel — q k^T and P v of RPEAttention.forward
+ *   (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:76, :88), the lookup products of irpe.py:641-644 / :683-687 and their
+ *   autograd products — instead of the framework's batched matmul (the vendor library).
+ *   *_strides[4] = {row, column, z0, z1} ELEMENT strides of each operand (rows of A = m, columns = k; rows of B = k,
+ *   columns = n): transposed views, the head-interleaved (B, L, 3, H, d) qkv layout and broadcast operands (batch
+ *   stride 0 on A or B) need no copies.  C must not alias itself (no zero stride on an extent > 1).  nb0 * nb1 <= 65535. */
+int cream_bmm_f32(float* c, const float* a, const float* b, int M, int N, int K, const int64_t* a_strides,
+                  const int64_t* b_strides, const int64_t* c_strides, int nb0, int nb1, void* stream);
 int cream_ln_f32_fwd(float* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
                      int M, int E, float eps, void* stream);
 int cream_ln_f32_bwd(float* dx, float* partial, const float* dy, const float* x, const float* mean, const float* rstd,

@@ -55,3 +55,24 @@ def check_against_fixture(fix, logits, loss, grads, tol, stride=997, skip_small=
     bad = {k: e for k, e in worst.items() if not (e <= tol)}
     assert not bad, f"exceeds tol {tol}: " + ", ".join(f"{k}={e:.2e}" for k, e in sorted(bad.items(), key=lambda t: -t[1])[:8])
     return max(worst.values())
+
+
+def forbid_framework_matmul(what="this path"):
+    """Context manager: the framework's matrix products (= the vendor library) raise when they receive a device tensor —
+    torch.mm / matmul / bmm / baddbmm / einsum, F.linear and the `@` operator.  Products must then run on the own kernels."""
+    import contextlib
+    import unittest.mock as mock
+
+    def guard(real):
+        def f(*a, **k):
+            flat = [t for x in a for t in (x if isinstance(x, (list, tuple)) else [x])]
+            if any(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
+                raise AssertionError(f"framework matmul on a device tensor inside {what}")
+            return real(*a, **k)
+        return f
+    stack = contextlib.ExitStack()
+    for owner, name in [(torch, "mm"), (torch, "matmul"), (torch, "bmm"), (torch, "baddbmm"), (torch, "einsum"),
+                        (torch.nn.functional, "linear"), (torch.Tensor, "__matmul__"), (torch.Tensor, "__rmatmul__"),
+                        (torch.Tensor, "matmul"), (torch.Tensor, "mm"), (torch.Tensor, "bmm")]:
+        stack.enter_context(mock.patch.object(owner, name, guard(getattr(owner, name))))
+    return stack

@@ -186,7 +186,7 @@ def test_rpe_attention_L577_matches_reference(rpe_on):
     run_attention_L577(rpe_on, "cpu", 1e-4)
 
 
-def run_attention_L577(rpe_on, device, tol, autocast=False):
+def run_attention_L577(rpe_on, device, tol, autocast=False, guard=None):
     from cream_amd.rpe_attention import RPEAttention
     fix = load_npz("irpe_attention_L577.npz")
     cfg = I.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on=rpe_on)
@@ -200,9 +200,11 @@ def run_attention_L577(rpe_on, device, tol, autocast=False):
     g = torch.Generator().manual_seed(43)
     x = torch.randn(1, 577, 192, generator=g).to(device).requires_grad_()
     gy = torch.randn(1, 577, 192, generator=g).to(device)
-    with torch.autocast(torch.device(device).type, dtype=torch.bfloat16, enabled=autocast):
-        y = att(x)
-    y.float().backward(gy)
+    import contextlib
+    with (guard if guard is not None else contextlib.nullcontext()):
+        with torch.autocast(torch.device(device).type, dtype=torch.bfloat16, enabled=autocast):
+            y = att(x)
+        y.float().backward(gy)
     worst = max(max_rel(y[:, ::3].detach().float().cpu(), fix[f"{rpe_on}|y"]), max_rel(x.grad[:, ::3].cpu(), fix[f"{rpe_on}|dx"]))
     for k, v in fix.items():
         if k.startswith(f"{rpe_on}|full|"):

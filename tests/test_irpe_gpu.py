@@ -135,8 +135,45 @@ def test_extended_family_on_gpu_through_dropin(case):
 @pytest.mark.parametrize("rpe_on", ["k", "qkv"])
 def test_rpe_attention_L577_on_gpu(rpe_on):
     """RPEAttention at the DeiT-base-384 sequence length against the reference-made L = 577 fixture:
-    fp32 <= 1e-3 (north_star), bf16 autocast at its documented tolerance."""
+    fp32 <= 1e-3 (north_star) on the own kernels only, bf16 autocast at its documented tolerance."""
     from test_irpe_cpu import run_attention_L577
-    w32 = run_attention_L577(rpe_on, DEV, 1e-3)
+    from helpers import forbid_framework_matmul
+    from cream_amd.autoformer import native_fp32
+    # the fp32 leg runs on the OWN exact-fp32 kernels (cream_linear_f32_*, cream_bmm_f32, rpe_index): the framework's
+    # matrix products (the vendor library) are forbidden on device tensors for its forward and backward
+    before = dict(native_fp32.CALLS)
+    w32 = run_attention_L577(rpe_on, DEV, 1e-3, guard=forbid_framework_matmul("RPEAttention in fp32"))
+    assert native_fp32.CALLS["matmul"] - before["matmul"] == 2 + len(rpe_on) and native_fp32.CALLS["linear"] - before["linear"] == 2
     w16 = run_attention_L577(rpe_on, DEV, 1.7e-2, autocast=True)       # 2x the measured 8.4e-3
     print(f"[L577 {rpe_on}] worst rel err fp32 {w32:.2e}, bf16 {w16:.2e}")
+
+
+@pytest.mark.parametrize("case", ["qkT", "pv", "lookup_shared", "lookup_per_head", "ragged"])
+def test_batched_fp32_product_matches_fp64_through_views(case):
+    """cream_bmm_f32 through native_fp32.matmul: head-interleaved / transposed / broadcast views as operands, forward and
+    both gradients against torch in fp64 (exact-fp32 accumulation: 1e-6 of the largest value)."""
+    from cream_amd.autoformer import native_fp32
+    torch.manual_seed(len(case))
+    B, H, L, d, nb = 3, 4, 77, 64, 50
+    qkv = torch.randn(B, L, 3, H, d, device=DEV)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+    if case == "qkT":
+        a, b = q, k.transpose(-2, -1)
+    elif case == "pv":
+        a, b = torch.randn(B, H, L, L, device=DEV).softmax(-1), v
+    elif case == "lookup_shared":
+        a, b = q, torch.randn(1, d, nb, device=DEV)[0]
+    elif case == "lookup_per_head":
+        a, b = torch.randn(B, H, L, nb, device=DEV), torch.randn(H, nb, d, device=DEV).unsqueeze(0)
+    else:
+        a, b = torch.randn(2, 1, 130, 37, device=DEV), torch.randn(2, 5, 37, 65, device=DEV)
+    a, b = a.detach().requires_grad_(), b.detach().requires_grad_()
+    y = native_fp32.matmul(a, b)
+    a64, b64 = a.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    y64 = torch.matmul(a64, b64)
+    g = torch.randn_like(y)
+    ga, gb = torch.autograd.grad(y, [a, b], g)
+    ga64, gb64 = torch.autograd.grad(y64, [a64, b64], g.double())
+    assert y.shape == y64.shape and ga.shape == a.shape and gb.shape == b.shape
+    for got, want in ((y, y64), (ga, ga64), (gb, gb64)):
+        assert max_rel(got.detach().double().cpu(), want.detach().cpu()) < 2e-6, case
