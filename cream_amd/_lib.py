@@ -53,6 +53,7 @@ SIGNATURES = {
     "cream_attn_rpe2d_padded_len": (_i, [_i]),
     "cream_attn_rpe2d_dtab_parts": (_i, [_i, _i]),
     "cream_attn_rpe2d_bwd_mode": (_i, [_i]),
+    "cream_attn_rpe2d_fwd_mode": (_i, [_i]),
     "cream_attn_rpe2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i,
                                   _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cream_attn_rpe2d_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,

@@ -914,6 +914,40 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+#include "attn_rpe2d_bwd1.hpp"
+#include "attn_rpe2d_fwd1.hpp"
+
+// 1: the DMA-staged forward (attn_rpe2d_fwd1.hpp) for the AutoFormer geometry in bf16; 0: attn_rpe2d_fwd14_kernel.
+// CREAM_ATTN_FWD1 in the environment sets the initial value; cream_attn_rpe2d_fwd_mode() switches it (A/B runs).
+std::atomic<int> g_fwd_dma{-1};
+int fwd_dma_mode() {
+    int m = g_fwd_dma.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_ATTN_FWD1");
+        // default OFF: bit-identical results, 47.4 us against 42.2 us at B = 128, H = 6 (profiles/r04_attn_fwd1.md: the two
+        // barrier phases of an item are set by the 2 + 2 + 2 + 1 split of the seven waves over the four SIMDs, not by the
+        // memory round trips the DMA removes)
+        m = e ? (atoi(e) != 0) : 0;
+        g_fwd_dma.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+int launch_fwd1(const FwdArgs& a, int B, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v2::attn_rpe2d_fwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CREAM_ERR_LAUNCH;
+        attr_done = true;
+    }
+    FwdArgs aa = a;
+    aa.nitems = B * a.H;
+    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    hipLaunchKernelGGL(v2::attn_rpe2d_fwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::FWD1_LDS_B, st, aa);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -937,7 +971,7 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
         // (the tile-streamed kernel's own FAST instantiation, launch_fwd_nt<T, 7, true>: 46.5 us against 40.6 us at B = 128, H = 6;
         //  10.56 vs 10.48 ms per step in a same-box A/B x3)
-        if (fast_geometry(a.G)) return launch_fwd14(a, B, st);
+        if (fast_geometry(a.G)) return fwd_dma_mode() ? launch_fwd1(a, B, st) : launch_fwd14(a, B, st);
     }
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);
@@ -1438,8 +1472,6 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
-#include "attn_rpe2d_bwd1.hpp"
-
 // 1: the one-pass backward (attn_rpe2d_bwd1.hpp) for the AutoFormer geometry in bf16; 0: the two-launch backward.
 // CREAM_ATTN_BWD1 in the environment sets the initial value; cream_attn_rpe2d_bwd_mode() switches it (A/B runs).
 std::atomic<int> g_bwd_onepass{-1};
@@ -1504,6 +1536,13 @@ int cream_attn_rpe2d_bwd_mode(int onepass)
 {
     const int prev = bwd_onepass_mode();
     if (onepass >= 0) g_bwd_onepass.store(onepass != 0, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_attn_rpe2d_fwd_mode(int dma)
+{
+    const int prev = fwd_dma_mode();
+    if (dma >= 0) g_fwd_dma.store(dma != 0, std::memory_order_relaxed);
     return prev;
 }
 

@@ -96,6 +96,13 @@ int cream_attn_rpe2d_dtab_parts(int B, int H);
  * (What autograd derives for multihead_super.py:135-154 either way; a switch for same-box A/B measurements.) */
 int cream_attn_rpe2d_bwd_mode(int onepass);
 
+/* Which forward runs for the same geometry in bf16: 1 = csrc/attn_rpe2d_fwd1.hpp (K and V of an item travel
+ * global -> LDS by DMA into unpadded swizzled images, the next item's matrices land under the current item, two barriers
+ * per item), 0 = attn_rpe2d_fwd14_kernel (register-staged matrices, four barriers).  Same algebra and operand roundings
+ * (multihead_super.py:133-160), bit-identical outputs.  dma < 0 only queries; returns the previous setting; initial value
+ * from CREAM_ATTN_FWD1 (default 0: measured 12 % slower, profiles/r04_attn_fwd1.md). */
+int cream_attn_rpe2d_fwd_mode(int dma);
+
 /* The attention core of AttentionSuper.forward between the qkv and proj GEMMs
  * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
  * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
