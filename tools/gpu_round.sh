@@ -21,7 +21,7 @@ echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
 [ -z "$QUICK" ] && for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
   # full-size steps only (no batch-4 host leg, no extra legs): the per-kernel means are those of the benchmarked shapes
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|gemm_|ln_|adamw|grad_finalize|soft_ce|tail_|stem_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-host-leg --no-kernel-timing > /dev/null 2> $OUT/${TAG}_pmc_$N.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|table_images|gemm_|ln_|adamw|grad_finalize|soft_ce|tail_|stem_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-host-leg --no-kernel-timing > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
   # config 4: the fused iRPE attention kernels and the rpe_index kernels under the same counters (bench.py reads their mfma_util / traffic)
   timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_' -d $OUT/${TAG}_pmc_irpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_pmc_irpe_$N.err
@@ -53,6 +53,9 @@ timeout 300 python tools/host_profile.py > $OUT/${TAG}_host_profile.txt 2>&1
 echo "host profile exit $?"; head -12 $OUT/${TAG}_host_profile.txt
 fi
 find $OUT -name '*.csv' -path "*${TAG}*" | head -20
+# idle time between the kernels of each queue (needs the raw trace: before it is dropped)
+TRACE=$(find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" | head -1)
+[ -n "$TRACE" ] && python $REPO/tools/summarize_gaps.py $TRACE > $OUT/${TAG}_step_gaps.txt 2>&1 && head -12 $OUT/${TAG}_step_gaps.txt
 # keep the merge small: drop raw traces, keep stats + counter csv
 find $OUT -name '*kernel_trace.csv' -path "*${TAG}_prof*" -delete
 find $OUT -name '*.db' -delete

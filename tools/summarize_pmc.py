@@ -16,8 +16,10 @@ FAMILY = {"gemm_nt": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5
           "gemm_nt_gelu": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() == "2",
           "gemm_nt_mul": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() == "3",
           "gemm_tn_wgrad": lambda k: k.startswith("gemm_tn_kernel"),
-          "attn_rpe2d_fwd": lambda k: k == "attn_rpe2d_fwd_kernel",
-          "attn_rpe2d_bwd": lambda k: k in ("attn_rpe2d_bwd_q_kernel", "attn_rpe2d_bwd_kv_kernel")}
+          "attn_rpe2d_fwd": lambda k: k in ("attn_rpe2d_fwd_kernel", "attn_rpe2d_fwd14_kernel", "attn_rpe2d_fwd1_kernel"),
+          # the one-pass backward (round 4) is ONE kernel per launch of the region; the two-launch pair only when it is absent
+          "attn_rpe2d_bwd": lambda k: k == "attn_rpe2d_bwd1_kernel",
+          "attn_rpe2d_bwd_pair": lambda k: k in ("attn_rpe2d_bwd_q_kernel", "attn_rpe2d_bwd_kv_kernel")}
 
 
 def main():
@@ -55,9 +57,11 @@ def main():
                 tot_b += (rec["hbm_read_MB_corrected"] + rec.get("hbm_write_MB", 0.0)) * 1e6 * n
                 tot_n += n
         if tot_n:
-            # attention backward = two kernels per launch of the region
-            per = 2 if name == "attn_rpe2d_bwd" else 1
+            # the two-launch attention backward = two kernels per launch of the region
+            per = 2 if name == "attn_rpe2d_bwd_pair" else 1
             fam[name] = int(tot_b / tot_n * per)
+    if "attn_rpe2d_bwd" not in fam and "attn_rpe2d_bwd_pair" in fam:
+        fam["attn_rpe2d_bwd"] = fam["attn_rpe2d_bwd_pair"]
     out = dict(source=f"rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 2 --warmup 1 (tools/gpu_round.sh {tag}), "
                       "one pass per counter group, means over the sampled launches (the sub-network changes per step)",
                units=dict(hbm_read_MB_corrected="2 x FETCH_SIZE[KiB] / 1024 (gfx950: wide coalesced reads are tallied at half "
