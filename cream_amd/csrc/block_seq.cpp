@@ -125,11 +125,33 @@ bool fork(hipStream_t main, hipStream_t side) {
     {
         std::lock_guard<std::mutex> lock(g_ev_mu);
         if (g_ev_n[dev] < EV_PER_DEV) {
-            if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], hipEventDisableTiming) != hipSuccess) return false;
+            // Events WITHOUT the system-scope fence: both streams run on this device, the kernels' own agent-scope release /
+            // acquire orders their data; the default system-scope release made every record on the main chain cost 4.1 us of
+            // step time, 2.7 us without it (CREAM_EXTRA_RECORDS experiment: 64 records per step; same-box A/B x2: 9.99 ->
+            // 9.85 ms per step, profiles/r04_step_gaps.md).  CREAM_EVENT_FLAGS=0 restores plain no-timing events,
+            // 2 = hipEventReleaseToDevice (measured: no different from 0).  Ordering by stream memory operations
+            // (hipStreamWriteValue32 / WaitValue32 on signal memory) was measured too: 11.29 against 9.35 ms.
+            static int fl = -1;
+            if (fl < 0) { const char* e = getenv("CREAM_EVENT_FLAGS"); fl = e ? atoi(e) : 1; }
+            const unsigned flags = hipEventDisableTiming | (fl == 1 ? hipEventDisableSystemFence : fl == 2 ? hipEventReleaseToDevice : 0u);
+            if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], flags) != hipSuccess) return false;
             ++g_ev_n[dev];
         }
         ev = g_ev[dev][g_ev_next[dev]];
         g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
+    }
+    // measurement switch (tools only): CREAM_EXTRA_RECORDS = n records n more events on the main stream that nobody
+    // waits for — what a marker packet between two kernels of the main chain costs (profiles/r04_step_gaps.md)
+    static int extra = -1;
+    if (extra < 0) { const char* e = getenv("CREAM_EXTRA_RECORDS"); extra = e ? atoi(e) : 0; }
+    for (int i = 0; i < extra; ++i) {
+        hipEvent_t ex;
+        {
+            std::lock_guard<std::mutex> lock(g_ev_mu);
+            ex = g_ev[dev][g_ev_next[dev]];
+            g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
+        }
+        if (ex != ev && hipEventRecord(ex, main) != hipSuccess) return false;
     }
     return hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
 }
