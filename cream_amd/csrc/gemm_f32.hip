@@ -17,8 +17,8 @@
 //   dgrad    dx = dy W  : A = dy (k := n),       B(k, j) = W[wmap(k)][j]
 //   wgrad    dW = dy^T x: A(n, m) = dy[m][n],    B(m, k) = x[m][k],  C rows through wmap (the interleaved qkv rows)
 // with wmap(r) = (r % seg) * step + r / seg  (seg = Q, step = 3 for the qkv super weight; identity otherwise).
-// 64 x 64 output tile per workgroup (4 waves, 32 x 32 accumulators each), 16-deep steps staged through LDS as
-// [k][64] fp32 images (operand reads are lane-contiguous), zero-filled edges, M / N / K arbitrary.
+// 128 x 128 output tile per workgroup (4 waves, 2 x 2 accumulators of 32 x 32 each), 16-deep steps through two LDS
+// stages as [k][128] fp32 images (operand reads are lane-contiguous), zero-filled edges, M / N / K arbitrary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,61 +41,133 @@ struct F32Gemm {
 
 __device__ __forceinline__ int wmap(int r, int seg, int step) { return seg > 0 ? (r % seg) * step + r / seg : r; }
 
-constexpr int BT = 64, BK = 16, LDT = BT + 1;
+constexpr int BT = 128, BK = 16, LDT = BT + 4;
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Gemm p)
+// ---- the tile core shared by both kernels -----------------------------------------------------------------------------
+// 128 x 128 output tile per workgroup, 4 waves (2 x 2) of 64 x 64 = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32 each;
+// 16-deep steps through TWO LDS stages ([k][128] fp32 images: operand reads are lane-contiguous), the next step's
+// elements are requested into registers before the current step is multiplied (one barrier per step), zero-filled
+// edges, M / N / K arbitrary.  `la(m, k)` / `lb(k, n)` return one element; the thread -> element map puts the
+// memory-contiguous index of each operand on consecutive lanes (a_kfast / b_nfast).  (Round 4: the first version —
+// 64 x 64 tiles, no overlap of loads and products — ran the projections of the iRPE layer at ~15 TFLOP/s.)
+// Addresses are SEPARABLE in every use (element (m, k) of A at am(m) + ak(k), element (k, n) of B at bn(n) + bk(k)): the
+// row / column parts of a thread's eight elements are computed once per tile, the contraction part once per step (the
+// first version evaluated the qkv row map — an integer division — for every element of every step: ~1.5k VALU
+// instructions per step next to 32 MFMAs).
+template <class AM, class AK, class BN_, class BK_, class Store>
+__device__ __forceinline__ void f32_tile_core(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K, int m0, int n0,
+                                              bool a_kfast, bool b_nfast, AM am, AK ak, BN_ bn, BK_ bk, Store st)
 {
-    __shared__ float As[BK][LDT], Bs[BK][LDT];
+    __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
-    const bool a_kfast = p.sak == 1;
-    const bool b_nfast = !p.b_w_is_n;    // memory-contiguous index of B: ic = n unless the forward form
-    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
+    const int wm = wave >> 1, wn = wave & 1, c32 = lane & 31, g = lane >> 5;
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m, k;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < p.M && gk < p.K) ? p.A[(int64_t)gm * p.sam + (int64_t)gk * p.sak] : 0.f;
-            int n, kb;
-            if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            float v = 0.f;
-            if (gn < p.N && gkb < p.K) {
-                const int iw = p.b_w_is_n ? gn : gkb, ic = p.b_w_is_n ? gkb : gn;
-                v = p.B[(int64_t)wmap(iw, p.b_seg, p.b_step) * p.ldw + ic];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // tile-invariant parts.  k-fast operand: eight rows (tid >> 4) + 16 i, one k per step; row-fast operand: one row
+    // tid & 127, eight k's (tid >> 7) + 2 i per step
+    int64_t arow[8], bcol[8];
+    unsigned aok = 0, bok = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + (a_kfast ? (tid >> 4) + 16 * i : (tid & 127));
+        const int n = n0 + (b_nfast ? (tid & 127) : (tid >> 4) + 16 * i);
+        if (m < M) { aok |= 1u << i; arow[i] = am(m); } else arow[i] = 0;
+        if (n < N) { bok |= 1u << i; bcol[i] = bn(n); } else bcol[i] = 0;
+    }
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+        if (a_kfast) {
+            const int k = k0 + (tid & 15);
+            const int64_t ko = k < K ? ak(k) : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra[i] = (k < K && ((aok >> i) & 1)) ? A[arow[i] + ko] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + (tid >> 7) + 2 * i;
+                ra[i] = (k < K && (aok & 1)) ? A[arow[0] + ak(k)] : 0.f;
             }
-            Bs[kb][n] = v;
         }
-        __syncthreads();
+        if (!b_nfast) {
+            const int k = k0 + (tid & 15);
+            const int64_t ko = k < K ? bk(k) : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rb[i] = (k < K && ((bok >> i) & 1)) ? B[bcol[i] + ko] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + (tid >> 7) + 2 * i;
+                rb[i] = (k < K && (bok & 1)) ? B[bcol[0] + bk(k)] : 0.f;
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (a_kfast) As[buf][tid & 15][(tid >> 4) + 16 * i] = ra[i]; else As[buf][(tid >> 7) + 2 * i][tid & 127] = ra[i];
+            if (b_nfast) Bs[buf][(tid >> 7) + 2 * i][tid & 127] = rb[i]; else Bs[buf][tid & 15][(tid >> 4) + 16 * i] = rb[i];
+        }
+    };
+    const int nk = (K + BK - 1) / BK;
+    if (nk > 0) { fetch(0); commit(0); }
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) fetch((s + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[buf][kk + g][wm * 64 + i * 32 + c32];
+                b[i] = Bs[buf][kk + g][wn * 64 + i * 32 + c32];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (s + 1 < nk) commit(buf ^ 1);             // (stage buf ^ 1 was last read in step s - 1: every wave is past the barrier that ended it)
         __syncthreads();
     }
     // D[i][j]: lane owns column j = lane & 31 and rows acc_row(r, lane >> 5)
-    const int n = n0 + wn * 32 + (lane & 31);
-    if (n >= p.N) return;
-    const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + acc_row(r, lane >> 5);
-        if (m < p.M) p.C[(int64_t)wmap(m, p.c_seg, p.c_step) * p.ldc + n] = acc[r] + bv;
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + c32;
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(r, g);
+                if (m < M) st(m, n, acc[i][j][r]);
+            }
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Gemm p)
+{
+    // B element (k, n) = B[wmap(iw) * ldw + ic] with (iw, ic) = (n, k) [forward] or (k, n) [dgrad / wgrad]
+    const bool fw = p.b_w_is_n != 0;
+    f32_tile_core(p.A, p.B, p.M, p.N, p.K, blockIdx.y * BT, blockIdx.x * BT, p.sak == 1, !fw,
+                  [&](int m) { return (int64_t)m * p.sam; },
+                  [&](int k) { return (int64_t)k * p.sak; },
+                  [&](int n) { return fw ? (int64_t)wmap(n, p.b_seg, p.b_step) * p.ldw : (int64_t)n; },
+                  [&](int k) { return fw ? (int64_t)k : (int64_t)wmap(k, p.b_seg, p.b_step) * p.ldw; },
+                  [&](int m, int n, float v) {
+                      p.C[(int64_t)wmap(m, p.c_seg, p.c_step) * p.ldc + n] = v + (p.bias ? p.bias[n] : 0.f);
+                  });
 }
 
 // ---- strided batched product (the attention products of the iRPE parity mode) -------------------------------------
 // C_z(M x N) = A_z(M x K) . B_z(K x N) for z = (z0, z1) in nb0 x nb1, every operand addressed through ELEMENT strides
 // (transposes, head-interleaved (B, L, 3, H, d) layouts and broadcast operands — batch stride 0 — are views, not copies):
 //   q k^T, P v of RPEAttention.forward (iRPE/DeiT-with-iRPE/rpe_vision_transformer.py:76, :88), the lookup products
-//   x W of irpe.py:641-644 / :683-687, and what autograd derives for them.  Same 64 x 64 tile, 16-deep LDS images and
-//   exact-fp32 matrix-core accumulation as gemm_f32_kernel; the loader picks the memory-contiguous index of each
-//   operand as its fast thread index.
+//   x W of irpe.py:641-644 / :683-687, and what autograd derives for them.  The tile core above; the loader picks the
+//   memory-contiguous index of each operand as its fast thread index.
 struct F32Bmm {
     const float* A; int64_t sam, sak, sa0, sa1;
     const float* B; int64_t sbk, sbn, sb0, sb1;
@@ -105,54 +177,40 @@ struct F32Bmm {
 
 __global__ __launch_bounds__(256) void bmm_f32_kernel(const F32Bmm p)
 {
-    __shared__ float As[BK][LDT], Bs[BK][LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
     const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
-    const float* A = p.A + z0 * p.sa0 + z1 * p.sa1;
-    const float* B = p.B + z0 * p.sb0 + z1 * p.sb1;
-    float* C = p.C + z0 * p.sc0 + z1 * p.sc1;
-    const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
-    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m, k;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < p.M && gk < p.K) ? A[(int64_t)gm * p.sam + (int64_t)gk * p.sak] : 0.f;
-            int n, kb;
-            if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < p.N && gkb < p.K) ? B[(int64_t)gkb * p.sbk + (int64_t)gn * p.sbn] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int n = n0 + wn * 32 + (lane & 31);
-    if (n >= p.N) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + acc_row(r, lane >> 5);
-        if (m < p.M) C[(int64_t)m * p.scm + (int64_t)n * p.scn] = acc[r];
-    }
+    const float* __restrict__ A = p.A + z0 * p.sa0 + z1 * p.sa1;
+    const float* __restrict__ B = p.B + z0 * p.sb0 + z1 * p.sb1;
+    float* __restrict__ C = p.C + z0 * p.sc0 + z1 * p.sc1;
+    f32_tile_core(A, B, p.M, p.N, p.K, blockIdx.y * BT, blockIdx.x * BT, p.sak == 1, p.sbn == 1,
+                  [&](int m) { return (int64_t)m * p.sam; }, [&](int k) { return (int64_t)k * p.sak; },
+                  [&](int n) { return (int64_t)n * p.sbn; }, [&](int k) { return (int64_t)k * p.sbk; },
+                  [&](int m, int n, float v) { C[(int64_t)m * p.scm + (int64_t)n * p.scn] = v; });
 }
 
-// column sums of an (M x C) fp32 matrix, one thread per column, rows in ascending order (fixed order)
-__global__ __launch_bounds__(64) void colsum_f32_kernel(float* __restrict__ out, const float* __restrict__ a, int M, int C, int64_t ld)
+// column sums of an (M x C) fp32 matrix: 64 columns x 16 row lanes per workgroup; row lane l adds rows l, l + 16, ...
+// in ascending order, the 16 lanes are combined in ascending order through LDS (a fixed summation tree).  (The first
+// version walked all M rows with one thread per column: 11 ms per call at M = 36,928 — 43 % of the fp32 iRPE layer.)
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(float* __restrict__ out, const float* __restrict__ a, int M, int C, int64_t ld)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, l = threadIdx.y;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += a[(int64_t)m * ld + c];
-    out[c] = s;
+    if (c < C) {
+        int m = l;
+        for (; m + 48 < M; m += 64) {                                        // four loads in flight
+            const float x0 = a[(int64_t)m * ld + c], x1 = a[(int64_t)(m + 16) * ld + c];
+            const float x2 = a[(int64_t)(m + 32) * ld + c], x3 = a[(int64_t)(m + 48) * ld + c];
+            s += x0; s += x1; s += x2; s += x3;
+        }
+        for (; m < M; m += 16) s += a[(int64_t)m * ld + c];
+    }
+    red[l][threadIdx.x] = s;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        float t = red[0][threadIdx.x];
+        for (int i = 1; i < 16; ++i) t += red[i][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 int launch(const F32Gemm& p, hipStream_t st)
@@ -198,7 +256,7 @@ int cream_linear_f32_wgrad(float* dw, float* dbias, const float* dy, const float
     F32Gemm p{dy, 1, N, x, ldx, dw, lddw, nullptr, N, K, M, 0, 0, 0, seg, step};
     const int rc = launch(p, (hipStream_t)stream);
     if (rc != CREAM_OK || !dbias) return rc;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, dbias, dy, M, N, (int64_t)N);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(64, 16), 0, (hipStream_t)stream, dbias, dy, M, N, (int64_t)N);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
