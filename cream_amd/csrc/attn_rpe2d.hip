@@ -30,6 +30,7 @@
 
 #include "attn_common.hpp"
 #include "cream_amd.h"
+#include "launch_ev.hpp"
 
 namespace {
 using namespace cream;
@@ -1506,7 +1507,7 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, img, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    hipLaunchKernelGGL(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, (const short*)img);
+    CREAM_LAUNCH(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, (const short*)img);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

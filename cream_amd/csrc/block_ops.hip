@@ -22,6 +22,7 @@
 
 #include "attn_common.hpp"
 #include "cream_amd.h"
+#include "launch_ev.hpp"
 
 namespace {
 using namespace cream;
@@ -657,7 +658,7 @@ int cream_ln_bwd(float* dx, void* dx_scaled, float* partial, const void* dy, con
     // on the chip all variants run at 4.6-4.8 TB/s (tools/probes/ln_probe.hip); next to the weight-gradient GEMMs of
     // the side stream the deeper request queue is worth 1.0-1.2 % of the training step (same-box A/B, twice).
     auto kern = E <= 512 ? ln_bwd_kernel<2, 2> : (E <= 768 ? ln_bwd_kernel<3, 0> : ln_bwd_kernel<LN_MAXC, 0>);
-    hipLaunchKernelGGL(kern, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
+    CREAM_LAUNCH(kern, dim3(cream_ln_partials()), dim3(256), 0, (hipStream_t)stream, dx,
                        (uint16_t*)dx_scaled, partial, (const uint16_t*)dy, x, mean, rstd, gamma, dres, sample_scale,
                        rows_per_sample, M, E);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "launch_ev.hpp"
 
 #include <atomic>
 #include <mutex>
@@ -117,41 +118,80 @@ constexpr int MAX_DEV = 16, EV_PER_DEV = 8;
 std::mutex g_ev_mu;
 hipEvent_t g_ev[MAX_DEV][EV_PER_DEV];
 int g_ev_n[MAX_DEV] = {}, g_ev_next[MAX_DEV] = {};
+}  // namespace
+namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; }
+namespace {
+
+// 1: the events that order the side stream behind dgrad_mul / the LayerNorm backwards / the attention backward ride on
+// those kernels' own dispatch packets (launch_ev.hpp); 0: an event record (a marker packet) behind each.  CREAM_FORK_ON_KERNEL.
+int fork_on_kernel_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("CREAM_FORK_ON_KERNEL"); m = e ? (atoi(e) != 0) : 1; }
+    return m;
+}
+
+hipEvent_t next_fork_event(int dev);
+
+// arm(): hand the next kernel launched through CREAM_LAUNCH on this thread a completion event; join(): make `side` wait
+// for it — by a plain record behind the kernel if the launch did not take the event (another code path, or mode 0)
+struct KernelFork {
+    hipEvent_t ev = nullptr;
+    hipStream_t main, side;
+    KernelFork(hipStream_t m, hipStream_t s) : main(m), side(s) {}
+    ~KernelFork() { if (ev && cream::tl_stop_event == ev) cream::tl_stop_event = nullptr; }      // (error return between arm and join)
+    bool arm() {
+        if (main == side) return true;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+        ev = next_fork_event(dev);
+        if (!ev) return false;
+        if (fork_on_kernel_mode()) cream::tl_stop_event = ev;
+        return true;
+    }
+    bool join() {
+        if (main == side) return true;
+        if (cream::tl_stop_event == ev || !fork_on_kernel_mode()) {           // not taken: record behind the kernel
+            cream::tl_stop_event = nullptr;
+            if (hipEventRecord(ev, main) != hipSuccess) return false;
+        }
+        return hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+    }
+};
+
+hipEvent_t next_fork_event(int dev) {
+    if (dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ev_mu);
+    if (g_ev_n[dev] < EV_PER_DEV) {
+        // Events WITHOUT the system-scope fence: both streams run on this device, the kernels' own agent-scope release /
+        // acquire orders their data; the default system-scope release made every record on the main chain cost 4.1 us of
+        // step time, 2.7 us without it (CREAM_EXTRA_RECORDS experiment: 64 records per step; same-box A/B x2: 9.99 ->
+        // 9.85 ms per step, profiles/r04_step_gaps.md).  CREAM_EVENT_FLAGS=0 restores plain no-timing events,
+        // 2 = hipEventReleaseToDevice (measured: no different from 0).  Ordering by stream memory operations
+        // (hipStreamWriteValue32 / WaitValue32 on signal memory) was measured too: 11.29 against 9.35 ms.
+        static int fl = -1;
+        if (fl < 0) { const char* e = getenv("CREAM_EVENT_FLAGS"); fl = e ? atoi(e) : 1; }
+        const unsigned flags = hipEventDisableTiming | (fl == 1 ? hipEventDisableSystemFence : fl == 2 ? hipEventReleaseToDevice : 0u);
+        if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], flags) != hipSuccess) return nullptr;
+        ++g_ev_n[dev];
+    }
+    hipEvent_t ev = g_ev[dev][g_ev_next[dev]];
+    g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
+    return ev;
+}
+
 bool fork(hipStream_t main, hipStream_t side) {
     if (main == side) return true;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
-    hipEvent_t ev;
-    {
-        std::lock_guard<std::mutex> lock(g_ev_mu);
-        if (g_ev_n[dev] < EV_PER_DEV) {
-            // Events WITHOUT the system-scope fence: both streams run on this device, the kernels' own agent-scope release /
-            // acquire orders their data; the default system-scope release made every record on the main chain cost 4.1 us of
-            // step time, 2.7 us without it (CREAM_EXTRA_RECORDS experiment: 64 records per step; same-box A/B x2: 9.99 ->
-            // 9.85 ms per step, profiles/r04_step_gaps.md).  CREAM_EVENT_FLAGS=0 restores plain no-timing events,
-            // 2 = hipEventReleaseToDevice (measured: no different from 0).  Ordering by stream memory operations
-            // (hipStreamWriteValue32 / WaitValue32 on signal memory) was measured too: 11.29 against 9.35 ms.
-            static int fl = -1;
-            if (fl < 0) { const char* e = getenv("CREAM_EVENT_FLAGS"); fl = e ? atoi(e) : 1; }
-            const unsigned flags = hipEventDisableTiming | (fl == 1 ? hipEventDisableSystemFence : fl == 2 ? hipEventReleaseToDevice : 0u);
-            if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], flags) != hipSuccess) return false;
-            ++g_ev_n[dev];
-        }
-        ev = g_ev[dev][g_ev_next[dev]];
-        g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
-    }
+    hipEvent_t ev = next_fork_event(dev);
+    if (!ev) return false;
     // measurement switch (tools only): CREAM_EXTRA_RECORDS = n records n more events on the main stream that nobody
     // waits for — what a marker packet between two kernels of the main chain costs (profiles/r04_step_gaps.md)
     static int extra = -1;
     if (extra < 0) { const char* e = getenv("CREAM_EXTRA_RECORDS"); extra = e ? atoi(e) : 0; }
     for (int i = 0; i < extra; ++i) {
-        hipEvent_t ex;
-        {
-            std::lock_guard<std::mutex> lock(g_ev_mu);
-            ex = g_ev[dev][g_ev_next[dev]];
-            g_ev_next[dev] = (g_ev_next[dev] + 1) % g_ev_n[dev];
-        }
-        if (ex != ev && hipEventRecord(ex, main) != hipSuccess) return false;
+        hipEvent_t ex = next_fork_event(dev);
+        if (ex && ex != ev && hipEventRecord(ex, main) != hipSuccess) return false;
     }
     return hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
 }
@@ -340,6 +380,8 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, wgrad_parts(wb16, at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     }
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
+    KernelFork f_dh(main, side), f_dp(main, side), f_dqkv(main, side), f_dx(main, side);
+    if (!grouped && !f_dh.arm()) return CREAM_ERR_LAUNCH;                 // (the dgrad's own packet carries the event)
     if (gelu_recompute_for(d))
         PTRY(K_GEMM_NT_MUL, main, 4.0 * M * E * F, 0, cream_linear_dgrad_gelugrad(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.c), d->w1, d->b1,
                                      M, E, F, d->F_valid > 0 ? d->F_valid : F, d->ld_w2_t, d->ld_w1, main));
@@ -347,27 +389,29 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
                                      main));
     if (!grouped) {
-        if (!fork(main, side)) return CREAM_ERR_LAUNCH;
+        if (!f_dh.join()) return CREAM_ERR_LAUNCH;
         PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, wgrad_parts(wb16, at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
+    if (!grouped && !f_dp.arm()) return CREAM_ERR_LAUNCH;
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
     if (!grouped) {
-        if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // dp complete on main
+        if (!f_dp.join()) return CREAM_ERR_LAUNCH;                        // dp complete on main
         PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, wgrad_parts(wb16, at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
+    if (!f_dqkv.arm()) return CREAM_ERR_LAUNCH;
     PTRY(K_ATTN_BWD, main, 2.5 * attn_flops(d), 0, cream_attn_rpe2d_bwd(dqkv, dqkv + Q, dqkv + 2 * Q, sb, sn, 64, at<float>(ws, L.dtab), at<void>(ws, L.dlt), at<void>(ws, L.qe),
                              at<void>(ws, L.de), at<float>(ws, L.delta), at<void>(ws, L.dout), at<void>(fws, FL.o),
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;                       // dqkv complete on main
+    if (!f_dqkv.join()) return CREAM_ERR_LAUNCH;                          // dqkv complete on main
     if (!grouped) {
         // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
         PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, wgrad_parts(wb16, at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
@@ -382,11 +426,12 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
              cream_wgrad_group(W, 4, M, G->wgrad_slabs, G->wgrad_counters, side));
     }
     PTRY(K_GEMM_NT, main, 2.0 * M * 3 * Q * E, 0, cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
+    if (!f_dx.arm()) return CREAM_ERR_LAUNCH;
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
                      at<float>(fws, FL.mean1), at<float>(fws, FL.rstd1), d->ln1_g, at<float>(ws, L.dx1), prev_scale, N, M, E, main));
 
     // ---- gradient finalisation: every parameter of the block in one launch, on the side stream ----
-    if (!fork(main, side)) return CREAM_ERR_LAUNCH;
+    if (!f_dx.join()) return CREAM_ERR_LAUNCH;
     cream_grad_job J[18];
     int n = 0;
     auto job = [&](float* dst, int64_t ld, const void* src, int nparts, int64_t pstride, int rows, int cols, int interleave,

@@ -21,6 +21,7 @@
 
 #include "cream_amd.h"
 #include "gemm_mfma.hpp"
+#include "launch_ev.hpp"
 
 namespace {
 using namespace cream;
@@ -83,11 +84,11 @@ int launch_nt(const NtParams& p, hipStream_t st)
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
     } else {
         constexpr int BM = 128, BN = 64, OCC = 3;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
     }
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }

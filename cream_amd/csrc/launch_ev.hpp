@@ -1,0 +1,26 @@
+// launch_ev.hpp — a completion event carried by a kernel's OWN dispatch packet.
+//
+// cream_block_bwd orders the weight-gradient stream behind kernels of the main chain.  An event recorded behind a
+// kernel is a marker packet between it and the next kernel of the chain: 2.7 us of step time each (4.1 us with the
+// default system-scope fence), 64 of them per training step (profiles/r04_step_gaps.md).  hipExtLaunchKernelGGL attaches
+// the event to the kernel's dispatch packet instead: the packet's completion signal is the event, nothing is enqueued
+// behind it.  The sequencing code arms `tl_stop_event` right before the call that launches the producing kernel; the
+// launch helper of that kernel (CREAM_LAUNCH) consumes it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+namespace cream {
+extern thread_local hipEvent_t tl_stop_event;       // defined in block_seq.cpp
+}
+
+#define CREAM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                        \
+    do {                                                                                                             \
+        hipEvent_t ev__ = cream::tl_stop_event;                                                                      \
+        if (ev__) {                                                                                                  \
+            cream::tl_stop_event = nullptr;                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev__, 0, __VA_ARGS__);                \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
+        }                                                                                                            \
+    } while (0)
