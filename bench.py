@@ -606,8 +606,10 @@ def main():
                 roof["traffic_unit"] = "HBM bytes per launch (mean over the sampled sub-networks), rocprofv3 PMC pass: " + src
             roof["launches"] = st["launches"]
             roof["avg_us"] = round(st["avg_ms"] * 1e3, 2)
-            roof["timing"] = ("in-step: HIP events inside the native block calls, on each kernel's launch stream, two streams live; "
-                              f"{nprof} steps right after the timed region at {round(prof_ms_per_step, 3)} ms/step with the events in place")
+            roof["timing"] = ("in-step: a start / stop HIP event pair carried by each kernel's own dispatch packet (hipExtLaunchKernelGGL, "
+                              "csrc/launch_ev.hpp) inside the native block calls, on the kernel's launch stream, two streams live; "
+                              f"{nprof} steps right after the timed region at {round(prof_ms_per_step, 3)} ms/step with the events in place; "
+                              "multi-kernel operators are timed on their last kernel")
             roof["kernels"] = {k: dict(launches=v["launches"], avg_us=round(v["avg_ms"] * 1e3, 2),
                                        total_ms=round(v["total_ms"], 3), ms_per_step=round(v["total_ms"] / nprof, 3),
                                        tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,

@@ -911,7 +911,7 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     FwdArgs aa = a;
     aa.nitems = B * a.H;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, st, aa);
+    CREAM_LAUNCH(kern, dim3(grid), dim3(waves * 64), lds, st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -945,7 +945,7 @@ int launch_fwd1(const FwdArgs& a, int B, hipStream_t st) {
     FwdArgs aa = a;
     aa.nitems = B * a.H;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    hipLaunchKernelGGL(v2::attn_rpe2d_fwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::FWD1_LDS_B, st, aa);
+    CREAM_LAUNCH(v2::attn_rpe2d_fwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::FWD1_LDS_B, st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -960,7 +960,7 @@ int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
     FwdArgs aa = a;
     aa.nitems = B * a.H;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    hipLaunchKernelGGL(attn_rpe2d_fwd14_kernel, dim3(grid), dim3(W14_THREADS), fwd14_lds_bytes(), st, aa);
+    CREAM_LAUNCH(attn_rpe2d_fwd14_kernel, dim3(grid), dim3(W14_THREADS), fwd14_lds_bytes(), st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -1469,7 +1469,7 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
     (void)kkv;
     return CREAM_OK;
 #endif
-    hipLaunchKernelGGL(kkv, dim3(pgrid), dim3(512), bwd_kv_lds_bytes<T>(a.NP), st, aa);
+    CREAM_LAUNCH(kkv, dim3(pgrid), dim3(512), bwd_kv_lds_bytes<T>(a.NP), st, aa);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

@@ -598,7 +598,7 @@ int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float*
     if (!y || !mean || !rstd || !x || !gamma || !beta) return CREAM_ERR_BAD_ARG;
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16) return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+    CREAM_LAUNCH(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
                        x, gamma, beta, M, E, eps, (float*)nullptr, (const uint16_t*)nullptr, (const float*)nullptr, 1);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
@@ -639,7 +639,7 @@ int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float
     if (E % 4 || E > 64 * 4 * LN_MAXC) return CREAM_ERR_TOO_LARGE;
     if (((uintptr_t)xsum | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) % 16 || (uintptr_t)res % 8)
         return CREAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
+    CREAM_LAUNCH(ln_fwd_kernel<uint16_t>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (uint16_t*)y, mean, rstd,
                        x, gamma, beta, M, E, eps, xsum, (const uint16_t*)res, sample_scale, rows_per_sample);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
@@ -775,7 +775,7 @@ int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream)
         blocks += (int)((nchunks + CL - 1) / CL);
     }
     J.first_block[njobs] = blocks;
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+    CREAM_LAUNCH(grad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 

@@ -119,7 +119,7 @@ std::mutex g_ev_mu;
 hipEvent_t g_ev[MAX_DEV][EV_PER_DEV];
 int g_ev_n[MAX_DEV] = {}, g_ev_next[MAX_DEV] = {};
 }  // namespace
-namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; }
+namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }
 namespace {
 
 // 1: the events that order the side stream behind dgrad_mul / the LayerNorm backwards / the attention backward ride on
@@ -131,12 +131,14 @@ int fork_on_kernel_mode() {
 }
 
 hipEvent_t next_fork_event(int dev);
+bool prof_active();
 
 // arm(): hand the next kernel launched through CREAM_LAUNCH on this thread a completion event; join(): make `side` wait
 // for it — by a plain record behind the kernel if the launch did not take the event (another code path, or mode 0)
 struct KernelFork {
     hipEvent_t ev = nullptr;
     hipStream_t main, side;
+    bool armed_ = false;
     KernelFork(hipStream_t m, hipStream_t s) : main(m), side(s) {}
     ~KernelFork() { if (ev && cream::tl_stop_event == ev) cream::tl_stop_event = nullptr; }      // (error return between arm and join)
     bool arm() {
@@ -145,12 +147,13 @@ struct KernelFork {
         if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
         ev = next_fork_event(dev);
         if (!ev) return false;
-        if (fork_on_kernel_mode()) cream::tl_stop_event = ev;
+        armed_ = fork_on_kernel_mode() && !prof_active();                     // (the in-step timing owns the packet's events)
+        if (armed_) cream::tl_stop_event = ev;
         return true;
     }
     bool join() {
         if (main == side) return true;
-        if (cream::tl_stop_event == ev || !fork_on_kernel_mode()) {           // not taken: record behind the kernel
+        if (cream::tl_stop_event == ev || !armed_) {                          // not taken: record behind the kernel
             cream::tl_stop_event = nullptr;
             if (hipEventRecord(ev, main) != hipSuccess) return false;
         }
@@ -250,6 +253,13 @@ hipEvent_t prof_event() {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+bool prof_active() { return g_prof_on.load(std::memory_order_relaxed); }
+// The pair of events of a record is CARRIED BY THE KERNEL'S OWN DISPATCH PACKET (launch_ev.hpp: CREAM_LAUNCH hands them to
+// hipExtLaunchKernelGGL as start / stop events): the elapsed time is the kernel's execution, as rocprofv3 reports it, and no
+// marker packets enter the streams (round 3 recorded an event in front of and behind every launch: ~1,400 markers per step,
+// 4 us each on the main chain — the timed pass ran 25 % slower than the step it measured).  Multi-kernel operators are
+// timed on their last kernel (attention backward: the one-pass kernel, not the 6 us table-image launch in front of it);
+// an operator whose launch does not go through CREAM_LAUNCH is not sampled.
 struct ProfScope {
     ProfRec r{};
     hipStream_t st;
@@ -259,8 +269,10 @@ struct ProfScope {
         std::lock_guard<std::mutex> lock(g_prof_mu);
         r.kind = kind; r.flops = flops; r.bytes = bytes;
         r.a = prof_event(); r.b = prof_event();
-        on = r.a && r.b && hipEventRecord(r.a, st) == hipSuccess;
-        if (!on) give_back();
+        on = r.a && r.b;
+        if (!on) { give_back(); return; }
+        cream::tl_start_event = r.a;
+        cream::tl_stop_event = r.b;
     }
     void give_back() {                       // (caller holds g_prof_mu) events of a failed scope return to the pool
         if (r.a) g_prof_free.push_back(r.a);
@@ -270,8 +282,13 @@ struct ProfScope {
     ~ProfScope() {
         if (!on) return;
         std::lock_guard<std::mutex> lock(g_prof_mu);
-        if (hipEventRecord(r.b, st) == hipSuccess) g_prof_recs.push_back(r);
-        else give_back();
+        if (cream::tl_stop_event == r.b || cream::tl_start_event == r.a) {   // the launch did not take them: no sample
+            cream::tl_stop_event = nullptr;
+            cream::tl_start_event = nullptr;
+            give_back();
+        } else {
+            g_prof_recs.push_back(r);
+        }
     }
 };
 #define PTRY(kind, st, flops, bytes, call) do { ProfScope ps_((kind), (hipStream_t)(st), (double)(flops), (double)(bytes)); TRY(call); } while (0)

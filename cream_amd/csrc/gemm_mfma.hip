@@ -71,7 +71,7 @@ int launch_nt256(const NtParams& p, hipStream_t st)
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, st, p);
+    CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -269,8 +269,8 @@ int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const vo
     // the bias-free instantiation has no bias accumulators (126 instead of 165 VGPRs: room for two more waves of the main chain's
     // kernels per SIMD next to two of these — measured neutral on the step, 10.76 vs 10.75 ms in a same-box A/B x3: the two
     // streams share throughput, not register space)
-    if (bias_parts) hipLaunchKernelGGL((gemm_tn_kernel<2, 64, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<2, 64, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (bias_parts) CREAM_LAUNCH((gemm_tn_kernel<2, 64, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else CREAM_LAUNCH((gemm_tn_kernel<2, 64, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 }  // namespace

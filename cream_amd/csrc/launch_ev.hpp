@@ -12,14 +12,18 @@
 
 namespace cream {
 extern thread_local hipEvent_t tl_stop_event;       // defined in block_seq.cpp
+// in-step kernel timing (cream_block_prof_*): a start event for the same launch — the pair then brackets the kernel's own
+// execution on its dispatch packet (what rocprofv3 reports), with no marker packets in the stream
+extern thread_local hipEvent_t tl_start_event;
 }
 
 #define CREAM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                        \
     do {                                                                                                             \
-        hipEvent_t ev__ = cream::tl_stop_event;                                                                      \
-        if (ev__) {                                                                                                  \
+        hipEvent_t ev__ = cream::tl_stop_event, sv__ = cream::tl_start_event;                                        \
+        if (ev__ || sv__) {                                                                                          \
             cream::tl_stop_event = nullptr;                                                                          \
-            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev__, 0, __VA_ARGS__);                \
+            cream::tl_start_event = nullptr;                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, sv__, ev__, 0, __VA_ARGS__);                   \
         } else {                                                                                                     \
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
         }                                                                                                            \
