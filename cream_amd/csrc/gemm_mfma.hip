@@ -52,7 +52,11 @@ int nt256_mode()
     int m = g_nt256.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("CREAM_GEMM_NT256");
-        m = e ? (atoi(e) != 0) : 0;
+        // default 2: with COLD operands (rotating buffer sets, profiles/r04_gemm_probe_cold.txt) the macro tile is 6-14 % faster
+        // than the 128-wide tiles where the contraction is long (fc2, fc1 dgrad, qkv dgrad: K = 1152 .. 1792, N = E) and
+        // equal or slower on the wide-output shapes (mode 1) — the warm-buffer probe of the same kernels had it the other way
+        // round.  Same-box A/B of the step, alternating, twice: 9.455 / 9.502 -> 9.351 / 9.402 ms (-1.0 %).
+        m = e ? atoi(e) : 2;
         g_nt256.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -79,7 +83,9 @@ template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
     if constexpr (EPI != EPI_GELUGRAD_COLSUM) {                  // (two accumulator sets do not fit the macro tile's registers)
-        if (p.N >= 960 && nt256_mode()) return launch_nt256<EPI>(p, st);
+        // mode 1: the wide outputs (N >= 960); mode 2: the LONG contractions (K >= 1152: fc2, fc1 dgrad, qkv dgrad at E >= 384 — N = E); mode 3: K >= 960
+        const int m256 = nt256_mode();
+        if ((m256 == 1 && p.N >= 960) || (m256 == 2 && p.K >= 1152) || (m256 == 3 && p.K >= 960)) return launch_nt256<EPI>(p, st);
     }
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
@@ -125,7 +131,7 @@ int cream_gemm_rows_per_colsum_slab(void) { return 128; }
 int cream_gemm_nt256(int on)
 {
     const int prev = nt256_mode();
-    if (on >= 0) g_nt256.store(on != 0, std::memory_order_relaxed);
+    if (on >= 0) g_nt256.store(on, std::memory_order_relaxed);
     return prev;
 }
 

@@ -362,10 +362,12 @@ int cream_scale_cast_colsum(void* out, float* partial, const float* x, const flo
  *                             this library uses for a problem (~1 workgroup per CU, at most 16). */
 int cream_gemm_rows_per_colsum_slab(void);
 
-/* Tile choice of the NT products with wide outputs (N >= 960: qkv_super / fc1 forward, fc2 dgrad — Linear_super.py:38-54,
- * qkv_super.py:45-55): 1 = the 256 x 256 macro tile (8 waves, one persistent workgroup per CU), 0 = 128 x 128 tiles
- * (two workgroups per CU).  on < 0 only queries; returns the previous setting; the initial one comes from
- * CREAM_GEMM_NT256 in the environment.  A switch for same-box A/B measurements — results are identical. */
+/* Tile choice of the NT products (Linear_super.py:38-54, qkv_super.py:45-55 and their dgrads): where the 256 x 256 macro
+ * tile (8 waves, 128 KB of LDS, one persistent workgroup per CU) replaces the 128-wide tiles (two to three workgroups per CU).
+ * 0 = nowhere; 1 = wide outputs (N >= 960: qkv / fc1 forward, fc2 dgrad); 2 = long contractions (K >= 1152: fc2 forward,
+ * fc1 dgrad, qkv dgrad at embed dim >= 384) — the default: 6-14 % faster there with cold operands; 3 = K >= 960.
+ * on < 0 only queries; returns the previous setting; the initial one comes from CREAM_GEMM_NT256 in the environment.
+ * Results are identical in every mode (same products, same epilogues). */
 int cream_gemm_nt256(int on);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
