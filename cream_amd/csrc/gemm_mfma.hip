@@ -85,6 +85,8 @@ int launch_nt(const NtParams& p, hipStream_t st)
     if constexpr (EPI != EPI_GELUGRAD_COLSUM) {                  // (two accumulator sets do not fit the macro tile's registers)
         // mode 1: the wide outputs (N >= 960); mode 2: the LONG contractions (K >= 1152: fc2, fc1 dgrad, qkv dgrad at E >= 384 — N = E); mode 3: K >= 960
         const int m256 = nt256_mode();
+        // (also measured: K >= 1152 plus the K = 448 shapes and qkv at E = 384, where the cold probe has the macro tile ahead: 9.47 / 9.45 ->
+        //  9.50 / 9.51 ms per step — the step does not follow the probe there)
         if ((m256 == 1 && p.N >= 960) || (m256 == 2 && p.K >= 1152) || (m256 == 3 && p.K >= 960)) return launch_nt256<EPI>(p, st);
     }
     if (p.N >= 640) {
