@@ -11,6 +11,8 @@ if [ -z "$SKIP_TESTS" ]; then
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_pytest_gpu.log 2>&1
 echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
 fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1
+echo "smoke exit $?"; tail -2 $OUT/${TAG}_smoke.log
 timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
