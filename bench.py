@@ -560,19 +560,26 @@ def main():
     if not a.no_kernel_timing:                # every rank runs the pass (its steps contain collectives)
         from cream_amd import _lib
         lib = _lib.load()
-        native_prof_summary()                 # (drop stale records)
-        trainer.start_epoch(0)
-        lib.cream_block_prof_enable(1)
-        pm = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        nprof = max(4, min(a.steps, 12))
-        pm[0].record()
-        for _ in range(nprof):
-            trainer.step(images, target)
-        pm[1].record()
-        torch.cuda.synchronize()
-        lib.cream_block_prof_enable(0)
-        ksum = native_prof_summary()
-        prof_ms_per_step = pm[0].elapsed_time(pm[1]) / nprof
+        try:
+            native_prof_summary()                 # (drop stale records)
+            trainer.start_epoch(0)
+            lib.cream_block_prof_enable(1)
+            pm = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            nprof = max(4, min(a.steps, 12))
+            pm[0].record()
+            for _ in range(nprof):
+                trainer.step(images, target)
+            pm[1].record()
+            torch.cuda.synchronize()
+            lib.cream_block_prof_enable(0)
+            ksum = native_prof_summary()
+            prof_ms_per_step = pm[0].elapsed_time(pm[1]) / nprof
+        except Exception as e:                    # the throughput line must not be lost to the timing pass
+            if world > 1:
+                raise                             # (ranks would fall out of step with each other)
+            sys.stderr.write(f"[bench] in-step kernel timing failed: {e}\n")
+            lib.cream_block_prof_enable(0)
+            ksum = {}
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
