@@ -239,7 +239,8 @@ int cream_linear_wgrad_splits(int M, int N, int K)
     // here, read by cream_grad_finalize).  Measured A/B in one call, 3 runs each: 256 / 384 / 512 slots ->
     // 11.60 / 11.60 / 11.65 ms per step (fewer partial bytes vs. a 1.5x slower kernel: 78 vs 53 us standalone);
     // 512 keeps the kernel itself at its best rate
-    constexpr int slots = 512;
+    static int slots = 0;                                       // CREAM_WGRAD_SLOTS (measurement switch); default 512
+    if (!slots) { const char* e = getenv("CREAM_WGRAD_SLOTS"); slots = e && atoi(e) >= 64 ? atoi(e) : 512; }
     int s = slots / tiles;
     if (s > 16) s = 16;                                         // (32 for the small proj gradient: 10.64 vs 10.60 ms per step, A/B x3)
     if (s > steps) s = steps;
