@@ -6,6 +6,7 @@
 // -DATTN_PROFILE: per-phase cycle stamps of the one-pass kernel (last item of every workgroup); -DATTN_PROFILE_STEPS adds
 // the sub-phases of step 3
 #include "../../cream_amd/csrc/attn_rpe2d.hip"
+namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }   // (block_seq.cpp defines them in the library)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

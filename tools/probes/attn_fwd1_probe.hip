@@ -5,6 +5,7 @@
 //         tools/probes/attn_fwd1_probe.hip -o tools/probes/attn_fwd1_probe && tools/probes/attn_fwd1_probe
 // -DATTN_PROFILE: per-phase cycle stamps of the new kernel (last item of every workgroup; -DATTN_PROFILE_ITEM1: the second)
 #include "../../cream_amd/csrc/attn_rpe2d.hip"
+namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }   // (block_seq.cpp defines them in the library)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

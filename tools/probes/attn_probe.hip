@@ -5,6 +5,7 @@
 //         tools/probes/attn_probe.hip -o tools/probes/attn_probe && tools/probes/attn_probe
 #define ATTN_PROFILE 1
 #include "../../cream_amd/csrc/attn_rpe2d.hip"
+namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }   // (block_seq.cpp defines them in the library)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
