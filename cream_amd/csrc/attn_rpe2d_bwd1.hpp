@@ -619,7 +619,9 @@ __global__ __launch_bounds__(THREADS) void attn_rpe2d_bwd1_kernel(const BwdArgs 
             store_tile_staged(myslot, reinterpret_cast<short*>(a.dv) + goff, a.dsn, wave * 32, dv, lane);
         }
         PROF_MARK();
-        const int job0 = wave, job1 = wave + NT;     // job = tab * 2 + dt; only wave 0 has a second one (job 7)
+        // job = tab * 2 + dt.  Wave w takes job w; the eighth job goes to wave 3 — the only wave that has its SIMD to itself
+        // (waves w and w + 4 share one), so every SIMD runs two jobs
+        const int job0 = wave, job1 = wave == 3 ? 7 : 8;
         {
             bf16x8 bk[4];
             slots_to_buckets14_bf16(bk, myslot, dx, lane, wave == 0, min(qr, G14 - 1), qc);
