@@ -182,23 +182,6 @@ __device__ __forceinline__ void mat_dma(const short* src, int64_t rs, uint32_t l
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-struct Mat4 { u32x4v v[4]; };                        // 224 x 64 bf16 = 1792 chunks of 16 B / 448 threads
-__device__ __forceinline__ void mat4_load(Mat4& r, const short* src, int64_t rs, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * THREADS, row = c >> 3, cc = c & 7;
-        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (int64_t)min(row, N14 - 1) * rs + cc * 8);
-        r.v[i] = row < N14 ? v : u32x4v{0, 0, 0, 0};
-    }
-}
-__device__ __forceinline__ void mat4_store(const Mat4& r, unsigned char* dst, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * THREADS, row = c >> 3, cc = c & 7;
-        *reinterpret_cast<u32x4v*>(dst + row * 128 + ((cc ^ swz128(row)) << 4)) = r.v[i];
-    }
-}
-
 // one-hot slot rows of the keys (geometry only): OH[j][c] = 1 iff key j sits in slot c
 __device__ __forceinline__ void fill_onehot_swz(unsigned char* oh) {
     const RelGeom G{N14, G14, G14, G14};
