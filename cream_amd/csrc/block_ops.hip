@@ -19,6 +19,7 @@
 // (leading dimension = the sampled width E: activations live in our own buffers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "attn_common.hpp"
 #include "cream_amd.h"
@@ -588,7 +589,17 @@ int grid_for(int64_t n_items, int per_block) {
 
 extern "C" {
 
-int cream_ln_partials(void) { return 1024; }
+int cream_ln_partials(void)
+{
+    // workgroups (= partial rows) of the LayerNorm backward.  CREAM_LN_PARTIALS (measurement switch, 256 .. 1024, a multiple of 64)
+    static int n = 0;
+    if (!n) {
+        const char* e = getenv("CREAM_LN_PARTIALS");
+        const int v = e ? atoi(e) : 0;
+        n = (v >= 256 && v <= 1024 && v % 64 == 0) ? v : 1024;
+    }
+    return n;
+}
 
 int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,
                  int M, int E, float eps, void* stream)
