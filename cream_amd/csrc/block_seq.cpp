@@ -133,6 +133,10 @@ int fork_on_kernel_mode() {
 hipEvent_t next_fork_event(int dev);
 bool prof_active();
 
+// what the side stream of this thread is already ordered behind: the df_prev output of the last cream_block_bwd call
+struct OrderedBehind { const void* df; hipStream_t main, side; };
+thread_local OrderedBehind tl_ordered = {nullptr, nullptr, nullptr};
+
 // arm(): hand the next kernel launched through CREAM_LAUNCH on this thread a completion event; join(): make `side` wait
 // for it — by a plain record behind the kernel if the launch did not take the event (another code path, or mode 0)
 struct KernelFork {
@@ -393,7 +397,14 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     const int wb16 = wgrad_bf16_mode();           // split-K partial tiles as bf16 (half the partial traffic) or fp32
     const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
     if (!grouped) {
-        if (!fork(main, side)) return CREAM_ERR_LAUNCH;                   // df, g complete on main
+        // df is complete on main.  If it is the df_prev that the PREVIOUS call on this thread and these streams produced, the
+        // side stream is already ordered behind its producer (it waited for that call's last LayerNorm backward before the
+        // finalisation): no event — one marker packet less per block on the main chain.
+        static int reuse = -1;                                             // CREAM_REUSE_ORDER=0: always fork (A/B switch)
+        if (reuse < 0) { const char* e = getenv("CREAM_REUSE_ORDER"); reuse = e ? (atoi(e) != 0) : 1; }
+        const bool ordered = reuse && df && df == tl_ordered.df && main == tl_ordered.main && side == tl_ordered.side;
+        tl_ordered.df = nullptr;
+        if (!ordered && !fork(main, side)) return CREAM_ERR_LAUNCH;
         PTRY(K_GEMM_TN, side, 2.0 * M * E * F, 0, wgrad_parts(wb16, at<float>(ws, L.pw2), nullptr, df, at<void>(fws, FL.g), M, E, F, S2, side));
     }
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
@@ -476,6 +487,7 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     job(G->ln1_g, E, at<float>(ws, L.pl1), P, 3 * (int64_t)E, 1, E, 0, 0);
     job(G->ln1_b, E, at<float>(ws, L.pl1) + E, P, 3 * (int64_t)E, 1, E, 0, 0);
     PTRY(K_GRAD_FINALIZE, side, 0, 0, cream_grad_finalize(J, n, side));
+    if (want_prev && main != side) tl_ordered = OrderedBehind{at<void>(ws, L.df_prev), main, side};
     return CREAM_OK;
 }
 
