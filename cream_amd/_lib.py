@@ -81,6 +81,7 @@ SIGNATURES = {
     "cream_grad_finalize": (_i, [_vp, _i, _vp]),
     "cream_gemm_rows_per_colsum_slab": (_i, []),
     "cream_gemm_nt256": (_i, [_i]),
+    "cream_gemm_nt8": (_i, [_i]),
     "cream_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_fwd_seg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_gelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),

@@ -21,6 +21,7 @@
 
 #include "cream_amd.h"
 #include "gemm_mfma.hpp"
+#include "gemm_nt8.hpp"
 #include "launch_ev.hpp"
 
 namespace {
@@ -62,26 +63,79 @@ int nt256_mode()
     return m;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remembered per device (one process may
+// drive several GPUs, block_seq.cpp: MAX_DEV), not per process
+template <typename K>
+bool raise_dynamic_lds(K kern, int bytes)
+{
+    static std::atomic<uint32_t> done{0};                      // bit d: raised on device d (per instantiation of this template)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32 && (done.load(std::memory_order_relaxed) >> dev & 1u)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+    return true;
+}
+
 template <int EPI>
 int launch_nt256(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256, BN = 256;
     auto kern = gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
-    static bool attr_done = false;               // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
     CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+// the counted-vmcnt, phase-interleaved kernel (gemm_nt8.hpp): 256 x 256 tiles, one persistent 8-wave workgroup per CU.
+// CREAM_GEMM_NT8 in the environment / cream_gemm_nt8(): 0 = never, 1 = wherever its limits allow, 2 = by shape (nt8_wanted)
+std::atomic<int> g_nt8{-1};
+int nt8_mode()
+{
+    int m = g_nt8.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_NT8");
+        m = e ? atoi(e) : 2;
+        g_nt8.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+bool nt8_fits(const NtParams& p)
+{
+    // 31-bit element offsets inside the kernel
+    const int64_t amax = (int64_t)p.M * p.lda, bmax = (int64_t)2 * p.nseg_stride + (int64_t)p.nseg * p.ldb + p.ldb;
+    const int64_t bplain = (int64_t)p.N * p.ldb;
+    return amax < ((int64_t)1 << 31) && bmax < ((int64_t)1 << 31) && bplain < ((int64_t)1 << 31) && p.lda < (1 << 24) && p.ldb < (1 << 24);
+}
+
+template <int EPI>
+int launch_nt8(const NtParams& p, hipStream_t st)
+{
+    auto kern = gemm_nt8_kernel<EPI>;
+    if (!raise_dynamic_lds(kern, NT8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256), slots = num_cus() / 8 * 8;
+    CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(512), NT8_LDS_BYTES, st, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
+    if constexpr (EPI != EPI_GELUGRAD_COLSUM) {
+        // mode 2: where the cold probe has it ahead (profiles/r05_gemm_probe_cold.txt): every plain / bias product; the two
+        // epilogues with element-wise work on the whole tile (GELU, x gelu') stay on the kernels whose second workgroup per CU
+        // multiplies while the first one is in its epilogue — except on the long contractions, where the loop outweighs it
+        const int m8 = nt8_mode();
+        const bool light = EPI == EPI_STORE || EPI == EPI_BIAS;
+        // mode 3: light epilogues, and only where at most 1/8 of the 256-wide column tiles is padding (CU-time, not wall time,
+        // is what the two-stream step pays for)
+        const int npad = (p.N + 255) / 256 * 256;
+        if ((m8 == 1 || (m8 == 2 && (light || p.K >= 1024)) || (m8 == 3 && light && (npad - p.N) * 8 <= npad)) && nt8_fits(p))
+            return launch_nt8<EPI>(p, st);
+    }
     if constexpr (EPI != EPI_GELUGRAD_COLSUM) {                  // (two accumulator sets do not fit the macro tile's registers)
         // mode 1: the wide outputs (N >= 960); mode 2: the LONG contractions (K >= 1152: fc2, fc1 dgrad, qkv dgrad at E >= 384 — N = E); mode 3: K >= 960
         const int m256 = nt256_mode();
@@ -134,6 +188,13 @@ int cream_gemm_nt256(int on)
 {
     const int prev = nt256_mode();
     if (on >= 0) g_nt256.store(on, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_gemm_nt8(int mode)
+{
+    const int prev = nt8_mode();
+    if (mode >= 0) g_nt8.store(mode, std::memory_order_relaxed);
     return prev;
 }
 

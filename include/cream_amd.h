@@ -369,6 +369,14 @@ int cream_gemm_rows_per_colsum_slab(void);
  * on < 0 only queries; returns the previous setting; the initial one comes from CREAM_GEMM_NT256 in the environment.
  * Results are identical in every mode (same products, same epilogues). */
 int cream_gemm_nt256(int on);
+/* Schedule of the NT products (same reference functions): the counted-vmcnt, phase-interleaved kernel of csrc/gemm_nt8.hpp
+ * (256 x 256 tiles, 8 waves in two staggered rows, a whole K-tile of LDS-DMA requests in flight across every barrier, K-tile
+ * stream continuous over output tiles, barrier-free per-wave epilogue).  0 = never (the kernels above), 1 = wherever its
+ * limits allow (31-bit element offsets), 2 = plain and bias products everywhere, the GELU / x gelu' epilogues only on long
+ * contractions (K >= 1024) — the default; mode < 0 only queries; returns the previous setting; the initial one
+ * comes from CREAM_GEMM_NT8 in the environment.  Forward, bias, bias + GELU results are identical to the other kernels';
+ * cream_linear_dgrad_mul rounds dy . W to bf16 before the multiplication (the reference's two operators do). */
+int cream_gemm_nt8(int mode);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
 int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,

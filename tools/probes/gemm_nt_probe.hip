@@ -17,6 +17,7 @@
 
 #define GEMM_PROFILE 1
 #include "gemm_mfma.hpp"
+#include "gemm_nt8.hpp"
 
 using namespace cream;
 using namespace cream::gemm;
@@ -83,7 +84,8 @@ __global__ void check_colsum(float* maxerr, NtParams p, int bm) {
 }
 
 
-struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); };
+struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); int nt8 = 0; };
+#define V8(EPI, PRIO, LE) {"nt8 256x256 " #EPI " prio" #PRIO " le" #LE, 256, 256, 512, EPI, gemm_nt8_kernel<EPI, PRIO, LE>, 1}
 #define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
 static const Variant VARIANTS[] = {
     V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3),
@@ -94,11 +96,19 @@ static const Variant VARIANTS[] = {
     V(256, 256, 2, 2, 2, EPI_BIAS, 1), V(256, 256, 2, 2, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 2, 2, EPI_MUL_COLSUM, 1),
     // round 4: fc2 dgrad with the GELU derivative recomputed from a second product over the same tile
     V(128, 128, 2, 2, 2, EPI_GELUGRAD_COLSUM, 2),
+    // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp); prio: 0 none, 1 setprio around the MFMA groups, 2 static for wave row 1; le1: fragment reads waited for before the barrier
+    V8(EPI_BIAS, 1, false), V8(EPI_BIAS, 0, false), V8(EPI_BIAS, 2, false), V8(EPI_BIAS, 1, true), V8(EPI_BIAS, 0, true), V8(EPI_BIAS, 2, true),
+    V8(EPI_STORE, 0, true), V8(EPI_BIAS_GELU, 0, true), V8(EPI_MUL_COLSUM, 0, true),
 };
 static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 512 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
     const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, tiles = ntn * ntm;
     static const int persist = getenv("GEMM_ONE_TILE_PER_WG") ? 0 : 1;
+    if (v.nt8) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, NT8_LDS_BYTES));
+        hipLaunchKernelGGL(v.kern, dim3(tiles > 256 ? 256 : tiles), dim3(512), NT8_LDS_BYTES, st, p);
+        return;
+    }
     const int slots = occ_of(v) * 256;
     const int lds = nt_lds_bytes(v.bm, v.bn, 2) > 65536 ? nt_lds_bytes(v.bm, v.bn, 2) : 0;
     if (lds) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -107,7 +117,7 @@ static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
 
 // phase timestamps of one variant on one shape: per workgroup start -> first data -> end of K loop -> end
 static void phase_profile(const Variant& v, const NtParams& p) {
-    const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, nwg = ntn * ntm;
+    const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, nwg = v.nt8 ? (ntn * ntm > 256 ? 256 : ntn * ntm) : ntn * ntm;
     long long* d; CK(hipMalloc(&d, (size_t)nwg * 8 * 8)); CK(hipMemset(d, 0, (size_t)nwg * 8 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(cream::gemm::g_gemm_prof), &d, sizeof(d)));
     for (int i = 0; i < 3; ++i) launch(v, p);
@@ -120,6 +130,12 @@ static void phase_profile(const Variant& v, const NtParams& p) {
         a += (double)(t[1] - t[0]); b += (double)(t[2] - t[1]); c += (double)(t[3] - t[2]);
         tmin = t[0] < tmin ? t[0] : tmin; tmax = t[3] > tmax ? t[3] : tmax;
     }
+    if (v.nt8) {
+        double e = 0; tmax = 0;
+        for (int w = 0; w < nwg; ++w) { const long long* t = &h[(size_t)w * 8]; e += (double)(t[4] - t[3]); tmax = t[4] > tmax ? t[4] : tmax; }
+        printf("    phases of %-30s workgroups %d (tiles %d): prologue %.0f, first tile K loop %.0f, its epilogue %.0f, remaining tiles %.0f ticks (mean per workgroup); kernel span %lld ticks (100 MHz)\n",
+               v.name, nwg, ntn * ntm, a / nwg, b / nwg, c / nwg, e / nwg, tmax - tmin);
+    } else
     printf("    phases of %-30s workgroups %d: start->first tile %.0f, K loop %.0f, epilogue %.0f ticks (mean per workgroup); kernel span %lld ticks\n",
            v.name, nwg, a / nwg, b / nwg, c / nwg, tmax - tmin);
     long long* z = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(cream::gemm::g_gemm_prof), &z, sizeof(z)));
@@ -397,9 +413,12 @@ int main(int argc, char** argv)
             CK(hipMemset(dout, 0xFF, no * 2));
             CK(hipMemset(dout2, 0xFF, no * 2));
             CK(hipMemset(dmax, 0, 16));
-            launch(v, p);
-            check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
-            if (v.epi == EPI_MUL_COLSUM || v.epi == EPI_GELUGRAD_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
+            for (int rep = 0; rep < (v.nt8 ? 4 : 1); ++rep) {     // (sync-structure edits are race-screened: every launch is checked)
+                if (rep) { CK(hipMemset(dout, 0xFF, no * 2)); CK(hipMemset(dout2, 0xFF, no * 2)); }
+                launch(v, p);
+                check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
+                if (v.epi == EPI_MUL_COLSUM || v.epi == EPI_GELUGRAD_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
+            }
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
             auto rotated = [&](int i) {
