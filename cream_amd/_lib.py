@@ -90,6 +90,8 @@ SIGNATURES = {
     "cream_linear_dgrad_seg": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i64, _vp]),
     "cream_linear_dgrad_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "cream_linear_wgrad_splits": (_i, [_i, _i, _i]),
+    "cream_linear_wgrad_splits_bf16": (_i, [_i, _i, _i]),
+    "cream_gemm_tn8": (_i, [_i]),
     "cream_linear_dgrad_gelugrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp]),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

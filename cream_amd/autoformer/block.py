@@ -277,15 +277,25 @@ def linear_dgrad_gelugrad(dy, wt, x, w, bias, N, K, Kvalid=None):
     return dh, parts
 
 
+def _wgrad_splits(M, N, K, want_bias, parts_dtype):
+    """token slices of a weight gradient: bf16 partial tiles take the split count of the macro-tile kernel
+    (cream_linear_wgrad_splits_bf16, csrc/gemm_tn8.hpp) — the library picks the kernel by the S it is called with."""
+    lib = _lib.load()
+    if parts_dtype == torch.bfloat16:
+        return lib.cream_linear_wgrad_splits_bf16(M, N, K)
+    return lib.cream_linear_wgrad_splits(M, N, K)
+
+
 def linear_wgrad_parts(dy, x, want_bias=False, out=None, bias_out=None, parts_dtype=torch.float32):
     """-> (parts (S, N, K) fp32 or bf16, bias_parts (S, N) fp32 or None): partial products dy_s^T x_s over S
     slices of the token dimension (S chosen by the library) and, on request, the column sums of dy_s."""
     M, N = dy.shape
     K = x.shape[1]
     lib = _lib.load()
-    S = lib.cream_linear_wgrad_splits(M, N, K)
     if out is None:
+        S = _wgrad_splits(M, N, K, want_bias, parts_dtype)
         out = torch.empty((S, N, K), dtype=parts_dtype, device=dy.device)
+    S = out.shape[0]
     if want_bias and bias_out is None:
         bias_out = torch.empty((S, N), dtype=torch.float32, device=dy.device)
     fn, name = ((lib.cream_linear_wgrad_parts_bf16, "cream_linear_wgrad_parts_bf16") if out.dtype == torch.bfloat16
@@ -320,7 +330,7 @@ def wgrad_parts_async(dy, x, want_bias=False):
     if not WGRAD_SIDE_STREAM:
         return linear_wgrad_parts(dy, x, want_bias, parts_dtype=wgrad_parts_dtype())
     M, N = dy.shape
-    S = _lib.load().cream_linear_wgrad_splits(M, N, x.shape[1])
+    S = _wgrad_splits(M, N, x.shape[1], want_bias, wgrad_parts_dtype())
     out = torch.empty((S, N, x.shape[1]), dtype=wgrad_parts_dtype(), device=dy.device)
     bout = torch.empty((S, N), dtype=torch.float32, device=dy.device) if want_bias else None
     main = torch.cuda.current_stream(dy.device)

@@ -44,10 +44,10 @@ Dims dims_of(const cream_block_desc* d) {
     x.B = d->B; x.N = d->N; x.E = d->E; x.H = d->H; x.F = d->F;
     x.Q = 64 * x.H; x.M = x.B * x.N; x.NP = cream_attn_rpe2d_padded_len(d->N);
     x.slabs = cream_colsum128_slabs((int)x.M); x.P = cream_ln_partials();
-    x.S2 = cream_linear_wgrad_splits((int)x.M, (int)x.E, (int)x.F);
-    x.S1 = cream_linear_wgrad_splits((int)x.M, (int)x.F, (int)x.E);
-    x.Sp = cream_linear_wgrad_splits((int)x.M, (int)x.E, (int)x.Q);
-    x.Sq = cream_linear_wgrad_splits((int)x.M, 3 * (int)x.Q, (int)x.E);
+    x.S2 = cream_linear_wgrad_splits_bf16((int)x.M, (int)x.E, (int)x.F);      // (bf16 partial tiles are the default, cream_block_wgrad_bf16)
+    x.S1 = cream_linear_wgrad_splits_bf16((int)x.M, (int)x.F, (int)x.E);
+    x.Sp = cream_linear_wgrad_splits_bf16((int)x.M, (int)x.E, (int)x.Q);
+    x.Sq = cream_linear_wgrad_splits_bf16((int)x.M, 3 * (int)x.Q, (int)x.E);
     return x;
 }
 bool desc_ok(const cream_block_desc* d) {

@@ -22,6 +22,7 @@
 #include "cream_amd.h"
 #include "gemm_mfma.hpp"
 #include "gemm_nt8.hpp"
+#include "gemm_tn8.hpp"
 #include "launch_ev.hpp"
 
 namespace {
@@ -291,6 +292,60 @@ int cream_linear_dgrad_gelugrad(void* dh, float* colsum_parts, const void* dy, c
     return launch_nt<EPI_GELUGRAD_COLSUM>(p, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+namespace {
+// the weight-gradient product on the macro tile of gemm_tn8.hpp (bf16 partial tiles, no bias partials).
+// CREAM_GEMM_TN8 in the environment / cream_gemm_tn8(): 0 = never, 1 = problems of at least six 256 x 256 tiles (default)
+std::atomic<int> g_tn8{-1};
+int tn8_mode()
+{
+    int m = g_tn8.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_TN8");
+        m = e ? atoi(e) : 2;
+        g_tn8.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+int tn8_tiles(int N, int K) { return ((N + 255) / 256) * ((K + 255) / 256); }
+// one workgroup per CU: as many token slices as fit the chip once
+int tn8_splits(int M, int N, int K)
+{
+    const int T = tn8_tiles(N, K), steps = (M + 63) / 64;
+    static int slots = 0;                                       // CREAM_TN8_SLOTS (measurement switch): workgroups per launch; default HALF the CUs: in the step the
+    // weight gradients share the chip with the main chain and every split is another partial tile through HBM (same-call A/B,
+    // profiles/r05_tn8_step_ab.txt: 256 / 192 / 128 / 96 / 64 slots -> 9.62 / 9.48 / 9.41 / 9.77* / 10.1* ms per step, * another box)
+    if (!slots) { const char* e = getenv("CREAM_TN8_SLOTS"); slots = e && atoi(e) >= 8 ? atoi(e) : num_cus() / 2 / 8 * 8; }
+    int s = slots / T;
+    if (s > steps) s = steps;
+    return s < 1 ? 1 : s;
+}
+bool tn8_wanted(int M, int N, int K)
+{
+    const int mode = tn8_mode();
+    if (mode <= 0 || M <= 0 || N % 8 || K % 8) return false;
+    const int T = tn8_tiles(N, K);
+    if ((int64_t)64 * (N > K ? N : K) * 2 + 4096 >= ((int64_t)1 << 31)) return false;     // 32-bit lane offsets inside a K-tile
+    return mode >= 2 ? T <= num_cus() : (T >= 6 && T <= num_cus());
+}
+}  // namespace
+
+extern "C" {
+
+int cream_gemm_tn8(int mode)
+{
+    const int prev = tn8_mode();
+    if (mode >= 0) g_tn8.store(mode, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_linear_wgrad_splits_bf16(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return tn8_wanted(M, N, K) ? tn8_splits(M, N, K) : cream_linear_wgrad_splits(M, N, K);
+}
+
 int cream_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -335,6 +390,18 @@ int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const vo
     if (M <= 0 || N <= 0 || K <= 0 || S <= 0 || N % 8 || K % 8) return CREAM_ERR_BAD_ARG;
     if (!dy || !x || !aligned16(dy) || !aligned16(x)) return CREAM_ERR_BAD_ARG;
     TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts, parts16};
+    if (parts16 && tn8_wanted(M, N, K) && S == tn8_splits(M, N, K)) {
+        if (bias_parts) {
+            auto kern = gemm_tn8_kernel<0, true>;
+            if (!raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+            CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
+        } else {
+            auto kern = gemm_tn8_kernel<0, false>;
+            if (!raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+            CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+    }
     const int grid = ((N + 127) / 128) * ((K + 127) / 128) * S;
     // the bias-free instantiation has no bias accumulators (126 instead of 165 VGPRs: room for two more waves of the main chain's
     // kernels per SIMD next to two of these — measured neutral on the step, 10.76 vs 10.75 ms in a same-box A/B x3: the two

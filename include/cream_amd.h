@@ -408,6 +408,14 @@ int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, co
  * copy (Linear_super.py:71-81 under autocast); the bias partials stay fp32. */
 int cream_linear_wgrad_parts_bf16(void* parts_bf16, float* bias_parts, const void* dy, const void* x, int M, int N,
                                   int K, int S, void* stream);
+/* The split count for a weight gradient with bf16 partial tiles (Linear_super.py:71-81, qkv_super.py:72-83 backward).
+ * cream_linear_wgrad_parts_bf16 called with THIS split count runs the macro-tile kernel of csrc/gemm_tn8.hpp (256 x 256 tile on
+ * the phase-interleaved loop, one 8-wave workgroup per CU, token slices for half the CUs — the weight gradients share the chip
+ * with the main chain and every slice is another partial tile through HBM); bias partials ride along.  With any other S, or with
+ * fp32 partials (cream_linear_wgrad_parts), the 128 x 128 kernel runs.  Same partial-tile layout and rounding either way.
+ * cream_gemm_tn8(0 | 1 | 2): never / problems of at least six 256 x 256 tiles / every problem (default); < 0 queries. */
+int cream_linear_wgrad_splits_bf16(int M, int N, int K);
+int cream_gemm_tn8(int mode);
 
 /* ---- parameter update + operand copies ------------------------------------------------------
  * torch.optim.AdamW as created by timm's create_optimizer (AutoFormer/supernet_train.py:294-296;

@@ -14,10 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #define GEMM_PROFILE 1
 #include "gemm_mfma.hpp"
 #include "gemm_nt8.hpp"
+#include "gemm_tn8.hpp"
 
 using namespace cream;
 using namespace cream::gemm;
@@ -217,6 +219,37 @@ __global__ void check_tn(float* maxerr, const float* ref, const float* bref, TnP
         atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
     }
 }
+// every bf16 partial tile against the fp32 sum over ITS token range: |got - want| <= bf16 rounding of want (+ accumulation-order noise)
+__global__ void check_tn16(float* maxerr, const float* ref, TnParams p) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.N * p.K) return;
+    const int n = (int)(i / p.K), k = (int)(i % p.K);
+    const int tsteps = (p.M + 63) / 64;
+    float worst = 0.f, total = 0.f;
+    for (int q = 0; q < p.S; ++q) {
+        const int lo = (int)((int64_t)tsteps * q / p.S) * 64, hi = min(p.M, (int)((int64_t)tsteps * (q + 1) / p.S) * 64);
+        float want = 0.f;
+        for (int m = lo; m < hi; ++m) want += bfv(p.dY[(int64_t)m * p.ldy + n]) * bfv(p.X[(int64_t)m * p.ldx + k]);
+        const float got = bfv(p.parts16[(int64_t)q * p.N * p.K + i]);
+        const float err = fabsf(got - want) / (fabsf(want) * (1.f / 128.f) + 1e-3f);     // 1.0 = one bf16 ulp-ish
+        worst = fmaxf(worst, err == err ? err : 1e30f);
+        total += got;
+    }
+    (void)total; (void)ref;
+    atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(worst));
+}
+__global__ void check_bias8(float* maxerr, const float* bref, TnParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    float b = 0.f;
+    for (int q = 0; q < p.S; ++q) b += p.bias_parts[(int64_t)q * p.N + i];
+    const float err = fabsf(b - bref[i]) / (1.f + fabsf(bref[i]));
+    atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
+}
+static int tn8_splits(int M, int N, int K) {
+    const int T = ((N + 255) / 256) * ((K + 255) / 256), steps = (M + 63) / 64;
+    int s = 256 / T; if (s > steps) s = steps; return s < 1 ? 1 : s;
+}
 static void tn_tests(const char* only) {
     struct T { int M, N, K, S; const char* what; };
     const T ts[] = {{394, 200, 136, 3, "wgrad ragged (M tail, N/K edges)"}, {25216, 1152, 384, 16, "wgrad qkv  E384 H6"},
@@ -224,7 +257,8 @@ static void tn_tests(const char* only) {
                     {25216, 1344, 384, 8, "wgrad fc1  E384 R3.5"}, {25216, 1152, 384, 8, "wgrad qkv  E384 H6"},
                     {25216, 384, 1344, 16, "wgrad fc2  E384 R3.5"}, {25216, 1792, 448, 8, "wgrad fc1  E448 R4"},
                     {25216, 1792, 448, 16, "wgrad fc1  E448 R4"}, {25216, 320, 320, 32, "wgrad proj E320"},
-                    {25216, 320, 320, 64, "wgrad proj E320"}};
+                    {25216, 320, 320, 64, "wgrad proj E320"}, {25216, 448, 1792, 16, "wgrad fc2  E448 R4"},
+                    {25216, 960, 320, 16, "wgrad fc1  E320 R3"}, {25216, 1344, 448, 16, "wgrad qkv  E448 H7"}, {1000, 328, 264, 4, "wgrad ragged 2 (partial blocks)"}};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float* dmax; CK(hipMalloc(&dmax, 16));
     for (const T& t : ts) {
@@ -256,8 +290,7 @@ static void tn_tests(const char* only) {
         CK(hipMemset(dparts, 0xFF, nw * 4 * t.S)); CK(hipMemset(dbias, 0xFF, (size_t)t.N * 4 * t.S)); CK(hipMemset(dmax, 0, 16));
         const int grid = ((t.N + 127) / 128) * ((t.K + 127) / 128) * t.S;
         struct TV { const char* name; void (*k)(const TnParams); };
-        const TV tvs[] = {{"64 tok x 2 stages occ2", gemm_tn_kernel<2, 64, 2>}, {"32 tok x 4 stages occ2", gemm_tn_kernel<2, 32, 4>},
-                          {"32 tok x 3 stages occ3", gemm_tn_kernel<3, 32, 3>}, {"32 tok x 2 stages occ3", gemm_tn_kernel<3, 32, 2>}};
+        const TV tvs[] = {{"64 tok x 2 stages occ2", gemm_tn_kernel<2, 64, 2>}};
         for (const TV& tv : tvs) {
             CK(hipMemset(dparts, 0xFF, nw * 4 * t.S)); CK(hipMemset(dbias, 0xFF, (size_t)t.N * 4 * t.S)); CK(hipMemset(dmax, 0, 16));
             hipLaunchKernelGGL(tv.k, dim3(grid), dim3(256), 0, 0, p);
@@ -272,6 +305,37 @@ static void tn_tests(const char* only) {
             printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  %-24s %7.1f us %6.0f TF/s  err dW %.2e bias %.2e %s%s\n", t.what, t.M, t.N, t.K, t.S, grid,
                    tv.name, us, fl / us / 1e6, hm[0], hm[1], (hm[0] > 1e-3f || hm[1] > 1e-3f) ? " <-- WRONG" : "", cold ? " [cold]" : "");
         }
+        // round 5: the macro tile on the phase-interleaved loop (gemm_tn8.hpp), bf16 partial tiles, its own split count
+        float* dbias8; CK(hipMalloc(&dbias8, (size_t)t.N * 4 * 512));
+        for (int prio = 0; prio < 2; ++prio)                          // (prio 1 = the instantiation with bias partials)
+        for (int sdiv = 1; sdiv <= 2; sdiv *= 2) {
+            const int S8 = std::max(1, tn8_splits(t.M, t.N, t.K) / sdiv);
+            uint16_t* d16; CK(hipMalloc(&d16, nw * 2 * S8));
+            TnParams q8{dy, dx, t.N, t.K, t.M, t.N, t.K, S8, nullptr, prio ? dbias8 : nullptr, d16};
+            auto k8 = prio ? gemm_tn8_kernel<0, true> : gemm_tn8_kernel<0, false>;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, TN8_LDS_BYTES));
+            const int T8 = ((t.N + 255) / 256) * ((t.K + 255) / 256), grid8 = T8 * S8;
+            float hm[4] = {0, 0, 0, 0};
+            for (int rep = 0; rep < 3; ++rep) {                       // race screen: every launch is checked
+                CK(hipMemset(d16, 0xFF, nw * 2 * S8)); CK(hipMemset(dmax, 0, 16));
+                if (prio) CK(hipMemset(dbias8, 0xFF, (size_t)t.N * 4 * S8));
+                hipLaunchKernelGGL(k8, dim3(grid8), dim3(512), TN8_LDS_BYTES, 0, q8);
+                check_tn16<<<(unsigned)((nw + 255) / 256), 256>>>(dmax, dref, q8);
+                if (prio) check_bias8<<<(t.N + 255) / 256, 256>>>(dmax, dbref, q8);
+                float h1[4]; CK(hipMemcpy(h1, dmax, 16, hipMemcpyDeviceToHost));
+                hm[0] = std::max(hm[0], h1[0]); hm[1] = std::max(hm[1], h1[1]);
+            }
+            auto rot8 = [&](int i) { TnParams q = q8; q.dY = ry[i % R]; q.X = rxx[i % R]; return q; };
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k8, dim3(grid8), dim3(512), TN8_LDS_BYTES, 0, rot8(i));
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k8, dim3(grid8), dim3(512), TN8_LDS_BYTES, 0, rot8(i + 3));
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            const double us = ms(e0, e1) / 20 * 1e3, fl = 2.0 * t.M * t.N * t.K;
+            printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  tn8 256x256 bias%d bf16 parts   %7.1f us %6.0f TF/s  worst partial error %.2f bf16 ulp, bias err %.1e %s%s\n", t.what, t.M, t.N, t.K, S8, grid8,
+                   prio, us, fl / us / 1e6, hm[0], hm[1], (hm[0] > 1.0f || hm[1] > 1e-3f) ? " <-- WRONG" : "", cold ? " [cold]" : "");
+            hipFree(d16);
+        }
+        hipFree(dbias8);
         for (int r = 1; r < R; ++r) { hipFree(ry[r]); hipFree(rxx[r]); }
         hipFree(dy); hipFree(dx); hipFree(dparts); hipFree(dbias); hipFree(dref); hipFree(dbref);
     }
