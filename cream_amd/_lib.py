@@ -53,7 +53,6 @@ SIGNATURES = {
     "cream_attn_rpe2d_padded_len": (_i, [_i]),
     "cream_attn_rpe2d_dtab_parts": (_i, [_i, _i]),
     "cream_attn_rpe2d_bwd_mode": (_i, [_i]),
-    "cream_attn_rpe2d_fwd_mode": (_i, [_i]),
     "cream_attn_rpe2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i,
                                   _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cream_attn_rpe2d_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
@@ -69,11 +68,7 @@ SIGNATURES = {
     "cream_colsum_slabs": (_i, [_i]),
     "cream_colsum": (_i, [_vp, _vp, _i, _i, _vp]),
     "cream_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
-    "cream_block_fuse_ln": (_i, [_i]),
     "cream_block_wgrad_bf16": (_i, [_i]),
-    "cream_block_gelu_recompute": (_i, [_i]),
-    "cream_linear_add_ln_supported": (_i, [_i, _i]),
-    "cream_linear_add_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _f, _vp]),
     "cream_colsum128_slabs": (_i, [_i]),
     "cream_colsum128": (_i, [_vp, _vp, _i, _i, _vp]),
     "cream_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -92,16 +87,11 @@ SIGNATURES = {
     "cream_linear_wgrad_splits": (_i, [_i, _i, _i]),
     "cream_linear_wgrad_splits_bf16": (_i, [_i, _i, _i]),
     "cream_gemm_tn8": (_i, [_i]),
-    "cream_linear_dgrad_gelugrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp]),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),
     "cream_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _i64, _vp]),
     "cream_soft_ce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
-    "cream_wgrad_group_slots": (_i, []),
-    "cream_wgrad_group_workspace": (_i64, []),
-    "cream_wgrad_group_max_tiles": (_i, []),
-    "cream_wgrad_group": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cream_linear_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i, _i, _vp]),
     "cream_bmm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_linear_f32_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
@@ -168,14 +158,7 @@ class BlockGrads(ctypes.Structure):
     """struct cream_block_grads of include/cream_amd.h."""
     _fields_ = ([(n, _vp) for n in ("wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "w2", "b2", "ln1_g", "ln1_b", "ln2_g",
                                     "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
-                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2", "ldt")] +
-                [("wgrad_slabs", _vp), ("wgrad_counters", _vp)])
-
-
-class WgradProblem(ctypes.Structure):
-    """struct cream_wgrad_problem of include/cream_amd.h."""
-    _fields_ = [("dy", _vp), ("x", _vp), ("ldy", _i64), ("ldx", _i64), ("dw", _vp), ("ld_dw", _i64), ("dbias", _vp),
-                ("N", _c.c_int32), ("K", _c.c_int32), ("interleave", _c.c_int32), ("reserved", _c.c_int32)]
+                [(n, _i64) for n in ("ld_qkv", "ld_proj", "ld_w1", "ld_w2", "ldt")])
 
 
 _lib = None
@@ -205,8 +188,6 @@ def load():
             raise CreamLibraryError(f"cream_amd: symbol {name} missing from {LIB_PATH}") from e
         fn.restype = res
         fn.argtypes = args
-    # process-wide switches of the native block driver (csrc/block_seq.cpp)
-    lib.cream_block_fuse_ln(int(os.environ.get("CREAM_FUSE_LN", "0") != "0"))
     _lib = lib
     return lib
 

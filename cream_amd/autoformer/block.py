@@ -67,25 +67,6 @@ def add_ln_fwd(x2d, res, sample_scale, rows_per_sample, gamma, beta, eps):
     return x1, y, mean, rstd
 
 
-def linear_add_ln_supported(E, K):
-    return bool(_lib.load().cream_linear_add_ln_supported(int(E), int(K)))
-
-
-def linear_add_ln_fwd(a, w, bias, x2d, sample_scale, rows_per_sample, gamma, beta, eps, K):
-    """x1 = x + s_b * bf16(a . W[:E, :K]^T + bias), y = LN(x1): projection, residual add and the next LayerNorm
-    in ONE kernel (csrc/gemm_ln.hip); the same bits as linear_fwd + add_ln_fwd.  -> (x1, y, mean, rstd)"""
-    M, E = x2d.shape
-    x1 = torch.empty_like(x2d)
-    y = torch.empty((M, E), dtype=torch.bfloat16, device=x2d.device)
-    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
-    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
-    with timing.region("gemm_nt_add_ln", flops=2 * M * E * K, nbytes=M * E * (4 + 4 + 2) + M * K * 2):
-        _lib.check(_lib.load().cream_linear_add_ln_fwd(_p(x1), _p(y), _p(mean), _p(rstd), _p(a), _p(w), _p(bias), _p(x2d),
-                                                      _p(sample_scale), rows_per_sample, _p(gamma), _p(beta), M, E, K,
-                                                      w.stride(0), float(eps), _stream()), "cream_linear_add_ln_fwd")
-    return x1, y, mean, rstd
-
-
 def ln_bwd_raw(dy, x2d, mean, rstd, gamma, dres, sample_scale, rows_per_sample, want_scaled):
     """-> (dx, dx_scaled or None, partial (P, 3, E): per-slab [dgamma, dbeta, colsum(dx_scaled)])"""
     M, E = x2d.shape
@@ -256,27 +237,6 @@ def wgrad_parts_dtype():
     return torch.bfloat16 if _lib.load().cream_block_wgrad_bf16(-1) else torch.float32
 
 
-def gelu_recompute(E):
-    """True when the library recomputes gelu'(h) inside the fc2 dgrad for this embed dim (cream_block_gelu_recompute;
-    E % 64 == 0): the forward then stores gelu(h) only."""
-    return bool(_lib.load().cream_block_gelu_recompute(-1)) and E % 64 == 0
-
-
-def linear_dgrad_gelugrad(dy, wt, x, w, bias, N, K, Kvalid=None):
-    """dh (M, K) = (dy (M, N) . W2[:N, :K]) * gelu'(float(h)), h = bf16(x (M, N) . W1[:K, :N]^T + bias[:K]), and the
-    per-slab column sums of dh (fc1 bias partials): the fc2 dgrad with the GELU derivative recomputed from the saved
-    LayerNorm output x instead of read from HBM.  wt: the transposed fc2 operand (K rows, ld); w: the fc1 operand."""
-    M = dy.shape[0]
-    lib = _lib.load()
-    dh = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
-    parts = torch.empty((lib.cream_colsum128_slabs(M), K), dtype=torch.float32, device=dy.device)
-    with timing.region("gemm_nt_mul", flops=4 * M * N * K):
-        _lib.check(lib.cream_linear_dgrad_gelugrad(_p(dh), _p(parts), _p(dy), _p(wt), _p(x), _p(w), _p(bias), M, N, K,
-                                                   K if Kvalid is None else Kvalid, wt.stride(0), w.stride(0), _stream()),
-                   "cream_linear_dgrad_gelugrad")
-    return dh, parts
-
-
 def _wgrad_splits(M, N, K, want_bias, parts_dtype):
     """token slices of a weight gradient: bf16 partial tiles take the split count of the macro-tile kernel
     (cream_linear_wgrad_splits_bf16, csrc/gemm_tn8.hpp) — the library picks the kernel by the S it is called with."""
@@ -341,64 +301,17 @@ def wgrad_parts_async(dy, x, want_bias=False):
     return out, bout
 
 
-# Weight gradients of a block: False (default) = one split-K launch per projection + cream_grad_finalize; True = ONE
-# stream-K launch with the reduction in the kernel (cream_wgrad_group).  Same-box A/B of the S supernet step, twice:
-# 10.92 ms (False) vs 11.58 ms (True) although the grouped launch needs 25 % less side-stream time standalone — its
-# workgroups live ~200 us and hold half of every SIMD's registers, which costs the main chain more.
-WGRAD_GROUPED = False
-_wgrad_ws = {}
-
-
-def wgrad_workspace(device):
-    """(slabs, counters) of cream_wgrad_group for `device`: one allocation per device for the life of the process —
-    the grouped launches of all blocks are ordered on the side stream (or the main stream without it), and every launch
-    leaves the counters zero."""
-    ent = _wgrad_ws.get(device)
-    if ent is None:
-        lib = _lib.load()
-        with torch.cuda.device(device):
-            slabs = torch.empty(lib.cream_wgrad_group_workspace(), dtype=torch.uint8, device=device)
-            counters = torch.zeros(lib.cream_wgrad_group_max_tiles(), dtype=torch.int32, device=device)
-        ent = _wgrad_ws[device] = (slabs, counters)
-    return ent
-
-
-def wgrad_group(problems):
-    """All weight gradients of a block in ONE launch on the current stream (cream_wgrad_group): `problems` = list of
-    (dy (M, N) bf16, x (M, K) bf16, weight parameter, bias parameter or None, interleave) — adds dy^T x into the active
-    slice of weight.grad (rows through the qkv interleave) and the column sums of dy into bias.grad[:N]."""
-    lib = _lib.load()
-    dev = problems[0][0].device
-    slabs, counters = wgrad_workspace(dev)
-    arr = (_lib.WgradProblem * len(problems))()
-    M = problems[0][0].shape[0]
-    flops = 0
-    for q, (dy, x, w, b, inter) in zip(arr, problems):
-        gw = _ensure_grad(w)
-        q.dy, q.x, q.ldy, q.ldx = dy.data_ptr(), x.data_ptr(), dy.stride(0), x.stride(0)
-        q.dw, q.ld_dw = gw.data_ptr(), gw.stride(0)
-        q.dbias = _ensure_grad(b).data_ptr() if b is not None else 0
-        q.N, q.K, q.interleave = dy.shape[1], x.shape[1], inter
-        flops += 2 * M * dy.shape[1] * x.shape[1]
-    with timing.region("gemm_tn_wgrad", flops=flops):
-        _lib.check(lib.cream_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(problems), M, _p(slabs), _p(counters), _stream()),
-                   "cream_wgrad_group")
-
-
 def join_side_stream(device):
     if WGRAD_SIDE_STREAM:
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def finalize_on_side_stream(jobs, blk, tensors, wgrads=None):
-    """The block's weight gradients (`wgrads`: ONE grouped launch, see wgrad_group), the finalisation of its small
-    gradients and the announcement of its gradients to the reducer, on the side stream: the main stream goes straight
-    on to the previous block.  `tensors`: everything the side stream reads — they were allocated on the main stream, so
-    the allocator is told not to recycle them before the side stream is done."""
+def finalize_on_side_stream(jobs, blk, tensors):
+    """The finalisation of the block's gradients and their announcement to the reducer, on the side stream: the main
+    stream goes straight on to the previous block.  `tensors`: everything the side stream reads — they were allocated on
+    the main stream, so the allocator is told not to recycle them before the side stream is done."""
     dev = tensors[0].device
     if not WGRAD_SIDE_STREAM:
-        if wgrads:
-            wgrad_group(wgrads)
         jobs.launch()
         _notify(blk)
         return
@@ -406,8 +319,6 @@ def finalize_on_side_stream(jobs, blk, tensors, wgrads=None):
     side = _side_stream(dev)
     side.wait_event(main.record_event())
     with torch.cuda.stream(side):
-        if wgrads:
-            wgrad_group(wgrads)
         jobs.launch()
         _notify(blk)
     for t in tensors:
@@ -1031,7 +942,7 @@ def _block_forward(blk, x2d, pend, dp1, B, N):
     o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
     p = linear_fwd(o.view(M, Q), wproj, bproj, E, Q)
     x1, c, mean2, rstd2 = add_ln_fwd(x, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
-    h, g = linear_gelu_fwd(c, w1, b1, F_, E, want_grad=not gelu_recompute(E))      # h = gelu'(pre-activation) or None
+    h, g = linear_gelu_fwd(c, w1, b1, F_, E)                 # h = gelu'(pre-activation), g = gelu(pre-activation)
     f = linear_fwd(g, w2, b2, E, F_)
     dims = (B, N, E, H, Q, F_, mr, float(at.sample_scale))
     return x1, f, dims, (x, mean1, rstd1, a, qkv, o, lse, sp, x1, mean2, rstd2, c, h, g)
@@ -1053,22 +964,17 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
 
     jobs = GradJobs()
     # ---- MLP branch -----------------------------------------------------------------------
-    grouped = WGRAD_GROUPED
+    # every weight gradient as soon as its operands exist, on the side stream (token-sliced partial tiles, added by the
+    # finalisation at the end of the block)
     extra = []
-    if not grouped:
-        pw2, _ = wgrad_parts_async(df, g)
-        jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
-        extra.append(pw2)
+    pw2, _ = wgrad_parts_async(df, g)
+    jobs.add(blk.fc2.weight, pw2, pw2.shape[0], E * F_, E, F_)
+    extra.append(pw2)
     jobs.add(blk.fc2.bias, pb2[0], pb2[1], pb2[2], 1, E, src_offset=pb2[3])
-    if h is None:                                            # gelu'(h) recomputed in the kernel from c and the fc1 operand
-        ops_ = operands(blk)
-        dh, pb1 = linear_dgrad_gelugrad(df, w2_t, c, ops_.w[2], ops_.b[2], E, F_)
-    else:
-        dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)       # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
-    if not grouped:
-        pw1, _ = wgrad_parts_async(dh, c)
-        jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
-        extra.append(pw1)
+    dh, pb1 = linear_dgrad_mul(df, w2_t, h, E, F_)           # (df . W2) * gelu'(h) (h holds the saved derivative) + fc1 bias partials
+    pw1, _ = wgrad_parts_async(dh, c)
+    jobs.add(blk.fc1.weight, pw1, pw1.shape[0], F_ * E, F_, E)
+    extra.append(pw1)
     jobs.add(blk.fc1.bias, pb1, pb1.shape[0], F_, 1, F_)
     dc = linear_dgrad(dh, w1_t, F_, E)
     # dx1 = dx2 + dLN2(dc); dp = s1 * dx1 is the gradient of the proj output, and its column sums
@@ -1080,10 +986,9 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     jobs.add(at.proj.bias, pl2, P, 3 * E, 1, E, src_offset=2 * E)
 
     # ---- attention branch ---------------------------------------------------------------------
-    if not grouped:
-        pwp, _ = wgrad_parts_async(dp, o.view(M, Q))
-        jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
-        extra.append(pwp)
+    pwp, _ = wgrad_parts_async(dp, o.view(M, Q))
+    jobs.add(at.proj.weight, pwp, pwp.shape[0], E * Q, E, Q)
+    extra.append(pwp)
     do = linear_dgrad(dp, wproj_t, E, Q)
     tabs_p = _tables(at)
     dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
@@ -1093,19 +998,15 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     for i, t in enumerate(tabs_p):                                     # dtab (workgroup partials, 4, 32, 64)
         jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
     dqkv2d = dqkv.view(M, 3 * Q)
-    if not grouped:
-        pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)              # rows [q | k | v]; bias rides along
-        jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
-        jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
-        extra += [pwq, pbq]
+    pwq, pbq = wgrad_parts_async(dqkv2d, a, want_bias=True)                  # rows [q | k | v]; bias rides along
+    jobs.add(at.qkv.weight, pwq, pwq.shape[0], 3 * Q * E, 3 * Q, E, interleave=Q)
+    jobs.add(at.qkv.bias, pbq, pbq.shape[0], 3 * Q, 1, 3 * Q)
+    extra += [pwq, pbq]
     da = linear_dgrad_seg(dqkv2d, wqkv_t, 3 * Q, E, Q)
     dx, df_prev, pl1 = ln_bwd_raw(da, x, mean1, rstd1, ln1.weight[:E], dx1, prev_scale, N, want_prev)
     jobs.add(ln1.weight, pl1, P, 3 * E, 1, E)
     jobs.add(ln1.bias, pl1, P, 3 * E, 1, E, src_offset=E)
-    # grouped mode: the four weight gradients (+ the qkv bias gradient: column sums of dqkv, rows [q | k | v]) in one launch
-    wgrads = [(df, g, blk.fc2.weight, None, 0), (dh, c, blk.fc1.weight, None, 0), (dp, o.view(M, Q), at.proj.weight, None, 0),
-              (dqkv2d, a, at.qkv.weight, at.qkv.bias, Q)] if grouped else None
-    finalize_on_side_stream(jobs, blk, [df, g, pb2[0], dh, c, pb1, pl2, dp, o, dtab, dqkv, a, pl1] + extra, wgrads)
+    finalize_on_side_stream(jobs, blk, [df, g, pb2[0], dh, c, pb1, pl2, dp, o, dtab, dqkv, a, pl1] + extra)
     return dx, df_prev, (pl1, P, 3 * E, 2 * E)
 
 
@@ -1175,7 +1076,7 @@ def _block_grads(blk):
     at = blk.attn
     ln1, ln2 = blk.attn_layer_norm, blk.ffn_layer_norm
     ent = blk.__dict__.get(_GRADS_KEY)
-    if ent is not None and ent[2] == WGRAD_GROUPED and all(p.grad is g for p, g in ent[1]):
+    if ent is not None and all(p.grad is g for p, g in ent[1]):
         return ent[0]
     params = _block_params(blk) + (ln1.weight, ln1.bias, ln2.weight, ln2.bias) + _tables(at)
     gr = [_ensure_grad(p) for p in params]
@@ -1185,10 +1086,7 @@ def _block_grads(blk):
     g.ln1_g, g.ln1_b, g.ln2_g, g.ln2_b = (t.data_ptr() for t in gr[8:12])
     g.tkv, g.tkh, g.tvv, g.tvh = (t.data_ptr() for t in gr[12:16])
     g.ldt = gr[12].stride(0)
-    if WGRAD_GROUPED:                          # (NULL pointers = split-K launches + cream_grad_finalize)
-        slabs, counters = wgrad_workspace(gr[0].device)
-        g.wgrad_slabs, g.wgrad_counters = slabs.data_ptr(), counters.data_ptr()
-    blk.__dict__[_GRADS_KEY] = (g, list(zip(params, gr)), WGRAD_GROUPED)
+    blk.__dict__[_GRADS_KEY] = (g, list(zip(params, gr)))
     return g
 
 

@@ -94,6 +94,17 @@ class GradReducer:
         assert mode in ("allreduce", "rs_ag")
         self.mode = mode
         self.slice_of = slice_of              # None: always send whole buckets
+        # slice_of(name, param, config, layout) -> (rows, cols) written by the step; a callable of the earlier three-argument
+        # form (name, param, config) keeps working
+        self._slice_nargs = 4
+        if slice_of is not None:
+            try:
+                import inspect
+                params = inspect.signature(slice_of).parameters.values()
+                if not any(q.kind == q.VAR_POSITIONAL for q in params):
+                    self._slice_nargs = min(4, sum(q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) for q in params))
+            except (TypeError, ValueError):
+                pass
         self.layout = attention_layout(model)  # change_qkv / super_embed_dim per block, from the modules themselves
         self.stage = None                     # staging arena of the packed messages (allocated on first use)
         self._slice_tables = {}
@@ -235,7 +246,10 @@ class GradReducer:
     def _slice_plan(self, b, config):
         """-> (message view into the staging arena, pack / unpack plan) of bucket b for this configuration; cached per
         (bucket, slice signature) — the S search space has 27 signatures per block."""
-        sig = tuple(self.slice_of(n, p, config, self.layout) for n, p in self.members[b])
+        if self._slice_nargs >= 4:
+            sig = tuple(self.slice_of(n, p, config, self.layout) for n, p in self.members[b])
+        else:
+            sig = tuple(self.slice_of(n, p, config) for n, p in self.members[b])
         key = (b, sig)
         plan = self._slice_tables.get(key)
         if plan is None:

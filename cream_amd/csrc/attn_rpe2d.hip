@@ -901,13 +901,7 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     const int waves = a.NP / 32 < 4 ? 4 : a.NP / 32;
     const size_t lds = fwd_lds_bytes<T>(a.NP, waves, FAST);
     auto kern = attn_rpe2d_fwd_kernel<T, NT, FAST>;
-    static bool attr_done = false;           // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!cream::raise_dynamic_lds(kern, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
     FwdArgs aa = a;
     aa.nitems = B * a.H;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
@@ -916,47 +910,9 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
 }
 
 #include "attn_rpe2d_bwd1.hpp"
-#include "attn_rpe2d_fwd1.hpp"
-
-// 1: the DMA-staged forward (attn_rpe2d_fwd1.hpp) for the AutoFormer geometry in bf16; 0: attn_rpe2d_fwd14_kernel.
-// CREAM_ATTN_FWD1 in the environment sets the initial value; cream_attn_rpe2d_fwd_mode() switches it (A/B runs).
-std::atomic<int> g_fwd_dma{-1};
-int fwd_dma_mode() {
-    int m = g_fwd_dma.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char* e = getenv("CREAM_ATTN_FWD1");
-        // default OFF: bit-identical results, 47.4 us against 42.2 us at B = 128, H = 6 (profiles/r04_attn_fwd1.md: the two
-        // barrier phases of an item are set by the 2 + 2 + 2 + 1 split of the seven waves over the four SIMDs, not by the
-        // memory round trips the DMA removes)
-        m = e ? (atoi(e) != 0) : 0;
-        g_fwd_dma.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
-
-int launch_fwd1(const FwdArgs& a, int B, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v2::attn_rpe2d_fwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
-    FwdArgs aa = a;
-    aa.nitems = B * a.H;
-    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    CREAM_LAUNCH(v2::attn_rpe2d_fwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::FWD1_LDS_B, st, aa);
-    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
-}
 
 int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rpe2d_fwd14_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!cream::raise_dynamic_lds(attn_rpe2d_fwd14_kernel, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
     FwdArgs aa = a;
     aa.nitems = B * a.H;
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
@@ -972,7 +928,7 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
         // (the tile-streamed kernel's own FAST instantiation, launch_fwd_nt<T, 7, true>: 46.5 us against 40.6 us at B = 128, H = 6;
         //  10.56 vs 10.48 ms per step in a same-box A/B x3)
-        if (fast_geometry(a.G)) return fwd_dma_mode() ? launch_fwd1(a, B, st) : launch_fwd14(a, B, st);
+        if (fast_geometry(a.G)) return launch_fwd14(a, B, st);
     }
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);
@@ -1451,15 +1407,7 @@ template <typename T, bool FAST>
 int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
     auto kq = attn_rpe2d_bwd_q_kernel<T, FAST>;
     auto kkv = attn_rpe2d_bwd_kv_kernel<T>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!cream::raise_dynamic_lds(kq, 160 * 1024) || !cream::raise_dynamic_lds(kkv, 160 * 1024)) return CREAM_ERR_LAUNCH;
     BwdArgs aa = a;
     aa.nitems = B * a.H;
     const int pgrid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
@@ -1489,20 +1437,10 @@ int bwd_onepass_mode() {
 // the side buffer `dlt` of the two-launch path (B*H*64*NP elements, far more than the 32 KB needed) carries the bf16
 // operand images of the four tables
 int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v2::attn_rpe2d_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CREAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!cream::raise_dynamic_lds(v2::attn_rpe2d_bwd1_kernel, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
     BwdArgs aa = a;
     aa.nitems = B * a.H;
-    {
-        static int stagger = -1;                     // CREAM_ATTN_BWD1_STAGGER (x 64 cycles per group); default below
-        if (stagger < 0) { const char* e = getenv("CREAM_ATTN_BWD1_STAGGER"); stagger = e ? atoi(e) : 0; }
-        aa.stagger = aa.nitems > fwd_persistent_grid() ? stagger : 0;      // (a single round of items: nothing to de-phase)
-    }
+    aa.stagger = 0;                                  // (de-phasing the workgroups' first items was measured: no gain, profiles/r04_attn_bwd1.md)
     short* img = reinterpret_cast<short*>(a.dlt);
     hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, img, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
     if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
@@ -1537,13 +1475,6 @@ int cream_attn_rpe2d_bwd_mode(int onepass)
 {
     const int prev = bwd_onepass_mode();
     if (onepass >= 0) g_bwd_onepass.store(onepass != 0, std::memory_order_relaxed);
-    return prev;
-}
-
-int cream_attn_rpe2d_fwd_mode(int dma)
-{
-    const int prev = fwd_dma_mode();
-    if (dma >= 0) g_fwd_dma.store(dma != 0, std::memory_order_relaxed);
     return prev;
 }
 

@@ -591,14 +591,8 @@ extern "C" {
 
 int cream_ln_partials(void)
 {
-    // workgroups (= partial rows) of the LayerNorm backward.  CREAM_LN_PARTIALS (measurement switch, 256 .. 1024, a multiple of 64)
-    static int n = 0;
-    if (!n) {
-        const char* e = getenv("CREAM_LN_PARTIALS");
-        const int v = e ? atoi(e) : 0;
-        n = (v >= 256 && v <= 1024 && v % 64 == 0) ? v : 1024;
-    }
-    return n;
+    // workgroups (= partial rows) of the LayerNorm backward (256 .. 1024 measured in the step: 1024 stays)
+    return 1024;
 }
 
 int cream_ln_fwd(void* y, float* mean, float* rstd, const float* x, const float* gamma, const float* beta,

@@ -122,13 +122,10 @@ int g_ev_n[MAX_DEV] = {}, g_ev_next[MAX_DEV] = {};
 namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }
 namespace {
 
-// 1: the events that order the side stream behind dgrad_mul / the LayerNorm backwards / the attention backward ride on
-// those kernels' own dispatch packets (launch_ev.hpp); 0: an event record (a marker packet) behind each.  CREAM_FORK_ON_KERNEL.
-int fork_on_kernel_mode() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("CREAM_FORK_ON_KERNEL"); m = e ? (atoi(e) != 0) : 1; }
-    return m;
-}
+// The events that order the side stream behind dgrad_mul / the LayerNorm backwards / the attention backward ride on those
+// kernels' own dispatch packets (launch_ev.hpp) instead of an event record (a marker packet) behind each:
+// 9.456 -> 9.407 ms per step (profiles/r04_step_gaps.md).
+int fork_on_kernel_mode() { return 1; }
 
 hipEvent_t next_fork_event(int dev);
 bool prof_active();
@@ -172,12 +169,9 @@ hipEvent_t next_fork_event(int dev) {
         // Events WITHOUT the system-scope fence: both streams run on this device, the kernels' own agent-scope release /
         // acquire orders their data; the default system-scope release made every record on the main chain cost 4.1 us of
         // step time, 2.7 us without it (CREAM_EXTRA_RECORDS experiment: 64 records per step; same-box A/B x2: 9.99 ->
-        // 9.85 ms per step, profiles/r04_step_gaps.md).  CREAM_EVENT_FLAGS=0 restores plain no-timing events,
-        // 2 = hipEventReleaseToDevice (measured: no different from 0).  Ordering by stream memory operations
-        // (hipStreamWriteValue32 / WaitValue32 on signal memory) was measured too: 11.29 against 9.35 ms.
-        static int fl = -1;
-        if (fl < 0) { const char* e = getenv("CREAM_EVENT_FLAGS"); fl = e ? atoi(e) : 1; }
-        const unsigned flags = hipEventDisableTiming | (fl == 1 ? hipEventDisableSystemFence : fl == 2 ? hipEventReleaseToDevice : 0u);
+        // 9.85 ms per step, profiles/r04_step_gaps.md; hipEventReleaseToDevice: no different from plain events).  Ordering by
+        // stream memory operations (hipStreamWriteValue32 / WaitValue32 on signal memory) was measured too: 11.29 against 9.35 ms.
+        const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
         if (hipEventCreateWithFlags(&g_ev[dev][g_ev_n[dev]], flags) != hipSuccess) return nullptr;
         ++g_ev_n[dev];
     }
@@ -192,14 +186,6 @@ bool fork(hipStream_t main, hipStream_t side) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
     hipEvent_t ev = next_fork_event(dev);
     if (!ev) return false;
-    // measurement switch (tools only): CREAM_EXTRA_RECORDS = n records n more events on the main stream that nobody
-    // waits for — what a marker packet between two kernels of the main chain costs (profiles/r04_step_gaps.md)
-    static int extra = -1;
-    if (extra < 0) { const char* e = getenv("CREAM_EXTRA_RECORDS"); extra = e ? atoi(e) : 0; }
-    for (int i = 0; i < extra; ++i) {
-        hipEvent_t ex = next_fork_event(dev);
-        if (ex && ex != ev && hipEventRecord(ex, main) != hipSuccess) return false;
-    }
     return hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
 }
 
@@ -211,11 +197,9 @@ bool fork(hipStream_t main, hipStream_t side) {
 // streams live, the weight-gradient GEMMs contending with the main chain.  bench.py reads them for the
 // roofline entry.  Off by default (one relaxed load per launch).
 enum ProfKind { K_LN_FWD = 0, K_GEMM_NT, K_GEMM_NT_GELU, K_GEMM_NT_MUL, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD,
-                K_GRAD_FINALIZE, K_GEMM_NT_LN, K_COUNT };
+                K_GRAD_FINALIZE, K_COUNT };
 const char* const kProfNames[K_COUNT] = {"ln_fwd", "gemm_nt", "gemm_nt_gelu", "gemm_nt_mul", "gemm_tn_wgrad", "attn_rpe2d_fwd",
-                                         "attn_rpe2d_bwd", "ln_bwd", "grad_finalize", "gemm_nt_add_ln"};
-// projection + residual add + LayerNorm as one kernel where the shapes allow (cream_block_fuse_ln)
-std::atomic<int> g_fuse_ln{0};
+                                         "attn_rpe2d_bwd", "ln_bwd", "grad_finalize"};
 // split-K partial tiles of the weight gradients as bf16 (cream_linear_wgrad_parts_bf16): half the partial traffic
 std::atomic<int> g_wgrad_bf16{-1};
 int wgrad_bf16_mode() {
@@ -227,19 +211,6 @@ int wgrad_bf16_mode() {
     }
     return m;
 }
-// fc1 stores gelu(h) only and the fc2 dgrad recomputes gelu'(h) from a second product (cream_linear_dgrad_gelugrad): 116 MB
-// less through HBM per block at E = 384, F = 1344.  Needs E % 64 == 0 (else the stored-derivative path runs).
-std::atomic<int> g_gelu_recompute{-1};
-int gelu_recompute_mode() {
-    int m = g_gelu_recompute.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char* e = getenv("CREAM_GELU_RECOMPUTE");
-        m = e ? (atoi(e) != 0) : 0;
-        g_gelu_recompute.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
-bool gelu_recompute_for(const cream_block_desc* d) { return gelu_recompute_mode() && d->E % 64 == 0 && !d->inference; }
 
 // the split-K weight-gradient launch in either partial format (the workspace regions are sized for fp32)
 int wgrad_parts(int bf16, float* parts, float* bias_parts, const void* dy, const void* x, int M, int N, int K, int S, void* stream) {
@@ -346,19 +317,12 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
     PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), d->inference ? nullptr : at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
                              d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
                              CREAM_BF16, stream));
-    if (g_fuse_ln.load(std::memory_order_relaxed) && cream_linear_add_ln_supported(E, Q)) {
-        // proj, x1 = x + s1 * p and c = LN2(x1) in one kernel: the branch output p never crosses HBM (csrc/gemm_ln.hip)
-        PTRY(K_GEMM_NT_LN, stream, 2.0 * M * E * Q, (double)M * E * 10 + (double)M * Q * 2,
-             cream_linear_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), at<void>(ws, L.o), d->wproj,
-                                     d->bproj, xin, dp1, N, d->ln2_g, d->ln2_b, M, E, Q, d->ld_proj, d->eps2, stream));
-    } else {
-        PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
-        // x1 = x + s1 * p ; c = LN2(x1)
-        PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
-                             at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
-    }
+    PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
+    // x1 = x + s1 * p ; c = LN2(x1)
+    PTRY(K_LN_FWD, stream, 0, (double)M * E * 12, cream_add_ln_fwd(at<float>(ws, L.x1), at<void>(ws, L.c), at<float>(ws, L.mean2), at<float>(ws, L.rstd2), xin,
+                         at<void>(ws, L.p), dp1, N, d->ln2_g, d->ln2_b, M, E, d->eps2, stream));
     // fc1 + gelu in one pass; L.h holds gelu'(h) for the backward, L.g = gelu(h)
-    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad((d->inference || gelu_recompute_for(d)) ? nullptr : at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
+    PTRY(K_GEMM_NT_GELU, stream, 2.0 * M * F * E, 0, cream_linear_gelu_fwd_pad(d->inference ? nullptr : at<void>(ws, L.h), at<void>(ws, L.g), at<void>(ws, L.c), d->w1, d->b1, M, F,
                                   d->F_valid > 0 ? d->F_valid : F, E, d->ld_w1, stream));
     PTRY(K_GEMM_NT, stream, 2.0 * M * E * F, 0, cream_linear_fwd(at<void>(ws, L.f), at<void>(ws, L.g), d->w2, d->b2, M, E, F, d->ld_w2, stream));
     return CREAM_OK;
@@ -386,20 +350,16 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     hipStream_t main = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : main;
 
     // ---- MLP branch ----------------------------------------------------------------------------
-    // Two ways to the weight gradients (measured in one call on one box, twice: 10.92 vs 11.58 ms per step):
-    //   grouped == false (default): one split-K launch per projection AS SOON AS its operands exist (launching them in two
-    //       pairs behind dgrad_mul / the attention backward instead: 11.0 vs 10.83 ms, same-box A/B x3), partials added by
-    //       cream_grad_finalize — short workgroups that interleave with the main chain;
-    //   grouped == true (the caller hands over slabs + counters): ONE stream-K launch per block with the reduction in the
-    //       kernel (cream_wgrad_group) — 25 % less side-stream time standalone, but its long-lived workgroups hold half of
-    //       every SIMD's registers for ~200 us and the main chain behind them loses more than the side stream gains.
-    const bool grouped = G->wgrad_slabs && G->wgrad_counters;
-    const int wb16 = wgrad_bf16_mode();           // split-K partial tiles as bf16 (half the partial traffic) or fp32
+    // Every weight gradient is launched on the side stream AS SOON AS its operands exist (launching them in two pairs behind
+    // dgrad_mul / the attention backward instead: 11.0 vs 10.83 ms per step, same-box A/B x3); token-sliced partial tiles, added by
+    // cream_grad_finalize at the end of the block.
+    const int wb16 = wgrad_bf16_mode();           // partial tiles as bf16 (half the partial traffic) or fp32
     const int S2 = (int)D.S2, S1 = (int)D.S1, Sp = (int)D.Sp, Sq = (int)D.Sq;
-    if (!grouped) {
+    {
         // df is complete on main.  If it is the df_prev that the PREVIOUS call on this thread and these streams produced, the
         // side stream is already ordered behind its producer (it waited for that call's last LayerNorm backward before the
-        // finalisation): no event — one marker packet less per block on the main chain.
+        // finalisation): no event — one marker packet less per block on the main chain.  The record is consumed by THIS call
+        // whatever it decides (include/cream_amd.h states the contract: df must then be passed on untouched).
         static int reuse = -1;                                             // CREAM_REUSE_ORDER=0: always fork (A/B switch)
         if (reuse < 0) { const char* e = getenv("CREAM_REUSE_ORDER"); reuse = e ? (atoi(e) != 0) : 1; }
         const bool ordered = reuse && df && df == tl_ordered.df && main == tl_ordered.main && side == tl_ordered.side;
@@ -409,27 +369,19 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     }
     // dh = (df . W2) * gelu'(h) (saved by the forward) and the fc1 bias partials in the dgrad's epilogue
     KernelFork f_dh(main, side), f_dp(main, side), f_dqkv(main, side), f_dx(main, side);
-    if (!grouped && !f_dh.arm()) return CREAM_ERR_LAUNCH;                 // (the dgrad's own packet carries the event)
-    if (gelu_recompute_for(d))
-        PTRY(K_GEMM_NT_MUL, main, 4.0 * M * E * F, 0, cream_linear_dgrad_gelugrad(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.c), d->w1, d->b1,
-                                     M, E, F, d->F_valid > 0 ? d->F_valid : F, d->ld_w2_t, d->ld_w1, main));
-    else
-        PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
-                                     main));
-    if (!grouped) {
-        if (!f_dh.join()) return CREAM_ERR_LAUNCH;
-        PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, wgrad_parts(wb16, at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
-    }
+    if (!f_dh.arm()) return CREAM_ERR_LAUNCH;                             // (the dgrad's own packet carries the event)
+    PTRY(K_GEMM_NT_MUL, main, 2.0 * M * E * F, 0, cream_linear_dgrad_mul(at<void>(ws, L.dh), at<float>(ws, L.pb1), df, d->w2_t, at<void>(fws, FL.h), M, E, F, d->ld_w2_t,
+                                 main));
+    if (!f_dh.join()) return CREAM_ERR_LAUNCH;
+    PTRY(K_GEMM_TN, side, 2.0 * M * F * E, 0, wgrad_parts(wb16, at<float>(ws, L.pw1), nullptr, at<void>(ws, L.dh), at<void>(fws, FL.c), M, F, E, S1, side));
     PTRY(K_GEMM_NT, main, 2.0 * M * F * E, 0, cream_linear_dgrad(at<void>(ws, L.dc), at<void>(ws, L.dh), d->w1_t, M, F, E, d->ld_w1_t, main));
     // dx1 = dx2 + dLN2(dc); dp = s1 * dx1 (gradient of the proj output) and its column sums
-    if (!grouped && !f_dp.arm()) return CREAM_ERR_LAUNCH;
+    if (!f_dp.arm()) return CREAM_ERR_LAUNCH;
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx1), at<void>(ws, L.dp), at<float>(ws, L.pl2), at<void>(ws, L.dc), at<float>(fws, FL.x1),
                      at<float>(fws, FL.mean2), at<float>(fws, FL.rstd2), d->ln2_g, dx2, dp1, N, M, E, main));
     // ---- attention branch -----------------------------------------------------------------------
-    if (!grouped) {
-        if (!f_dp.join()) return CREAM_ERR_LAUNCH;                        // dp complete on main
-        PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, wgrad_parts(wb16, at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
-    }
+    if (!f_dp.join()) return CREAM_ERR_LAUNCH;                            // dp complete on main
+    PTRY(K_GEMM_TN, side, 2.0 * M * E * Q, 0, wgrad_parts(wb16, at<float>(ws, L.pwp), nullptr, at<void>(ws, L.dp), at<void>(fws, FL.o), M, E, Q, Sp, side));
     PTRY(K_GEMM_NT, main, 2.0 * M * E * Q, 0, cream_linear_dgrad(at<void>(ws, L.dout), at<void>(ws, L.dp), d->wproj_t, M, E, Q, d->ld_proj_t, main));
     const uint16_t* qkv = at<uint16_t>(fws, FL.qkv);
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
@@ -440,19 +392,8 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
                              d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
     if (!f_dqkv.join()) return CREAM_ERR_LAUNCH;                          // dqkv complete on main
-    if (!grouped) {
-        // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
-        PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, wgrad_parts(wb16, at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
-    } else {
-        // all four weight gradients (+ the qkv bias gradient) in ONE launch: their operands are complete on the main stream here
-        cream_wgrad_problem W[4] = {
-            {df, at<void>(fws, FL.g), E, F, G->w2, G->ld_w2, nullptr, E, F, 0, 0},
-            {at<void>(ws, L.dh), at<void>(fws, FL.c), F, E, G->w1, G->ld_w1, nullptr, F, E, 0, 0},
-            {at<void>(ws, L.dp), at<void>(fws, FL.o), E, Q, G->wproj, G->ld_proj, nullptr, E, Q, 0, 0},
-            {dqkv, at<void>(fws, FL.a), 3 * Q, E, G->wqkv, G->ld_qkv, G->bqkv, 3 * Q, E, Q, 0}};
-        PTRY(K_GEMM_TN, side, 2.0 * M * ((double)E * F * 2 + (double)E * Q + 3.0 * Q * E), 0,
-             cream_wgrad_group(W, 4, M, G->wgrad_slabs, G->wgrad_counters, side));
-    }
+    // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
+    PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, wgrad_parts(wb16, at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));
     PTRY(K_GEMM_NT, main, 2.0 * M * 3 * Q * E, 0, cream_linear_dgrad_seg(at<void>(ws, L.da), dqkv, d->wqkv_t, M, 3 * Q, E, d->ld_qkv_t, Q, d->seg_qkv_t, main));
     if (!f_dx.arm()) return CREAM_ERR_LAUNCH;
     PTRY(K_LN_BWD, main, 0, (double)M * E * 16, cream_ln_bwd(at<float>(ws, L.dx), want_prev ? at<void>(ws, L.df_prev) : nullptr, at<float>(ws, L.pl1), at<void>(ws, L.da), x,
@@ -468,13 +409,11 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
         J[n].cols = cols; J[n].interleave = interleave; J[n].src_bf16 = bf16; J[n].reserved = 0;
         ++n;
     };
-    if (!grouped) {
-        job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, wb16);
-        job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, wb16);
-        job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, wb16);
-        job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, wb16);
-        job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
-    }
+    job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, wb16);
+    job(G->w1, G->ld_w1, at<void>(ws, L.pw1), S1, (int64_t)F * E, F, E, 0, wb16);
+    job(G->wproj, G->ld_proj, at<void>(ws, L.pwp), Sp, (int64_t)E * Q, E, Q, 0, wb16);
+    job(G->wqkv, G->ld_qkv, at<void>(ws, L.pwq), Sq, 3 * (int64_t)Q * E, 3 * Q, E, Q, wb16);
+    job(G->bqkv, 3 * Q, at<void>(ws, L.pbq), Sq, 3 * Q, 1, 3 * Q, 0, 0);
     job(G->b2, E, pb2, pb2_parts, pb2_pstride, 1, E, 0, 0);
     job(G->b1, F, at<void>(ws, L.pb1), slabs, F, 1, F, 0, 0);
     job(G->ln2_g, E, at<float>(ws, L.pl2), P, 3 * (int64_t)E, 1, E, 0, 0);
@@ -491,13 +430,6 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     return CREAM_OK;
 }
 
-int cream_block_gelu_recompute(int on)
-{
-    const int prev = gelu_recompute_mode();
-    if (on >= 0) g_gelu_recompute.store(on != 0, std::memory_order_relaxed);
-    return prev;
-}
-
 int cream_block_wgrad_bf16(int on)
 {
     const int prev = wgrad_bf16_mode();
@@ -505,10 +437,6 @@ int cream_block_wgrad_bf16(int on)
     return prev;
 }
 
-int cream_block_fuse_ln(int on)
-{
-    return g_fuse_ln.exchange(on ? 1 : 0);
-}
 
 int cream_block_prof_enable(int on)
 {

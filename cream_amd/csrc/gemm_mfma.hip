@@ -64,27 +64,13 @@ int nt256_mode()
     return m;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remembered per device (one process may
-// drive several GPUs, block_seq.cpp: MAX_DEV), not per process
-template <typename K>
-bool raise_dynamic_lds(K kern, int bytes)
-{
-    static std::atomic<uint32_t> done{0};                      // bit d: raised on device d (per instantiation of this template)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev >= 0 && dev < 32 && (done.load(std::memory_order_relaxed) >> dev & 1u)) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-    if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
-    return true;
-}
-
 template <int EPI>
 int launch_nt256(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256, BN = 256;
     auto kern = gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
-    if (!raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
+    if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
     CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
@@ -98,7 +84,7 @@ int nt8_mode()
     int m = g_nt8.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("CREAM_GEMM_NT8");
-        m = e ? atoi(e) : 2;
+        m = e ? atoi(e) : 4;
         g_nt8.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -116,8 +102,11 @@ template <int EPI>
 int launch_nt8(const NtParams& p, hipStream_t st)
 {
     auto kern = gemm_nt8_kernel<EPI>;
-    if (!raise_dynamic_lds(kern, NT8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256), slots = num_cus() / 8 * 8;
+    if (!cream::raise_dynamic_lds(kern, NT8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+    // one persistent workgroup per CU (one tile per workgroup instead: 9.45 vs 9.45 ms per step, 192 workgroups: 10.2 —
+    // profiles/r05_nt8_step_ab.txt)
+    const int slots = num_cus() / 8 * 8;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(512), NT8_LDS_BYTES, st, p);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
@@ -125,7 +114,7 @@ int launch_nt8(const NtParams& p, hipStream_t st)
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
-    if constexpr (EPI != EPI_GELUGRAD_COLSUM) {
+    {
         // mode 2: where the cold probe has it ahead (profiles/r05_gemm_probe_cold.txt): every plain / bias product; the two
         // epilogues with element-wise work on the whole tile (GELU, x gelu') stay on the kernels whose second workgroup per CU
         // multiplies while the first one is in its epilogue — except on the long contractions, where the loop outweighs it
@@ -134,10 +123,12 @@ int launch_nt(const NtParams& p, hipStream_t st)
         // mode 3: light epilogues, and only where at most 1/8 of the 256-wide column tiles is padding (CU-time, not wall time,
         // is what the two-stream step pays for)
         const int npad = (p.N + 255) / 256 * 256;
-        if ((m8 == 1 || (m8 == 2 && (light || p.K >= 1024)) || (m8 == 3 && light && (npad - p.N) * 8 <= npad)) && nt8_fits(p))
+        // mode 4: the forward products only (bias epilogue: no weight-gradient stream runs beside them), same padding bound
+        if ((m8 == 1 || (m8 == 2 && (light || p.K >= 1024)) || (m8 == 3 && light && (npad - p.N) * 8 <= npad) ||
+             (m8 == 4 && EPI == EPI_BIAS && (npad - p.N) * 8 <= npad)) && nt8_fits(p))
             return launch_nt8<EPI>(p, st);
     }
-    if constexpr (EPI != EPI_GELUGRAD_COLSUM) {                  // (two accumulator sets do not fit the macro tile's registers)
+    {
         // mode 1: the wide outputs (N >= 960); mode 2: the LONG contractions (K >= 1152: fc2, fc1 dgrad, qkv dgrad at E >= 384 — N = E); mode 3: K >= 960
         const int m256 = nt256_mode();
         // (also measured: K >= 1152 plus the K = 448 shapes and qkv at E = 384, where the cold probe has the macro tile ahead: 9.47 / 9.45 ->
@@ -273,25 +264,6 @@ int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const 
     return launch_nt<EPI_MUL_COLSUM>(p, (hipStream_t)stream);
 }
 
-int cream_linear_dgrad_gelugrad(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* x, const void* w,
-                                const void* bias, int M, int N, int K, int Kvalid, int64_t ldwt, int64_t ldw, void* stream)
-{
-    // dh(M x K) = (dy(M x N) . W2(N x K)) * gelu'(h),  h = bf16(x(M x N) . W1(K x N)^T + bias): both NT products over the same
-    // (M x K) output tile, contraction N
-    const int rc = check_nt(dh, dy, wt, M, K, N, ldwt, N);
-    if (rc) return rc < 0 ? rc : CREAM_OK;
-    if (!colsum_parts || !x || !w || !bias || !aligned16(x) || !aligned16(w) || ldw < N || ldw % 8 || N % 64 || Kvalid <= 0 || Kvalid > K)
-        return CREAM_ERR_BAD_ARG;
-    NtParams p = plain(dh, dy, wt, M, K, N, ldwt);
-    p.colsum = colsum_parts;
-    p.A2 = (const uint16_t*)x; p.lda2 = N;
-    p.B2 = (const uint16_t*)w; p.ldb2 = ldw;
-    p.K2 = N;
-    p.bias = (const uint16_t*)bias;
-    p.nvalid = Kvalid;
-    return launch_nt<EPI_GELUGRAD_COLSUM>(p, (hipStream_t)stream);
-}
-
 }  // extern "C"
 
 namespace {
@@ -313,10 +285,10 @@ int tn8_tiles(int N, int K) { return ((N + 255) / 256) * ((K + 255) / 256); }
 int tn8_splits(int M, int N, int K)
 {
     const int T = tn8_tiles(N, K), steps = (M + 63) / 64;
-    static int slots = 0;                                       // CREAM_TN8_SLOTS (measurement switch): workgroups per launch; default HALF the CUs: in the step the
-    // weight gradients share the chip with the main chain and every split is another partial tile through HBM (same-call A/B,
-    // profiles/r05_tn8_step_ab.txt: 256 / 192 / 128 / 96 / 64 slots -> 9.62 / 9.48 / 9.41 / 9.77* / 10.1* ms per step, * another box)
-    if (!slots) { const char* e = getenv("CREAM_TN8_SLOTS"); slots = e && atoi(e) >= 8 ? atoi(e) : num_cus() / 2 / 8 * 8; }
+    // workgroups per launch: HALF the CUs.  In the step the weight gradients share the chip with the main chain and every slice is
+    // another partial tile through HBM (same-call A/B, profiles/r05_tn8_step_ab.txt: 256 / 192 / 128 workgroups -> 9.62 / 9.48 /
+    // 9.41 ms per step; another box: 128 / 96 / 64 -> 9.69 / 9.77 / 10.1)
+    const int slots = num_cus() / 2 / 8 * 8;
     int s = slots / T;
     if (s > steps) s = steps;
     return s < 1 ? 1 : s;
@@ -355,8 +327,7 @@ int cream_linear_wgrad_splits(int M, int N, int K)
     // here, read by cream_grad_finalize).  Measured A/B in one call, 3 runs each: 256 / 384 / 512 slots ->
     // 11.60 / 11.60 / 11.65 ms per step (fewer partial bytes vs. a 1.5x slower kernel: 78 vs 53 us standalone);
     // 512 keeps the kernel itself at its best rate
-    static int slots = 0;                                       // CREAM_WGRAD_SLOTS (measurement switch); default 512
-    if (!slots) { const char* e = getenv("CREAM_WGRAD_SLOTS"); slots = e && atoi(e) >= 64 ? atoi(e) : 512; }
+    const int slots = 512;
     int s = slots / tiles;
     if (s > 16) s = 16;                                         // (32 for the small proj gradient: 10.64 vs 10.60 ms per step, A/B x3)
     if (s > steps) s = steps;
@@ -393,11 +364,11 @@ int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const vo
     if (parts16 && tn8_wanted(M, N, K) && S == tn8_splits(M, N, K)) {
         if (bias_parts) {
             auto kern = gemm_tn8_kernel<0, true>;
-            if (!raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+            if (!cream::raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
             CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
         } else {
             auto kern = gemm_tn8_kernel<0, false>;
-            if (!raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
+            if (!cream::raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
             CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
         }
         return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
@@ -411,44 +382,3 @@ int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const vo
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 }  // namespace
-
-extern "C" {
-
-/* ---- all weight gradients of a block in one launch (stream-K ranges, in-kernel fixed-order reduction) ---- */
-int cream_wgrad_group_slots(void) { return 2 * num_cus() / 8 * 8; }          /* ranges = workgroups per launch: 2 per CU */
-
-int64_t cream_wgrad_group_workspace(void) { return (int64_t)2 * cream_wgrad_group_slots() * TN_SLAB * 4; }
-
-int cream_wgrad_group_max_tiles(void) { return 4096; }
-
-int cream_wgrad_group(const cream_wgrad_problem* probs, int nprobs, int M, void* slabs, int32_t* counters, void* stream)
-{
-    if (!probs || nprobs <= 0 || nprobs > 4 || M <= 0 || !slabs || !counters || !aligned16(slabs)) return CREAM_ERR_BAD_ARG;
-    TnGroupParams g{};
-    g.np = nprobs; g.M = M; g.tsteps = (M + 63) / 64;
-    int T = 0;
-    for (int i = 0; i < nprobs; ++i) {
-        const cream_wgrad_problem& q = probs[i];
-        if (q.N <= 0 || q.K <= 0 || q.N % 8 || q.K % 8 || !q.dy || !q.x || !q.dw || q.ldy < q.N || q.ldx < q.K || q.ld_dw < q.K ||
-            q.ld_dw % 4 || q.interleave < 0 || (q.interleave > 0 && q.N != 3 * q.interleave))
-            return CREAM_ERR_BAD_ARG;
-        if (!aligned16(q.dy) || !aligned16(q.x) || !aligned16(q.dw) || q.ldy % 8 || q.ldx % 8) return CREAM_ERR_BAD_ARG;
-        TnProblem& P = g.prob[i];
-        P.dY = (const uint16_t*)q.dy; P.X = (const uint16_t*)q.x; P.ldy = q.ldy; P.ldx = q.ldx;
-        P.dst = q.dw; P.ld_dst = q.ld_dw; P.dst_bias = q.dbias; P.N = q.N; P.K = q.K; P.interleave = q.interleave;
-        P.tile0 = T; P.ntk = (q.K + 127) / 128; P.ntn = (q.N + 127) / 128;
-        P.colmajor = q.K > q.N;                               // X (M x K) is the larger operand: keep its sharers together
-        T += P.ntn * P.ntk;
-    }
-    if (T > cream_wgrad_group_max_tiles()) return CREAM_ERR_TOO_LARGE;
-    g.T = T;
-    g.slabs = (float*)slabs; g.counters = counters;
-    const int64_t U = (int64_t)T * g.tsteps;
-    const int slots = cream_wgrad_group_slots();
-    if ((U + 1) * slots >= ((int64_t)1 << 31)) return CREAM_ERR_TOO_LARGE;     // the kernel's range arithmetic is 32-bit
-    const int grid = U < slots ? (int)U : slots;
-    hipLaunchKernelGGL(gemm_tn_group_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
-    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
-}
-
-}  // extern "C"

@@ -47,7 +47,7 @@
 namespace cream {
 namespace gemm {
 
-enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3, EPI_GELUGRAD_COLSUM = 4 };
+enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_COLSUM = 3 };
 
 // Phase timestamps for tools/probes/gemm_nt_probe.hip (compiled out of the library)
 #ifdef GEMM_PROFILE
@@ -71,13 +71,6 @@ struct NtParams {
     int64_t ldaux;
     float* colsum;          // EPI_MUL_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
     int nvalid;             // EPI_BIAS_GELU: columns n >= nvalid are written as zeros (N padded up to a multiple of 8)
-    // EPI_GELUGRAD_COLSUM (fc2 dgrad with the GELU derivative RECOMPUTED instead of read): a second product over the same
-    // output tile, H = A2 (M x K2) . B2 (N x K2)^T (the fc1 forward: A2 = LN2 output, B2 = W1), h = bf16(H + bias);
-    // out = (A . B^T) * gelu'(h) (0 for n >= nvalid) + per-slab column sums.  K2 == K, K % 64 == 0, plain operands (no segments).
-    const uint16_t* A2;
-    const uint16_t* B2;
-    int64_t lda2, ldb2;
-    int K2;
 };
 
 // erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
@@ -157,7 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
     static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
     static_assert(HM >= 32 && WTM % HM == 0 && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles of one wave row, inside one stage");
-    static_assert((EPI != EPI_MUL_COLSUM && EPI != EPI_GELUGRAD_COLSUM) || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
+    static_assert(EPI != EPI_MUL_COLSUM || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
     char* const smem = LdsBlock<NST * STAGE * 2>::get();
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
     float* const ctile = reinterpret_cast<float*>(smem + STAGE * 2);           // stage 1
@@ -176,14 +169,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         const int row = (wave + NW * i) * 8 + (lane >> 3);
         cch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
     }
-    auto sources2 = [&](const uint16_t* (&src)[NPIECE], int m0, int n0) {      // the second product: plain operands
-#pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const int piece = wave + NW * i, row = piece * 8 + (lane >> 3);
-            if (row < BM) src[i] = p.A2 + (int64_t)min(m0 + row, p.M - 1) * p.lda2 + cch[i];
-            else src[i] = p.B2 + (int64_t)min(n0 + row - BM, p.N - 1) * p.ldb2 + cch[i];
-        }
-    };
     auto sources = [&](const uint16_t* (&src)[NPIECE], int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
@@ -222,7 +207,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     };
 
     f32x16 acc[TN][TM];
-    f32x16 acc2[EPI == EPI_GELUGRAD_COLSUM ? TN : 1][EPI == EPI_GELUGRAD_COLSUM ? TM : 1];      // the second product (pre-activation)
 
     // one K-step from stage `buf`; vc = valid 8-wide chunks (8 unless TAIL).  Fragments are double
     // buffered in registers: the reads of sub-step ks+1 are issued BEFORE the MFMAs of sub-step ks
@@ -270,8 +254,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     using No = std::integral_constant<bool, false>;
     using Yes = std::integral_constant<bool, true>;
     const int nfull = K / BK, rem = K % BK, nk = nfull + (rem ? 1 : 0);
-    const int nk2 = EPI == EPI_GELUGRAD_COLSUM ? p.K2 / BK : 0;          // steps of the second product (no tail)
-    const uint16_t* src2[EPI == EPI_GELUGRAD_COLSUM ? NPIECE : 1];
 
     // epilogue geometry: a thread owns an 8-column chunk of rows r0, r0 + RPP, ... of each half tile
     constexpr int CPR = BN / 8;                                 // chunks per tile row
@@ -284,7 +266,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     int t = xcd_remap(orig, ntiles);
     int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
     sources(src, m0, n0);
-    if constexpr (EPI == EPI_GELUGRAD_COLSUM) sources2(src2, m0, n0);
     if (nk > 0) { if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{}); }
 
     for (;;) {
@@ -302,10 +283,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s + 1 < nk) { if (s + 1 < nfull) issue(src, (s + 1) * BK, (s + 1) & 1, No{}); else issue(src, (s + 1) * BK, (s + 1) & 1, Yes{}); }
-            else if constexpr (EPI == EPI_GELUGRAD_COLSUM) {    // the stream of K-steps continues with the second product
-                if (s + 1 == nk) { kb = 0; kin = 0; }           // the B-side K offset restarts with the second product
-                if (s + 1 < nk + nk2) issue(src2, (s + 1 - nk) * BK, (s + 1) & 1, No{});
-            }
         };
         for (int s = 0; s < nfull; ++s) {                       // (the tail step lives outside the loop: one
             top_of_step(s);                                     //  accumulator live range, no phi copies)
@@ -316,39 +293,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         if (rem) {
             top_of_step(nfull);
             step(nfull & 1, rem >> 3, Yes{});
-        }
-        if constexpr (EPI == EPI_GELUGRAD_COLSUM) {
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b) acc2[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = nk; s < nk + nk2; ++s) {
-                top_of_step(s);
-                step_into(acc2, s & 1, 8, No{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            // dh = (dy . W2) * gelu'(h), h = bf16(c . W1^T + b1): element-wise in the accumulator layout (a lane owns output
-            // row m and, per 32 x 32 tile, four runs of four columns n) — gelu is evaluated in fp32 ON the bf16 value, as the
-            // forward's epilogue does (supernet_transformer.py:14-16, :276-277); padded columns (n >= nvalid) give 0
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int nn = n0 + wn * WTN + tn * 32 + 8 * r4 + 4 * g;
-                    u32x2v braw2 = u32x2v{0, 0};
-                    if (nn < p.N) braw2 = *reinterpret_cast<const u32x2v*>(p.bias + nn);
-                    const float b4[4] = {__uint_as_float(braw2[0] << 16), __uint_as_float(braw2[0] & 0xFFFF0000u),
-                                         __uint_as_float(braw2[1] << 16), __uint_as_float(braw2[1] & 0xFFFF0000u)};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool live = nn + e < p.nvalid;
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) {
-                            const float hb = __uint_as_float(((uint32_t)(uint16_t)f2bf(acc2[tn][tm][4 * r4 + e] + b4[e])) << 16);
-                            acc[tn][tm][4 * r4 + e] *= live ? gelu_grad_f(hb) : 0.f;
-                        }
-                    }
-                }
         }
         GPROF(2);
 
@@ -364,8 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             t = xcd_remap(orig, ntiles);
             m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
             sources(src, m0, n0);
-            if constexpr (EPI == EPI_GELUGRAD_COLSUM) sources2(src2, m0, n0);
-            kb = 0; kin = 0;
+                    kb = 0; kin = 0;
             if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{});
         }
 
@@ -450,15 +393,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     }
                     if (p.out) *reinterpret_cast<u32x4v*>(o) = pb;          // (no gelu' without a backward: inference, frozen teacher)
                     *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
-                } else if constexpr (EPI == EPI_GELUGRAD_COLSUM) {
-                    u32x4v db;                                  // (the factor is already in the accumulators)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        db[e] = f2bf_pair(v[2 * e], v[2 * e + 1]);
-                        cs[2 * e] += __uint_as_float(db[e] << 16);
-                        cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
-                    }
-                    *reinterpret_cast<u32x4v*>(o) = db;
                 } else {   // EPI_MUL_COLSUM
                     const u32x4v fb = auxv[j];
                     u32x4v db;
@@ -471,7 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     *reinterpret_cast<u32x4v*>(o) = db;
                 }
             }
-            if constexpr (EPI == EPI_MUL_COLSUM || EPI == EPI_GELUGRAD_COLSUM) {
+            if constexpr (EPI == EPI_MUL_COLSUM) {
                 if (((half + 1) * HM) % SLAB == 0) {            // a 128-row slab is complete: its column sums leave
                     __syncthreads();                            // the fp32 pass has been consumed
                     float* red = ctile;                         // [RPP][BN]
@@ -748,192 +682,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnParams p)
             if (n < p.N)
                 *reinterpret_cast<f32x4v*>(out + (int64_t)n * p.K + k0 + c4) = *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4);
         }
-    }
-}
-
-// =================================================================================================
-// Grouped TN kernel — ALL weight gradients of a transformer block in one launch, reduced in the kernel.
-//
-// Up to 4 problems dW_i(N_i x K_i) = dY_i^T . X_i over the same M tokens (qkv, proj, fc1, fc2 of
-// supernet_transformer.py:251-287).  Their 128 x 128 output tiles are laid end to end and the (tile, 64-token step)
-// space is cut into gridDim.x EQUAL contiguous ranges (stream-K): every workgroup does the same number of steps
-// whatever the mix of shapes (the per-GEMM split-K of gemm_tn_kernel needed 8-16 splits per tile to fill the chip:
-// 4 x 22 MB of fp32 partials written per block and 129 MB read back by cream_grad_finalize; here a tile has
-// ~gridDim.x / tiles contributors — 3 to 5 for the supernet-S shapes).
-// A range that covers a whole tile adds it straight into the gradient.  Partial ranges write an fp32 slab
-// (at most two per workgroup: the one that starts the range, the one that ends it), publish it with the agent-scope
-// release / ticket protocol of cdna_hip_programming.md (plain stores -> every wave drains vmcnt -> barrier -> one
-// lane: release fence, drained, relaxed ticket fetch_add), and the workgroup that draws the LAST ticket of a tile
-// (acquire fence by one lane, barrier) adds the slabs of all contributors IN RANGE ORDER — a fixed summation order
-// whatever the arrival order, bit-reproducible, no atomics on data — into dW[rowmap(n)][k] (the q / k / v row
-// interleave of qkv_super.py:75) and, for the first k-tile of a problem with a bias, the column sums of dY into db.
-// Nobody waits on anybody: no spinning, no deadlock.  The last arriver resets the tile's counter for the next launch.
-struct TnProblem {
-    const uint16_t* dY; const uint16_t* X;
-    int64_t ldy, ldx;
-    float* dst; int64_t ld_dst;
-    float* dst_bias;          // (N) += column sums of dY, or nullptr
-    int N, K;
-    int interleave;           // > 0: dst row of output n = 3 * (n % interleave) + n / interleave
-    int tile0, ntk, ntn;      // first tile of this problem in the launch-wide tile order; k-tiles per tile row, tile rows
-    int colmajor;             // tile order inside the problem: 0 = tile rows (share dY) adjacent, 1 = tile columns (share X) adjacent
-};
-struct TnGroupParams {
-    TnProblem prob[4];
-    int np, M, tsteps, T;     // problems, tokens, ceil(M / 64), tiles in total
-    float* slabs;             // [2 * gridDim.x][TN_SLAB] fp32
-    int32_t* counters;        // [T], zero before the first launch
-};
-constexpr int TN_SLAB = 128 * 128 + 128;                        // tile + its bias row
-
-// range w of G over U units: [U w / G, U (w + 1) / G).  32-bit: the launcher guarantees U * G < 2^31
-__device__ __forceinline__ int tn_range_lo(int U, int w, int G) { return (int)((unsigned)U * (unsigned)w / (unsigned)G); }
-
-template <int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, OCC))) void gemm_tn_group_kernel(const TnGroupParams g)
-{
-    constexpr int BT = 128, BM = 64, NST = 2;
-    __shared__ __attribute__((aligned(1024))) uint16_t lds[NST * 2 * BM * BT];
-    const int G = gridDim.x, w = xcd_remap(blockIdx.x, G);     // neighbouring ranges (same tile row, same tokens) share an XCD's L2
-    const int U = g.T * g.tsteps;
-    int lo = tn_range_lo(U, w, G);
-    const int lo0 = lo, hi = tn_range_lo(U, w + 1, G);
-    while (lo < hi) {
-        // the lane index is made opaque per range: everything derived from it (fragment offsets, source pointers, epilogue
-        // addresses) is recomputed per range instead of being hoisted out of this loop and kept live across the MFMA loops
-        // (measured at compile time: 256 VGPRs + scratch with the hoisting, 162 without — and with it no other kernel's
-        // wave fits next to two of these on a SIMD)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wn = wave >> 1, wk = wave & 1;
-        const int gq = lane >> 5, c32 = lane & 31;
-        const int tile = lo / g.tsteps, s_lo = lo - tile * g.tsteps;
-        const int s_hi = min(g.tsteps, s_lo + (hi - lo));
-        // the tile's problem (constant indices: the descriptors stay in scalar registers, no private copy of the arguments)
-        TnProblem P = g.prob[0];
-        if (g.np > 1 && tile >= g.prob[1].tile0) P = g.prob[1];
-        if (g.np > 2 && tile >= g.prob[2].tile0) P = g.prob[2];
-        if (g.np > 3 && tile >= g.prob[3].tile0) P = g.prob[3];
-        // neighbouring tiles (= neighbouring workgroups on one XCD, marching through the tokens in step) share the LARGER operand
-        const int lt = tile - P.tile0;
-        const int n0 = (P.colmajor ? lt % P.ntn : lt / P.ntk) * BT, k0 = (P.colmajor ? lt / P.ntn : lt % P.ntk) * BT;
-        const bool want_bias = P.dst_bias && k0 == 0;
-        f32x16 acc[2][2], bacc[2];
-        tn_zero(acc, bacc);
-        const TnTile t{P.dY, P.X, P.ldy, P.ldx, g.M, P.N, P.K, n0, k0};
-        tn_accumulate<BM, NST>(t, s_lo, s_hi, want_bias, acc, bacc, lds, tid);
-        // ---- the accumulators leave through LDS (the stages are idle): [128 n][128 k] fp32 = exactly the 64 KB of the two
-        //      stages, so that every global access below is a 16-byte row chunk: thread = (rows r0 + 8 i, columns c4 .. c4 + 3)
-        float* ct = reinterpret_cast<float*>(lds);
-        __syncthreads();                                                       // every wave is done reading the stages
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ct[(wn * 64 + a * 32 + acc_row(r, gq)) * BT + wk * 64 + b * 32 + c32] = acc[a][b][r];
-        const bool whole = s_lo == 0 && s_hi == g.tsteps;
-        float* slab = g.slabs + ((int64_t)2 * w + (lo == lo0 ? 0 : 1)) * TN_SLAB;   // slab 0 starts this workgroup's range, slab 1 ends it
-        if (want_bias && wk == 0 && c32 == 0) {                                 // the bias row: 32 values per (wave, half)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nl = wn * 64 + a * 32 + acc_row(r, gq);
-                    if (whole) { if (n0 + nl < P.N) P.dst_bias[n0 + nl] += bacc[a][r]; }
-                    else __hip_atomic_store(slab + BT * BT + nl, bacc[a][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
-                }
-        }
-        __syncthreads();
-        const int c4 = (tid & 31) * 4, r0 = tid >> 5;
-        const bool kok = k0 + c4 < P.K;                                        // K % 8 == 0: a 4-chunk is all in or all out
-        auto add_rows = [&](int i, const f32x4v& v) {                          // dW[rowmap(n)][k0 + c4 ..] += v
-            const int n = n0 + r0 + 8 * i;
-            if (kok && n < P.N) {
-                const int rr = P.interleave > 0 ? 3 * (n % P.interleave) + n / P.interleave : n;
-                float* d = P.dst + (int64_t)rr * P.ld_dst + k0 + c4;
-                f32x4v o = *reinterpret_cast<f32x4v*>(d);
-                o += v;
-                *reinterpret_cast<f32x4v*>(d) = o;
-            }
-        };
-        if (whole) {
-            // ---- the only contributor of this tile: add into the gradient in place
-#pragma unroll
-            for (int i = 0; i < 16; ++i) add_rows(i, *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4));
-        } else {
-            // ---- partial range: publish the slab WRITE-THROUGH (sc1 16-byte stores: no release fence, no L2 write-back of
-            //      everybody's dirty lines), every wave drains its stores, barrier, one lane draws the tile's ticket
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const f32x4v v = *reinterpret_cast<const f32x4v*>(ct + (r0 + 8 * i) * BT + c4);
-                float* dst = slab + (r0 + 8 * i) * BT + c4;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                                   // (also: everyone is done reading ct)
-            // contributors of this tile: the workgroups whose ranges intersect [tile * tsteps, (tile + 1) * tsteps)
-            const int t_lo = tile * g.tsteps, t_hi = t_lo + g.tsteps;
-            const int w_first = (int)((((unsigned)t_lo + 1u) * (unsigned)G - 1u) / (unsigned)U);
-            const int w_last = (int)(((unsigned)t_hi * (unsigned)G - 1u) / (unsigned)U);
-            const int nc = w_last - w_first + 1;
-            // their slab addresses (0 = empty range), once, into LDS
-            uint64_t* tab = reinterpret_cast<uint64_t*>(lds) + 8;
-            int* flag = reinterpret_cast<int*>(lds);
-            int mine = 0;
-            for (int c = tid; c < nc; c += 256) {
-                const int wc = w_first + c, clo = tn_range_lo(U, wc, G), chi = tn_range_lo(U, wc + 1, G);
-                const bool live = chi > clo;
-                tab[c] = live ? reinterpret_cast<uint64_t>(g.slabs + ((int64_t)2 * wc + (clo >= t_lo ? 0 : 1)) * TN_SLAB) : 0;
-                mine += live;
-            }
-            if (tid == 0) flag[1] = 0;
-            __syncthreads();
-            if (mine) atomicAdd(&flag[1], mine);                               // LDS: number of live contributors
-            __syncthreads();
-            if (tid == 0) {
-                const int n = flag[1];
-                const int ticket = __hip_atomic_fetch_add(&g.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = ticket == n - 1;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale lines: plain loads below
-                    g.counters[tile] = 0;                                      // ready for the next launch (stream order)
-                }
-                flag[0] = last;
-            }
-            __syncthreads();
-            if (flag[0] != 0) {
-                // ---- last arriver: add the slabs of ALL contributors in range order (fixed summation order), eight loads
-                //      in flight per row (the reads come from other CUs' write-through stores: HBM / Infinity Cache latency)
-#pragma nounroll
-                for (int i = 0; i < 16; ++i) {
-                    f32x4v sum = f32x4v{0, 0, 0, 0};
-                    const int off = (r0 + 8 * i) * BT + c4;
-                    for (int cb = 0; cb < nc; cb += 8) {
-                        f32x4v v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint64_t a = cb + j < nc ? tab[cb + j] : 0;
-                            v[j] = a ? *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(a) + off) : f32x4v{0, 0, 0, 0};
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sum += v[j];
-                    }
-                    add_rows(i, sum);
-                }
-                if (want_bias && tid < BT && n0 + tid < P.N) {
-                    float bsum = 0.f;
-                    for (int c = 0; c < nc; ++c)
-                        if (tab[c]) bsum += reinterpret_cast<const float*>(tab[c])[BT * BT + tid];
-                    P.dst_bias[n0 + tid] += bsum;
-                }
-            }
-        }
-        lo += s_hi - s_lo;
-        if (lo < hi) __syncthreads();                                          // next range restages the LDS
     }
 }
 

@@ -9,6 +9,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include <atomic>
 
 namespace cream {
 extern thread_local hipEvent_t tl_stop_event;       // defined in block_seq.cpp
@@ -28,3 +31,19 @@ extern thread_local hipEvent_t tl_start_event;
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
         }                                                                                                            \
     } while (0)
+
+namespace cream {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remembered per device (one process may
+// drive several GPUs, block_seq.cpp: MAX_DEV), not per process
+template <typename K>
+bool raise_dynamic_lds(K kern, int bytes)
+{
+    static std::atomic<uint32_t> done{0};                      // bit d: raised on device d (per instantiation of this template)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32 && (done.load(std::memory_order_relaxed) >> dev & 1u)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+    return true;
+}
+}  // namespace cream

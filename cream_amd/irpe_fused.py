@@ -144,11 +144,22 @@ def dropout_threshold(p):
 _seed_gen = None
 
 
-def _new_seed():
-    """Seeds of the in-kernel keep masks come from a DEDICATED host generator seeded from torch.initial_seed(): they
-    follow torch.manual_seed without consuming numbers of the global host stream (Mixup / the config sampler draw from
-    it between layers)."""
+def _new_seed(device=None):
+    """Seed of one in-kernel keep mask.  On a GPU it is derived from the device generator's (seed, offset) — the state
+    torch.nn.Dropout itself consumes (rpe_vision_transformer.py:64, :91) — and advances that offset: masks follow
+    torch.manual_seed, a second torch.manual_seed(s) with the SAME s replays them, and no number of the host stream is used
+    (Mixup / the configuration sampler draw from it between layers).  Without a device generator: a dedicated host generator
+    seeded from torch.initial_seed()."""
     global _seed_gen
+    gens = getattr(torch.cuda, "default_generators", ())
+    if torch.cuda.is_available() and len(gens):
+        g = gens[torch.cuda.current_device() if device is None else torch.device(device).index or 0]
+        if hasattr(g, "get_offset"):
+            seed, off = int(g.initial_seed()), int(g.get_offset())
+            g.set_offset(off + 4)                              # (multiples of 4: one Philox counter step, as a dropout launch takes)
+            x = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x ^= x >> 31
+            return int(x % (2 ** 31 - 1))
     if _seed_gen is None or _seed_gen[0] != torch.initial_seed():
         g = torch.Generator()
         g.manual_seed(torch.initial_seed() ^ 0x5DEECE66D)
@@ -298,5 +309,5 @@ def attention(qkv, scale, rpe_q, rpe_k, rpe_v, dropout_p=0.0, seed=None):
     terms = tuple(_term(r, L, dev) for r in (rpe_q, rpe_k, rpe_v))
     ws = [t[0] if t is not None else None for t in terms]
     if dropout_p and seed is None:
-        seed = _new_seed()
+        seed = _new_seed(dev)
     return _Fused.apply(qkv, float(scale), ws[0], ws[1], ws[2], terms, float(dropout_p or 0.0), int(seed or 0))

@@ -93,8 +93,11 @@ def similarity(a, b):
     """a (M, D) . b (N, D)^T.  Device tensors go through the own kernels: bf16 under autocast (what `@` would compute in),
     exact fp32 otherwise (csrc/gemm_f32.hip); host tensors (tests, the gloo runs) keep the framework product."""
     if a.is_cuda and a.shape[1] % 8 == 0 and b.shape[0] % 8 == 0:
-        if torch.is_autocast_enabled("cuda") or a.dtype == torch.bfloat16:
+        bf16_autocast = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if bf16_autocast or a.dtype == torch.bfloat16:
             return _SimilarityNT.apply(a, b)
+        if torch.is_autocast_enabled("cuda"):                 # fp16 autocast: what `@` computes in — not this library's path
+            return a @ b.T
         from ..autoformer import native_fp32
         if native_fp32.usable(a, b):
             return native_fp32.linear(a, b, None, b.shape[0], a.shape[1])

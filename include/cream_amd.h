@@ -96,13 +96,6 @@ int cream_attn_rpe2d_dtab_parts(int B, int H);
  * (What autograd derives for multihead_super.py:135-154 either way; a switch for same-box A/B measurements.) */
 int cream_attn_rpe2d_bwd_mode(int onepass);
 
-/* Which forward runs for the same geometry in bf16: 1 = csrc/attn_rpe2d_fwd1.hpp (K and V of an item travel
- * global -> LDS by DMA into unpadded swizzled images, the next item's matrices land under the current item, two barriers
- * per item), 0 = attn_rpe2d_fwd14_kernel (register-staged matrices, four barriers).  Same algebra and operand roundings
- * (multihead_super.py:133-160), bit-identical outputs.  dma < 0 only queries; returns the previous setting; initial value
- * from CREAM_ATTN_FWD1 (default 0: measured 12 % slower, profiles/r04_attn_fwd1.md). */
-int cream_attn_rpe2d_fwd_mode(int dma);
-
 /* The attention core of AttentionSuper.forward between the qkv and proj GEMMs
  * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
  * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
@@ -266,22 +259,6 @@ int cream_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const float
                      const float* sample_scale, int rows_per_sample, const float* gamma,
                      const float* beta, int M, int E, float eps, void* stream);
 
-/* A projection whose output width is the embedding dimension, the residual add and the LayerNorm
- * that follows, in ONE kernel (csrc/gemm_ln.hip) — supernet_transformer.py:262-276:
- *   x = residual + drop_path(self.attn(...)) ; x = self.ffn_layer_norm(x)   and, across the block
- * boundary, fc2 -> residual add -> the next block's attn_layer_norm.  Same results, bit for bit, as
- * cream_linear_fwd followed by cream_add_ln_fwd:
- *   p = bf16(a(M x K, bf16) . w[:E, :K]^T + bias)   (w: row stride ldw elements; bias bf16 or NULL)
- *   xsum(f32) = x(f32) + sample_scale[row / rows_per_sample] * p   (scale may be NULL = 1)
- *   y(bf16) = LayerNorm(xsum; gamma, beta, eps), mean / rstd of xsum saved.
- * The M x E branch output p is never written.  Shapes: cream_linear_add_ln_supported(E, K) != 0
- * (E a multiple of 64 in [192, 512], K a multiple of 32), else CREAM_ERR_TOO_LARGE. */
-int cream_linear_add_ln_supported(int E, int K);
-int cream_linear_add_ln_fwd(float* xsum, void* y, float* mean, float* rstd, const void* a, const void* w,
-                            const void* bias, const float* x, const float* sample_scale, int rows_per_sample,
-                            const float* gamma, const float* beta, int M, int E, int K, int64_t ldw, float eps,
-                            void* stream);
-
 /* Number of row slabs ln_bwd reduces over: partial must hold cream_ln_partials()*3*E floats. */
 int cream_ln_partials(void);
 
@@ -392,13 +369,6 @@ int cream_linear_dgrad_seg(void* dx, const void* dy, const void* wt, int M, int 
                            int kseg, int64_t kseg_stride, void* stream);
 int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* factor,
                              int M, int N, int K, int64_t ldwt, void* stream);
-/* fc2 dgrad with the GELU derivative RECOMPUTED instead of read (supernet_transformer.py:275-285 backward): the kernel forms
- * BOTH dy . W2 and the fc1 pre-activation h = bf16(x . W1^T + bias) for an output tile (x = the LayerNorm output the forward
- * fed to fc1, w = the fc1 operand (K rows, ld ldw)) and writes dh = (dy . W2) * gelu'(float(h)) (0 for columns >= Kvalid) and
- * its per-slab column sums — the forward then stores gelu(h) only: 68 MB less written and 48 MB less read per block at
- * E = 384, F = 1344 for 26 GFLOP of matrix-core work that the HBM-bound kernel has to spare.  N % 64 == 0. */
-int cream_linear_dgrad_gelugrad(void* dh, float* colsum_parts, const void* dy, const void* wt, const void* x, const void* w,
-                                const void* bias, int M, int N, int K, int Kvalid, int64_t ldwt, int64_t ldw, void* stream);
 int cream_linear_wgrad_splits(int M, int N, int K);
 int cream_linear_wgrad_parts(float* parts, float* bias_parts, const void* dy, const void* x, int M, int N,
                              int K, int S, void* stream);
@@ -470,28 +440,6 @@ int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
  * logits (B x C) bf16 or f32 (logits_dtype), target (B x C) f32, C <= 2048; softmax statistics in fp32. */
 int cream_soft_ce(float* loss_rows, float* dlogits, const void* logits, const float* target, int B, int C, int logits_dtype,
                   float grad_scale, void* stream);
-
-/* ---- all weight gradients of a transformer block in ONE launch --------------------------------
- * dW_i[rowmap(n)][k] += sum_m dy_i[m][n] x_i[m][k]  and  dbias_i[n] += sum_m dy_i[m][n]   for up to 4 projections
- * over the same M tokens — what autograd derives for LinearSuper / qkv_super (Linear_super.py:71-81,
- * qkv_super.py:72-83: interleave = Q maps output n of [q | k | v] to super row 3 (n % Q) + n / Q).
- * The (128 x 128 tile, 64-token step) space of all problems is cut into cream_wgrad_group_slots() equal ranges
- * (stream-K); partial ranges meet through fp32 slabs in `slabs` (cream_wgrad_group_workspace() bytes, contents
- * irrelevant between launches) and are added by the last-arriving workgroup of each tile in range order — fixed
- * summation order, no atomics on data, bit-reproducible.  `counters`: >= cream_wgrad_group_max_tiles() int32,
- * ZERO before the first launch; every launch leaves them zero.  Launches sharing slabs / counters must be
- * stream-ordered.  dy / x bf16 (row strides ldy / ldx elements), dw fp32 (row stride ld_dw), N, K % 8 == 0. */
-typedef struct cream_wgrad_problem {
-    const void* dy; const void* x;
-    int64_t ldy, ldx;
-    float* dw; int64_t ld_dw;
-    float* dbias;                 /* (N) or NULL */
-    int32_t N, K, interleave, reserved;
-} cream_wgrad_problem;
-int cream_wgrad_group_slots(void);
-int64_t cream_wgrad_group_workspace(void);
-int cream_wgrad_group_max_tiles(void);
-int cream_wgrad_group(const cream_wgrad_problem* probs, int nprobs, int M, void* slabs, int32_t* counters, void* stream);
 
 /* ---- fp32-I/O instantiations (parity mode) -------------------------------------------------------
  * The same operators with fp32 tensors on both sides, for the "within 1e-3 of the reference PyTorch-CPU
@@ -578,10 +526,6 @@ typedef struct cream_block_grads {
     float *wqkv, *bqkv, *wproj, *bproj, *w1, *b1, *w2, *b2;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *tkv, *tkh, *tvv, *tvh;
     int64_t ld_qkv, ld_proj, ld_w1, ld_w2, ldt;
-    /* both NULL (default): one split-K launch per projection + cream_grad_finalize; both set: the block's weight gradients
-     * in ONE cream_wgrad_group launch (workspace / counters as that function wants them, shared by all blocks of a device) */
-    void* wgrad_slabs;
-    int32_t* wgrad_counters;
 } cream_block_grads;
 
 /* Bytes of the forward workspace (kept by the caller for the backward); *off_x = block input after
@@ -601,7 +545,12 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
  * both produced by whoever consumed the block's output.  Outputs in ws: dx (fp32, *off_dx) and,
  * if want_prev, df_prev = bf16(prev_scale * dx) (*off_df_prev) with its column sums as plane 2 of
  * the (cream_ln_partials() x 3 x E) partials at *off_pl1 — i.e. (df, pb2) of the previous block.
- * Parameter gradients are complete when `side_stream` has drained. */
+ * Parameter gradients are complete when `side_stream` has drained.
+ * Ordering contract of df: when a call returns df_prev (want_prev) and the NEXT cream_block_bwd call on the same thread and
+ * the same two streams is handed exactly that buffer as df, the library does not order the side stream behind it again (it
+ * already is: one marker packet less per block).  The caller must therefore pass that df_prev on UNTOUCHED — a caller that
+ * rewrites it on `stream` between the two calls, or produces another df at the same address, sets CREAM_REUSE_ORDER=0 in
+ * the environment (always order).  The record is consumed by the next call on the thread whatever it is given. */
 int64_t cream_block_bwd_workspace(const cream_block_desc* d, int64_t* off_dx, int64_t* off_df_prev, int64_t* off_pl1);
 int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const void* fws, const float* x,
                     void* ws, const float* dx2, const void* df, const float* pb2, int pb2_parts,
@@ -609,18 +558,9 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const
                     void* stream, void* side_stream);
 
 
-/* Switch (process-wide, returns the previous value): cream_block_fwd runs proj + residual add +
- * ffn_layer_norm as ONE kernel (cream_linear_add_ln_fwd) where cream_linear_add_ln_supported says so.
- * Results are identical either way. */
-int cream_block_fuse_ln(int on);
 /* cream_block_bwd writes the split-K partial tiles of the four weight gradients as bf16 (1) or fp32 (0); returns the
  * previous setting; on < 0 only queries.  Initial value: CREAM_WGRAD_BF16 in the environment, else 1. */
 int cream_block_wgrad_bf16(int on);
-/* 1: cream_block_fwd stores gelu(h) only and cream_block_bwd recomputes gelu'(h) inside the fc2 dgrad
- * (cream_linear_dgrad_gelugrad) for blocks with E % 64 == 0; 0: the forward also stores gelu'(h).  Returns the previous
- * setting; on < 0 only queries.  The setting must not change between a forward and its backward.  Initial value:
- * CREAM_GELU_RECOMPUTE in the environment, else 0. */
-int cream_block_gelu_recompute(int on);
 
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).

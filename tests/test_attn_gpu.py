@@ -171,30 +171,27 @@ def test_attention_at_bench_batch_matches_oracle(H):
 @pytest.mark.parametrize("B,H", [(2, 3), (50, 6), (128, 5)])
 def test_kernel_variants_of_the_benchmark_geometry_agree(B, H):
     """The AutoFormer geometry (N = 197, bf16) has two backward implementations (one-pass kernel / two-launch pair,
-    cream_attn_rpe2d_bwd_mode) and two forward ones (register-staged fwd14 / DMA-staged, cream_attn_rpe2d_fwd_mode): on the
-    same inputs the forwards must agree BIT FOR BIT (same algebra, same roundings), the backwards to the reordering of
-    their fp32 sums (one bf16 ulp on dq / dk / dv), a rerun of the one-pass kernel bit for bit; items <
-    compute units, items not a multiple of them, and the benchmark batch."""
+    cream_attn_rpe2d_bwd_mode — the pair is what every other geometry and the fp32 parity mode run): on the same inputs
+    the backwards must agree to the reordering of their fp32 sums (one bf16 ulp on dq / dk / dv), a rerun of the one-pass kernel
+    bit for bit; items < compute units, items not a multiple of them, and the benchmark batch."""
     from cream_amd import _lib
     lib = _lib.load()
     qkv, tabs, go = _inputs(B, H, 14, 14, seed=B + H)
     res = {}
-    prev_f, prev_b = lib.cream_attn_rpe2d_fwd_mode(-1), lib.cream_attn_rpe2d_bwd_mode(-1)
+    prev_b = lib.cream_attn_rpe2d_bwd_mode(-1)
     try:
-        for fm, bm in ((0, 0), (1, 1), (0, 1)):
-            lib.cream_attn_rpe2d_fwd_mode(fm)
+        for bm in (0, 1, 1):
             lib.cream_attn_rpe2d_bwd_mode(bm)
-            res[(fm, bm)] = _fused(qkv, tabs, go, 14, torch.bfloat16)
+            res.setdefault(bm, []).append(_fused(qkv, tabs, go, 14, torch.bfloat16))
     finally:
-        lib.cream_attn_rpe2d_fwd_mode(prev_f)
         lib.cream_attn_rpe2d_bwd_mode(prev_b)
-    out00, g00 = res[(0, 0)]
-    out11, g11 = res[(1, 1)]
-    out01, g01 = res[(0, 1)]
-    assert torch.equal(out00, out11) and torch.equal(out00, out01)          # forward variants: identical bits
-    for a, b in zip(g11, g01):                                              # same backward kernel, identical forward -> identical bits
+    out0, g0 = res[0][0]
+    out1, g1 = res[1][0]
+    out1b, g1b = res[1][1]
+    assert torch.equal(out0, out1) and torch.equal(out1, out1b)             # one forward kernel
+    for a, b in zip(g1, g1b):                                               # the one-pass backward is reproducible
         assert torch.equal(a, b)
-    for i, (a, b) in enumerate(zip(g01, g00)):                              # one-pass vs two-launch
+    for i, (a, b) in enumerate(zip(g1, g0)):                                # one-pass vs two-launch
         assert torch.isfinite(a).all()
         # dqkv (bf16): at most one ulp (2^-8) on the largest elements; the four table gradients (fp32 sums): 2e-3
         assert _rel(a, b) < (8e-3 if i == 0 else 2e-3), (i, _rel(a, b))

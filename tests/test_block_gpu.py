@@ -695,99 +695,6 @@ def test_fp32_layernorm_kernels_match_fp64(M, E, Es):
     assert torch.count_nonzero(dg[E:]) == 0 and torch.count_nonzero(db[E:]) == 0
 
 
-@pytest.mark.parametrize("M,shapes", [
-    (394, [(200, 136, False, 0)]),                                                   # ragged: token tail, N / K edges, one tile each way
-    (25216, [(384, 1344, False, 0), (1344, 384, False, 0), (384, 384, False, 0), (1152, 384, True, 384)]),   # a supernet-S block (E 384, H 6)
-    (25216, [(448, 1792, False, 0), (1792, 448, False, 0), (448, 448, False, 0), (1344, 448, True, 448)]),   # the widest block
-    (3000, [(320, 960, False, 0), (960, 320, True, 320)]),
-    (64, [(128, 128, True, 0)]),                                                     # one step: fewer units than workgroups
-])
-def test_grouped_wgrad_matches_fp64_and_is_reproducible(M, shapes):
-    """cream_wgrad_group (csrc/gemm_mfma.hpp: gemm_tn_group_kernel — all weight gradients of a block in one launch, stream-K
-    ranges, last-arriver reduction in range order) against dy^T x in fp64: added INTO the existing gradient (active slice
-    only, qkv rows through the interleave), bias column sums, bit-identical across repeated launches (fixed summation order
-    whatever the arrival order; counters left zero), nothing written outside the slice."""
-    from cream_amd.autoformer import block as K
-    torch.manual_seed(M)
-    probs, refs = [], []
-    for (N, Kd, bias, inter) in shapes:
-        dy = (torch.randn(M, N, device=DEV) * 0.5).to(torch.bfloat16)
-        x = torch.randn(M, Kd, device=DEV).to(torch.bfloat16)
-        w = torch.nn.Parameter(torch.zeros(N + 24, Kd + 40, device=DEV))
-        b = torch.nn.Parameter(torch.zeros(N + 24, device=DEV)) if bias else None
-        probs.append((dy, x, w, b, inter))
-        refs.append((dy.double().T @ x.double(), dy.double().sum(0)))
-    runs = []
-    for rep in range(3):
-        for (_, _, w, b, _) in probs:
-            w.grad = torch.full_like(w, 0.25)                       # pre-existing gradient: the kernel accumulates
-            if b is not None:
-                b.grad = torch.full_like(b, -0.5)
-        K.wgrad_group(probs)
-        torch.cuda.synchronize()
-        runs.append([(w.grad.clone(), b.grad.clone() if b is not None else None) for (_, _, w, b, _) in probs])
-    assert int(K.wgrad_workspace(torch.device(DEV))[1].abs().sum()) == 0          # counters back to zero
-    worst = 0.0
-    for i, ((dy, x, w, b, inter), (rw, rb)) in enumerate(zip(probs, refs)):
-        N, Kd = dy.shape[1], x.shape[1]
-        gw, gb = runs[0][i]
-        rows = torch.arange(N, device=DEV)
-        rows = 3 * (rows % inter) + rows // inter if inter else rows
-        got = gw[rows][:, :Kd].double() - 0.25
-        worst = max(worst, _rel(got, rw))
-        mask = torch.ones_like(gw, dtype=torch.bool)
-        mask[rows[:, None], torch.arange(Kd, device=DEV)[None, :]] = False
-        assert torch.all(gw[mask] == 0.25), "written outside the active slice"
-        if gb is not None:
-            worst = max(worst, _rel(gb[:N].double() + 0.5, rb))
-            assert torch.all(gb[N:] == -0.5)
-        for rep in (1, 2):
-            assert torch.equal(runs[rep][i][0], gw), "not bit-reproducible"
-            if gb is not None:
-                assert torch.equal(runs[rep][i][1], gb)
-    print(f"[grouped wgrad M={M} {[s[:2] for s in shapes]}] worst rel err vs fp64 {worst:.2e}")
-    assert worst < 2e-5                                             # bf16 operands are exact inputs here; fp32 accumulation over M
-
-
-def test_block_backward_grouped_wgrad_equals_split_k_path():
-    """The optional grouped weight-gradient launch inside the native block backward (block.WGRAD_GROUPED) against the default
-    split-K + finalize path on the same B = 128 block: identical dx, every parameter gradient equal to fp32 summation-order
-    noise (both add exact bf16 x bf16 products in fp32, in different fixed orders), both bit-reproducible."""
-    from cream_amd.autoformer import block as K, engine
-    torch.manual_seed(0)
-    m = engine.build_supernet("S", drop_path_rate=0.0, depth=2).to(DEV)
-    cfg = dict(layer_num=2, embed_dim=[384] * 2, num_heads=[6, 5], mlp_ratio=[3.5, 4.0])
-    m.set_sample_config(cfg)
-    m.train()
-    x = torch.randn(128, 3, 224, 224, device=DEV)
-    t = torch.softmax(torch.randn(128, 1000, device=DEV), -1)
-    res = {}
-    from cream_amd import _lib
-    was = _lib.load().cream_block_wgrad_bf16(0)                    # fp32 partial tiles: this test compares SUMMATION ORDERS
-    try:
-        for grouped in (False, True, True):
-            K.WGRAD_GROUPED = grouped
-            m.zero_grad(set_to_none=False)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = engine.soft_target_cross_entropy(m(x), t)
-            loss.backward()
-            torch.cuda.synchronize()
-            res.setdefault(grouped, []).append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-    finally:
-        K.WGRAD_GROUPED = False
-        _lib.load().cream_block_wgrad_bf16(was)
-    worst = 0.0
-    for k, a in res[False][0].items():
-        b = res[True][0][k]
-        assert torch.equal(res[True][1][k], b), k                  # grouped path reproducible
-        if float(a.abs().max()) == 0.0:
-            assert float(b.abs().max()) == 0.0, k
-            continue
-        worst = max(worst, _rel(b, a))
-    print(f"[grouped vs split-K weight gradients inside the block backward] worst rel difference {worst:.2e}")
-    assert worst < 1e-5
-
-
 def test_bf16_partial_tiles_of_the_weight_gradients_stay_within_their_rounding():
     """cream_block_wgrad_bf16: the split-K partial tiles leave the weight-gradient GEMMs as bf16 (half of the 226 MB of
     partial traffic per block).  Against fp32 partials on the same B = 128 block: every other gradient bit-identical (the
@@ -873,71 +780,6 @@ def test_native_head_matches_fp32_linear():
     assert torch.all(m.head.weight.grad[:, 384:] == 0.5)
 
 
-@pytest.mark.parametrize("M,E,K,ldw,bias,scale", [(197 * 8, 384, 384, 448, True, True), (25216, 448, 448, 448, True, True),
-                                                   (25216, 320, 1120, 1792, True, False), (1000, 192, 32, 40, False, True),
-                                                   (67, 512, 1344, 1344, True, True), (197 * 4, 256, 96, 96, False, False)])
-def test_projection_residual_layernorm_kernel_equals_the_two_kernel_path(M, E, K, ldw, bias, scale):
-    """cream_linear_add_ln_fwd (csrc/gemm_ln.hip: 64 complete rows per workgroup, LayerNorm in the epilogue) against
-    cream_linear_fwd + cream_add_ln_fwd: same MFMA sequence per output, same LayerNorm arithmetic -> identical bits.
-    Ragged M (tail tile), every supported width class, row stride > K, with / without bias and per-sample scale."""
-    from cream_amd.autoformer import block as K_
-    assert K_.linear_add_ln_supported(E, K) and not K_.linear_add_ln_supported(216, K) and not K_.linear_add_ln_supported(E, K + 8)
-    g = torch.Generator(device=DEV).manual_seed(M + E + K)
-    N = 197 if M % 197 == 0 else 7
-    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
-    w = (torch.randn(E + 3, ldw, device=DEV, generator=g) * K ** -0.5).bfloat16()
-    b = torch.randn(E, device=DEV, generator=g).bfloat16() if bias else None
-    x = torch.randn(M, E, device=DEV, generator=g) * 3 + 0.5
-    sc = ((torch.rand((M + N - 1) // N, device=DEV, generator=g) > 0.3).float() / 0.7) if scale else None
-    gamma = torch.randn(E, device=DEV, generator=g)
-    beta = torch.randn(E, device=DEV, generator=g)
-    p = K_.linear_fwd(a, w, b, E, K)
-    want = K_.add_ln_fwd(x, p, sc, N, gamma, beta, 1e-5)
-    got = K_.linear_add_ln_fwd(a, w, b, x, sc, N, gamma, beta, 1e-5, K)
-    torch.cuda.synchronize()
-    for name, u, v in zip(("x1", "y", "mean", "rstd"), got, want):
-        assert torch.equal(u, v), (name, float((u.float() - v.float()).abs().max()))
-    # and against fp32 math on the same bf16 operands
-    ref = x + (sc.repeat_interleave(N)[:M, None] if scale else 1.0) * (a.float() @ w[:E, :K].float().t() + (b.float() if bias else 0)).bfloat16().float()
-    assert _rel(got[0], ref) < 2e-2
-    assert _rel(got[1].float(), F.layer_norm(got[0], (E,), gamma, beta, 1e-5)) < 1e-2
-
-
-def test_native_block_forward_with_fused_projection_layernorm_is_bit_identical():
-    """cream_block_fuse_ln(1): cream_block_fwd runs proj + residual add + ffn_layer_norm as one kernel; outputs and every
-    gradient of a 3-block stack (with drop-path scales) equal the unfused sequencing bit for bit."""
-    from cream_amd import _lib
-    from cream_amd.autoformer import block as K
-    lib = _lib.load()
-    m = _supernet(depth=3).to(DEV)
-    cfg = dict(layer_num=3, embed_dim=[448] * 3, num_heads=[7, 5, 6], mlp_ratio=[4.0, 3.0, 3.5])
-    m.set_sample_config(cfg)
-    m.train()
-    g = torch.Generator(device=DEV).manual_seed(13)
-    B = 4
-    x0 = torch.randn(B, 197, 448, device=DEV, generator=g)
-    scales = (torch.rand(3, 2, B, device=DEV, generator=g) > 0.3).float() / 0.7
-    dout = torch.randn(B, 197, 448, device=DEV, generator=g)
-    blks = list(m.blocks)
-    res = []
-    prev = lib.cream_block_fuse_ln(0)
-    try:
-        for fuse in (0, 1):
-            lib.cream_block_fuse_ln(fuse)
-            m.zero_grad(set_to_none=True)
-            x = x0.clone().requires_grad_()
-            y = K.StackFunction.apply(x, scales, blks)
-            y.backward(dout)
-            torch.cuda.synchronize()
-            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
-                                                             if p.grad is not None}))
-    finally:
-        lib.cream_block_fuse_ln(prev)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    for k, v in res[0][2].items():
-        assert torch.equal(v, res[1][2][k]), k
-
-
 def test_forward_without_backward_skips_the_gelu_derivative_and_gives_the_same_output():
     """A forward that no backward will follow (no_grad evaluation, a frozen teacher): the fc1 epilogue writes gelu(h) only
     (cream_linear_gelu_fwd with gp = NULL, cream_block_desc.inference) — same outputs bit for bit."""
@@ -961,3 +803,101 @@ def test_forward_without_backward_skips_the_gelu_derivative_and_gives_the_same_o
         y_eval = K.StackFunction.apply(x0, None, blks)
     torch.cuda.synchronize()
     assert torch.equal(y_grad.detach(), y_eval)
+
+
+@pytest.mark.parametrize("M,N,K,ldw", [(25216, 1344, 384, 448), (25216, 384, 1344, 1792), (1000, 200, 136, 144),
+                                        (197 * 8, 320, 1120, 1792), (197 * 8, 448, 448, 448)])
+def test_phase_interleaved_nt_kernel_matches_fp32_and_the_two_stage_kernels(M, N, K, ldw):
+    """csrc/gemm_nt8.hpp (cream_gemm_nt8(1): 256 x 256 tile, counted vmcnt, two staggered wave rows, K-tile stream continuous over the
+    output tiles, per-wave epilogue) against plain PyTorch fp32 of the same products (Linear_super.py:38-54, :71-81) and against
+    the two-stage kernels on the same inputs: forward, forward without bias, dgrad, bias + GELU (both outputs) and the
+    x gelu' dgrad with its column sums — row / column edges, K tails (136, 1120 % 64 != 0), several tiles per workgroup
+    (594 at the bench shape), and twice in a row (every launch of a sync-structure change is checked)."""
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K_
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    wsup = (torch.randn(N + 64, ldw, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N + 64, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    gp = torch.rand(M, K, device=DEV, generator=g).bfloat16()
+    W = wsup[:N, :K].float()
+    wt = torch.zeros(ldw, N + 64, device=DEV, dtype=torch.bfloat16)
+    wt[:, :] = wsup.t()
+
+    def run():
+        out = K_.linear_fwd(x, wsup, bias, N, K)
+        out0 = K_.linear_fwd(x, wsup, None, N, K)
+        dx = K_.linear_dgrad(dy, wt, N, K)
+        gpo, go = K_.linear_gelu_fwd(x, wsup, bias, N, K)
+        dh, cs = K_.linear_dgrad_mul(dy, wt, gp, N, K)
+        return out, out0, dx, gpo, go, dh, cs
+
+    was = lib.cream_gemm_nt8(-1)
+    try:
+        lib.cream_gemm_nt8(0)
+        ref = run()
+        lib.cream_gemm_nt8(1)
+        new = run()
+        again = run()
+    finally:
+        lib.cream_gemm_nt8(was)
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)                                           # reproducible (no race between the staggered wave rows)
+    out, out0, dx, gpo, go, dh, cs = new
+    assert _rel(out.float(), x.float() @ W.t() + bias[:N].float()) < 1e-2
+    assert _rel(out0.float(), x.float() @ W.t()) < 1e-2
+    assert _rel(dx.float(), dy.float() @ W) < 1e-2
+    # same products, same accumulation order over K, one rounding: the plain / bias / GELU epilogues agree with the two-stage
+    # kernels to the last bit
+    for a, b in zip(new[:5], ref[:5]):
+        assert torch.equal(a, b)
+    # x gelu': this kernel rounds dy . W to bf16 before the multiplication (as the reference's two operators do), the two-stage
+    # kernel multiplies the fp32 accumulator: one bf16 ulp apart at most, both within 1e-2 of fp32
+    want = (dy.float() @ W) * gp.float()
+    assert _rel(dh.float(), want) < 1e-2 and _rel(dh.float(), ref[5].float()) < 1e-2
+    two_step = ((dy.float() @ W).bfloat16().float() * gp.float()).bfloat16()
+    assert float((dh.float() - two_step.float()).abs().max()) <= 2 ** -7 * float(two_step.float().abs().max())
+    assert cs.shape == ref[6].shape and _rel(cs.sum(0), dh.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(25216, 1344, 384), (25216, 384, 1344), (25216, 1152, 448), (25216, 320, 320), (1000, 328, 264), (394, 200, 136)])
+def test_macro_tile_weight_gradient_kernel_writes_correctly_rounded_partial_tiles(M, N, K):
+    """csrc/gemm_tn8.hpp (cream_linear_wgrad_parts_bf16 called with cream_linear_wgrad_splits_bf16's split count): every bf16
+    partial tile equals the fp32 sum of dy_s^T x_s over ITS token slice rounded once (within one bf16 ulp of the fp64 value), the bias
+    partials add up to the column sums of dy (Linear_super.py:71-81 backward), tiles that stick out of the matrix (N, K not
+    multiples of 256, blocks of 8 columns), token tails (M % 64 != 0), and the 128 x 128 kernel called with the SAME split count
+    writes the same tiles (<= 1 bf16 ulp: same slices, different tile shape)."""
+    import ctypes
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K_
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    dy = (torch.randn(M, N, device=DEV, generator=g) * 0.1).bfloat16()
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    was = lib.cream_gemm_tn8(-1)
+    try:
+        lib.cream_gemm_tn8(2)
+        S = lib.cream_linear_wgrad_splits_bf16(M, N, K)
+        parts, bparts = K_.linear_wgrad_parts(dy, x, want_bias=True, parts_dtype=torch.bfloat16)
+        parts2, _ = K_.linear_wgrad_parts(dy, x, want_bias=False, parts_dtype=torch.bfloat16)
+        assert parts.shape == (S, N, K) and parts.dtype == torch.bfloat16 and bparts.shape == (S, N)
+        assert torch.equal(parts, parts2)                                  # bias partials ride along: same tiles; reproducible
+        lib.cream_gemm_tn8(0)                                              # the 128 x 128 kernel with the same S
+        old = torch.empty_like(parts)
+        _lib.check(lib.cream_linear_wgrad_parts_bf16(old.data_ptr(), ctypes.c_void_p(0), dy.data_ptr(), x.data_ptr(), M, N, K, S,
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "cream_linear_wgrad_parts_bf16")
+    finally:
+        lib.cream_gemm_tn8(was)
+    steps = (M + 63) // 64
+    worst = 0.0
+    for s in range(S):
+        lo, hi = steps * s // S * 64, min(M, steps * (s + 1) // S * 64)
+        want = dy[lo:hi].double().t() @ x[lo:hi].double()
+        err = (parts[s].double() - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -8 + 1e-3).all()), s       # one rounding to bf16 (+ fp32 accumulation noise)
+        worst = max(worst, float((parts[s].float() - old[s].float()).abs().max() / want.abs().max()))
+    assert worst <= 2.0 ** -7
+    assert _rel(bparts.sum(0), dy.float().sum(0)) < 1e-4
+    assert _rel(parts.float().sum(0), dy.float().t() @ x.float()) < 4e-3

@@ -141,19 +141,16 @@ def test_new_entry_points_validate_arguments_without_launching():
     assert 1 <= lib.cream_attn_rpe2d_dtab_parts(128, 6) <= 768
 
 
-def test_shape_predicates_and_switches_without_a_device():
-    """Entry points that take no device pointers: the supported-shape predicate of the fused projection + LayerNorm kernel
-    and the process-wide switches of the block driver (each returns the previous value)."""
+def test_switches_without_a_device():
+    """Entry points that take no device pointers: the process-wide kernel-choice switches (each returns the previous value)."""
     from cream_amd import _lib
     lib = _lib.load()
-    assert lib.cream_linear_add_ln_supported(384, 384) and lib.cream_linear_add_ln_supported(448, 1792)
-    assert lib.cream_linear_add_ln_supported(192, 32) and lib.cream_linear_add_ln_supported(512, 64)
-    assert not lib.cream_linear_add_ln_supported(216, 384)        # supernet-T widths: not a multiple of 64
-    assert not lib.cream_linear_add_ln_supported(576, 384)        # wider than one workgroup's row tile
-    assert not lib.cream_linear_add_ln_supported(384, 40)         # K not a multiple of 32
-    prev = lib.cream_block_fuse_ln(1)
-    assert lib.cream_block_fuse_ln(prev) == 1
-    assert lib.cream_block_fuse_ln(prev) == prev
+    for fn in (lib.cream_gemm_nt8, lib.cream_gemm_tn8, lib.cream_gemm_nt256, lib.cream_block_wgrad_bf16):
+        prev = fn(-1)
+        assert fn(1) == prev and fn(prev) == 1 and fn(-1) == prev
+    # one token slice per workgroup: the macro-tile kernel of the weight gradients takes fewer, longer slices than the 128 x 128 one
+    assert 1 <= lib.cream_linear_wgrad_splits_bf16(25216, 1344, 384) <= lib.cream_linear_wgrad_splits(25216, 1344, 384)
+    assert lib.cream_linear_wgrad_splits_bf16(0, 8, 8) == 0
 
 
 def test_library_has_no_undefined_kernel_stubs():

@@ -39,15 +39,6 @@ __global__ void ref_nt(float* out, NtParams p) {
         s += bfv(p.A[(int64_t)m * p.lda + k]) * bfv(b[(int64_t)(k / p.kseg) * p.kseg_stride + k % p.kseg]);
     out[i] = s;
 }
-__global__ void ref_nt2(float* out, NtParams p) {                 // the second product of EPI_GELUGRAD_COLSUM (plain operands)
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)p.M * p.N) return;
-    const int m = (int)(i / p.N), n = (int)(i % p.N);
-    float s = 0.f;
-    for (int k = 0; k < p.K2; ++k) s += bfv(p.A2[(int64_t)m * p.lda2 + k]) * bfv(p.B2[(int64_t)n * p.ldb2 + k]);
-    out[i] = s;
-}
-__device__ const float* g_ref2 = nullptr;
 // expected outputs of an epilogue from the fp32 reference product; max error against what the kernel wrote
 __global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, int bm) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -66,10 +57,6 @@ __global__ void check_epi(float* maxerr, const float* ref, NtParams p, int epi, 
         (void)hb;
         err = fabsf(g - got2) / (1.f + fabsf(g));
         atomicMax(reinterpret_cast<int*>(maxerr + 1), __float_as_int(err == err ? err : 1e30f));
-    } else if (epi == EPI_GELUGRAD_COLSUM) {
-        const float h = g_ref2[i] + bfv(p.bias[n]);
-        uint32_t hb = __float_as_uint(h); hb += 0x7FFF + ((hb >> 16) & 1); hb &= 0xFFFF0000u;      // bf16 round to nearest even
-        want = n < p.nvalid ? v * gelu_grad_f(__uint_as_float(hb)) : 0.f;
     } else want = v * bfv(p.aux[(int64_t)m * p.ldaux + n]);
     err = fabsf(want - got) / (1.f + fabsf(want));
     atomicMax(reinterpret_cast<int*>(maxerr), __float_as_int(err == err ? err : 1e30f));
@@ -96,8 +83,6 @@ static const Variant VARIANTS[] = {
     V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
     // round 4: the same macro tile with FOUR waves of 128 x 128 (16 accumulator tiles per wave: half the LDS fragment reads per MFMA)
     V(256, 256, 2, 2, 2, EPI_BIAS, 1), V(256, 256, 2, 2, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 2, 2, EPI_MUL_COLSUM, 1),
-    // round 4: fc2 dgrad with the GELU derivative recomputed from a second product over the same tile
-    V(128, 128, 2, 2, 2, EPI_GELUGRAD_COLSUM, 2),
     // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp); prio: 0 none, 1 setprio around the MFMA groups, 2 static for wave row 1; le1: fragment reads waited for before the barrier
     V8(EPI_BIAS, 1, false), V8(EPI_BIAS, 0, false), V8(EPI_BIAS, 2, false), V8(EPI_BIAS, 1, true), V8(EPI_BIAS, 0, true), V8(EPI_BIAS, 2, true),
     V8(EPI_STORE, 0, true), V8(EPI_BIAS_GELU, 0, true), V8(EPI_MUL_COLSUM, 0, true),
@@ -420,12 +405,6 @@ int main(int argc, char** argv)
         p.nseg = s.nseg >= s.N ? s.N : s.nseg; p.nseg_stride = nseg_stride; p.kseg = s.kseg >= s.K ? s.K : s.kseg; p.kseg_stride = kseg_stride;
         p.M = s.M; p.N = s.N; p.K = s.K; p.nvalid = s.N; p.out = dout; p.out2 = dout2; p.ldo = s.N; p.bias = db; p.aux = dh; p.ldaux = s.N; p.colsum = dcs;
         ref_nt<<<(unsigned)((no + 255) / 256), 256>>>(dref, p);
-        // second product of EPI_GELUGRAD_COLSUM: the same activations against the LAST N rows of the weight buffer (a different
-        // matrix), K2 = K rounded down to a multiple of 64
-        float* dref2; CK(hipMalloc(&dref2, no * 4));
-        p.A2 = dx; p.lda2 = s.K; p.B2 = dw + (nw - (size_t)s.N * s.ldb); p.ldb2 = s.ldb; p.K2 = s.K / 64 * 64;
-        ref_nt2<<<(unsigned)((no + 255) / 256), 256>>>(dref2, p);
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ref2), &dref2, sizeof(dref2)));
         CK(hipDeviceSynchronize());
         // the library on the same problem (plain layouts only): col-major C(N x M) = W('t', lda = ldb) . x('n', ldb = K) + bias
         double lib_us = -1;
@@ -472,7 +451,6 @@ int main(int argc, char** argv)
                cold ? "   [cold: rotating operand / output sets]" : "");
         for (const Variant& v : VARIANTS) {
             if (!plain && v.epi != EPI_BIAS) continue;
-            if (v.epi == EPI_GELUGRAD_COLSUM && (s.K % 64 || p.K2 == 0)) continue;
             if (only_var && !strstr(v.name, only_var)) continue;
             CK(hipMemset(dout, 0xFF, no * 2));
             CK(hipMemset(dout2, 0xFF, no * 2));
@@ -481,13 +459,13 @@ int main(int argc, char** argv)
                 if (rep) { CK(hipMemset(dout, 0xFF, no * 2)); CK(hipMemset(dout2, 0xFF, no * 2)); }
                 launch(v, p);
                 check_epi<<<(unsigned)((no + 255) / 256), 256>>>(dmax, dref, p, v.epi, v.bm);
-                if (v.epi == EPI_MUL_COLSUM || v.epi == EPI_GELUGRAD_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
+                if (v.epi == EPI_MUL_COLSUM) check_colsum<<<(((s.M + 127) / 128) * s.N + 255) / 256, 256>>>(dmax, p, 128);
             }
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
             auto rotated = [&](int i) {
                 NtParams q = p;
-                q.A = rx[i % R]; q.A2 = rx[i % R]; q.out = ro[i % R]; q.out2 = ro2[i % R]; q.aux = rh[i % R];
+                q.A = rx[i % R]; q.out = ro[i % R]; q.out2 = ro2[i % R]; q.aux = rh[i % R];
                 return q;
             };
             for (int i = 0; i < 3; ++i) launch(v, rotated(i));
@@ -502,7 +480,7 @@ int main(int argc, char** argv)
             if (getenv("GEMM_PHASES")) phase_profile(v, p);
         }
         for (int r = 1; r < R; ++r) { hipFree(rx[r]); hipFree(ro[r]); hipFree(ro2[r]); hipFree(rh[r]); hipFree(rl[r]); }
-        hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dref2); hipFree(dh); hipFree(dcs);
+        hipFree(dx); hipFree(dw); hipFree(db); hipFree(dout); hipFree(dout2); hipFree(dlib); hipFree(dref); hipFree(dh); hipFree(dcs);
         fflush(stdout);
     }
     return 0;
