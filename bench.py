@@ -317,6 +317,14 @@ def pmc_kernels(pattern):
     return dict(source=os.path.relpath(files[-1], ROOT), kernels=out) if out else None
 
 
+def native_kernel_choice():
+    """the process-wide kernel-choice switches of the library as the timed region ran them (include/cream_amd.h)"""
+    from cream_amd import _lib
+    lib = _lib.load()
+    return {"cream_gemm_nt8": lib.cream_gemm_nt8(-1), "cream_gemm_nt256": lib.cream_gemm_nt256(-1), "cream_gemm_tn8": lib.cream_gemm_tn8(-1),
+            "cream_block_wgrad_bf16": lib.cream_block_wgrad_bf16(-1), "cream_attn_rpe2d_bwd_mode": lib.cream_attn_rpe2d_bwd_mode(-1)}
+
+
 def native_prof_summary():
     """Collect the in-step HIP-event records of csrc/block_seq.cpp -> {name: dict(launches, total_ms, avg_ms, flops, bytes)}."""
     import ctypes
@@ -616,7 +624,8 @@ def main():
             roof["timing"] = ("in-step: a start / stop HIP event pair carried by each kernel's own dispatch packet (hipExtLaunchKernelGGL, "
                               "csrc/launch_ev.hpp) inside the native block calls, on the kernel's launch stream, two streams live; "
                               f"{nprof} steps right after the timed region at {round(prof_ms_per_step, 3)} ms/step with the events in place; "
-                              "multi-kernel operators are timed on their last kernel")
+                              "multi-kernel operators are timed on their last kernel; the pass with events runs ~10 % slower per step than "
+                              "the timed region, so these per-kernel rates are slightly pessimistic (they agree with rocprofv3's)")
             roof["kernels"] = {k: dict(launches=v["launches"], avg_us=round(v["avg_ms"] * 1e3, 2),
                                        total_ms=round(v["total_ms"], 3), ms_per_step=round(v["total_ms"] / nprof, 3),
                                        tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
@@ -650,7 +659,10 @@ def main():
                                 # what RCCL was told (unset = library defaults): read a SCALE record against these
                                 "rccl_env": {k: os.environ[k] for k in sorted(os.environ)
                                              if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG")}},
-                       "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp), no vendor GEMM library"},
+                       "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp, gemm_nt8.hpp, gemm_tn8.hpp), no vendor GEMM library",
+                       "wgrad_partials": "bf16 token-sliced partial tiles of the weight gradients, added in fp32 in fixed order "
+                                         "(cream_block_wgrad_bf16; within 1.9e-3 of fp32 partials, tests/test_block_gpu.py)",
+                       "kernel_choice": native_kernel_choice()},
             "roofline": roof,
             # whole-step algorithmic rate PER GPU from the FLOPs of the sub-networks actually sampled in the timed region
             # (SURVEY 8d formula, step_flops_per_image), not from the search-space mean

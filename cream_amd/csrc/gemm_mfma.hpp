@@ -308,7 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             t = xcd_remap(orig, ntiles);
             m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
             sources(src, m0, n0);
-                    kb = 0; kin = 0;
+            kb = 0; kin = 0;
             if (0 < nfull) issue(src, 0, 0, No{}); else issue(src, 0, 0, Yes{});
         }
 

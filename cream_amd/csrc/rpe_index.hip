@@ -28,6 +28,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -608,6 +609,8 @@ int launch_gather(void* y, const void* in, const int32_t* idx, int B, int H, int
     //   bf16  NV = 4, G = 8,  768 threads  4.5 TB/s   (3.3)
     {
         constexpr int NV = 4, NS = 4;
+        // (round 5 re-sweep in the product path, profiles/r05_rpe_gather_sweep.txt: G 2..32 x 512 / 768 / 1024 threads — fp32
+        //  0.557-0.604 of the HBM peak with G = 2, 1024 threads at 0.596; bf16 best at G = 8, 768 threads: the choice stands)
         const int thr = BYTES == 2 ? 768 : 1024, G = BYTES == 2 ? 8 : 2;
         int64_t rows = std::min<int64_t>(Lq, (int64_t)NV * thr * V / Lk);      // NV vectors per thread cover the row block
         rows = std::min<int64_t>(rows, (int64_t)NS * thr / nb);                 // NS staged lookup values per thread

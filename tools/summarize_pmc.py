@@ -9,14 +9,20 @@ import os
 import re
 import sys
 
-PAT = re.compile(r"(gemm_nt_kernel<[^>]*>|gemm_tn_kernel<[^>]*>|attn_rpe2d_\w+_kernel|ln_\w+_kernel|adamw_mirror_kernel|"
+PAT = re.compile(r"(gemm_nt_kernel<[^>]*>|gemm_tn_kernel<[^>]*>|gemm_nt8_kernel<[^>]*>|gemm_tn8_kernel<[^>]*>|attn_rpe2d_\w+_kernel|ln_\w+_kernel|adamw_mirror_kernel|"
                  r"grad_finalize_kernel|rpe_gather_planes?<[^>]*>|rpe_scatter_planes|irpe_attn_\w+_kernel<[^>]*>|irpe_table_grad_kernel)")
 EPI = {"0": "store", "1": "bias", "2": "bias+gelu (two outputs)", "3": "x gelu' + column sums"}
-FAMILY = {"gemm_nt": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() in ("0", "1"),
-          "gemm_nt_gelu": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() == "2",
-          "gemm_nt_mul": lambda k: k.startswith("gemm_nt_kernel") and k.split(",")[5].strip() == "3",
-          "gemm_tn_wgrad": lambda k: k.startswith("gemm_tn_kernel"),
-          "attn_rpe2d_fwd": lambda k: k in ("attn_rpe2d_fwd_kernel", "attn_rpe2d_fwd14_kernel", "attn_rpe2d_fwd1_kernel"),
+def _epi(k):
+    """epilogue template argument of an NT kernel name: 6th of gemm_nt_kernel<...>, 1st of gemm_nt8_kernel<...>"""
+    p = [x.strip() for x in k[k.index("<") + 1:-1].split(",")]
+    return p[0] if k.startswith("gemm_nt8_kernel") else p[5]
+
+
+FAMILY = {"gemm_nt": lambda k: k.startswith(("gemm_nt_kernel", "gemm_nt8_kernel")) and _epi(k) in ("0", "1"),
+          "gemm_nt_gelu": lambda k: k.startswith(("gemm_nt_kernel", "gemm_nt8_kernel")) and _epi(k) == "2",
+          "gemm_nt_mul": lambda k: k.startswith(("gemm_nt_kernel", "gemm_nt8_kernel")) and _epi(k) == "3",
+          "gemm_tn_wgrad": lambda k: k.startswith(("gemm_tn_kernel", "gemm_tn8_kernel")),
+          "attn_rpe2d_fwd": lambda k: k in ("attn_rpe2d_fwd_kernel", "attn_rpe2d_fwd14_kernel"),
           # the one-pass backward (round 4) is ONE kernel per launch of the region; the two-launch pair only when it is absent
           "attn_rpe2d_bwd": lambda k: k == "attn_rpe2d_bwd1_kernel",
           "attn_rpe2d_bwd_pair": lambda k: k in ("attn_rpe2d_bwd_q_kernel", "attn_rpe2d_bwd_kv_kernel")}
@@ -41,6 +47,10 @@ def main():
         if k.startswith("gemm_nt_kernel"):
             p = [x.strip() for x in k[k.index("<") + 1:-1].split(",")]
             rec["tile"], rec["epilogue"] = f"{p[0]}x{p[1]}", EPI.get(p[5], p[5])
+        if k.startswith("gemm_nt8_kernel"):
+            rec["tile"], rec["epilogue"] = "256x256 (phase-interleaved loop)", EPI.get(_epi(k), _epi(k))
+        if k.startswith("gemm_tn8_kernel"):
+            rec["tile"] = "256x256 (phase-interleaved loop, bf16 partial tiles)"
         if "FETCH_SIZE" in mean:
             rec["hbm_read_MB_corrected"] = round(mean["FETCH_SIZE"] * 2 / 1024, 1)
         if "WRITE_SIZE" in mean:

@@ -18,8 +18,8 @@ def short(name):
 def category(k):
     if k.startswith("hipBLASLt GEMM") or "Cijk_" in k:
         return "GEMM library (hipBLASLt)"
-    if "gemm_nt_kernel" in k or "gemm_tn_kernel" in k:
-        return "GEMM (csrc/gemm_mfma.hpp, hand-written MFMA)"
+    if "gemm_nt_kernel" in k or "gemm_tn_kernel" in k or "gemm_nt8_kernel" in k or "gemm_tn8_kernel" in k:
+        return "GEMM (csrc/gemm_mfma.hpp, gemm_nt8.hpp, gemm_tn8.hpp: hand-written MFMA)"
     if "adamw_mirror" in k:
         return "optimizer + bf16 operand refresh (csrc/optim.hip)"
     if "attn_rpe2d" in k:
