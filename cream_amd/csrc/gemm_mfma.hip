@@ -363,11 +363,11 @@ int wgrad_parts_any(float* parts, uint16_t* parts16, float* bias_parts, const vo
     TnParams p{(const uint16_t*)dy, (const uint16_t*)x, N, K, M, N, K, S, parts, bias_parts, parts16};
     if (parts16 && tn8_wanted(M, N, K) && S == tn8_splits(M, N, K)) {
         if (bias_parts) {
-            auto kern = gemm_tn8_kernel<0, true>;
+            auto kern = gemm_tn8_kernel<true>;
             if (!cream::raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
             CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
         } else {
-            auto kern = gemm_tn8_kernel<0, false>;
+            auto kern = gemm_tn8_kernel<false>;
             if (!cream::raise_dynamic_lds(kern, TN8_LDS_BYTES)) return CREAM_ERR_LAUNCH;
             CREAM_LAUNCH(kern, dim3(tn8_tiles(N, K) * S), dim3(512), TN8_LDS_BYTES, (hipStream_t)stream, p);
         }

@@ -24,7 +24,7 @@
 //       phase 3  C11 = A_q1 . B_q1     reads A_q1 (8)
 //       phase 4  C10 = A_q1 . B_q0     reads nothing (B_q0 stayed in registers)
 //     Every phase is  { stage one half-tile (2 LDS-DMA per wave) | fragment reads | s_waitcnt vmcnt(8) } -> s_barrier ->
-//     lgkmcnt(0) -> setprio 1 -> 8 MFMA -> setprio 0 -> s_barrier.  The waves of wave row 1 run ONE BARRIER behind
+//     lgkmcnt(0) -> 8 MFMA -> s_barrier.  The waves of wave row 1 run ONE BARRIER behind
 //     those of wave row 0 (waves w and w + 4 share a SIMD): while one wave of a SIMD multiplies, the other one reads
 //     fragments and issues loads — the matrix pipe alternates between them instead of idling behind either's memory.
 //   * the half-tiles are requested in the order they are needed, one per phase, into slots that died two phases
@@ -89,9 +89,9 @@ __device__ __forceinline__ void nt8_dma2(const void* base, uint32_t off0, uint32
                  : "=&s"(keep) : "v"(off0), "v"(off1), "s"(lds_dst), "s"(base) : "memory", "scc");
 }
 
-// PRIO: 0 = no priority changes, 1 = s_setprio 1 around every MFMA group, 2 = static s_setprio 1 for wave row 1 (the younger half)
-// LGKM_EARLY: the fragment reads are waited for BEFORE the first barrier of a phase (inside the load segment) instead of after it
-template <int EPI, int PRIO = 1, bool LGKM_EARLY = false>
+// (Measured and dropped, profiles/r05b_gemm_probe_cold_variants.txt + r05_nt8_phase_trace.txt: s_setprio 1 around every MFMA group and a
+//  static s_setprio 1 for wave row 1 — no change; waiting for the fragment reads BEFORE the first barrier of a phase — 2-3 % slower.)
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const NtParams p)
 {
     constexpr bool STORE_AWARE = true;                           // (measured: 2-3 % over waiting for the epilogue's stores)
@@ -202,10 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const NtParams p)
     wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
     NT8_PROF(1);
-    if (wr == 1) {
-        __builtin_amdgcn_s_barrier();                            // wave row 1 runs one barrier behind wave row 0
-        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();                   // wave row 1 runs one barrier behind wave row 0
     __builtin_amdgcn_sched_barrier(0);
 
     uint32_t c_par = 0;                                          // LDS buffer of the K-tile being multiplied
@@ -225,16 +222,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const NtParams p)
     do {                                                                                         \
         if (counted) { if (pre) wait_vmcnt<8 + NS + NPRE>(); else wait_vmcnt<8 + NS>(); }        \
         else { if (pre) wait_vmcnt<8 + NPRE>(); else wait_vmcnt<8>(); }                          \
-        if (LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
         __builtin_amdgcn_s_barrier();                                                            \
-        if (!LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NT8_STAMP();                                                                             \
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                            \
     } while (0)
 #define NT8_POST()                                                                               \
     do {                                                                                         \
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NT8_STAMP();                                                                             \
         __builtin_amdgcn_s_barrier();                                                            \

@@ -36,7 +36,7 @@ constexpr int TN8_LDS_BYTES = 2 * 65536;
 // BIAS: bias_parts[split][n] = column sums of dY over the split's tokens (F.linear's bias gradient) ride along as MFMAs against a
 // ones fragment, in the workgroups of the first column tile only: wave column 0 sums row block tm 0 in phase 4, wave column 1
 // row block tm 1 in phase 3 (the two phases without Y reads; both waves of a wave row hold both Y fragments anyway).
-template <int PRIO = 0, bool BIAS = false>
+template <bool BIAS = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const TnParams p)
 {
     constexpr uint32_t SLOT = 16384, KTB = 65536;
@@ -123,10 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const TnParams p)
     stage(W_Y0{}); stage(W_X0{});
     wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) {
-        __builtin_amdgcn_s_barrier();                            // waves 4-7 run one barrier behind waves 0-3
-        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();                  // waves 4-7 run one barrier behind waves 0-3
     __builtin_amdgcn_sched_barrier(0);
 
 #define TN8_PRE()                                                                                \
@@ -135,11 +132,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const TnParams p)
         __builtin_amdgcn_s_barrier();                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                            \
     } while (0)
 #define TN8_POST()                                                                               \
     do {                                                                                         \
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_barrier();                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \

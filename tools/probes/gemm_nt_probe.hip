@@ -74,7 +74,7 @@ __global__ void check_colsum(float* maxerr, NtParams p, int bm) {
 
 
 struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); int nt8 = 0; };
-#define V8(EPI, PRIO, LE) {"nt8 256x256 " #EPI " prio" #PRIO " le" #LE, 256, 256, 512, EPI, gemm_nt8_kernel<EPI, PRIO, LE>, 1}
+#define V8(EPI) {"nt8 256x256 phase-interleaved " #EPI, 256, 256, 512, EPI, gemm_nt8_kernel<EPI>, 1}
 #define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
 static const Variant VARIANTS[] = {
     V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3),
@@ -83,9 +83,8 @@ static const Variant VARIANTS[] = {
     V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
     // round 4: the same macro tile with FOUR waves of 128 x 128 (16 accumulator tiles per wave: half the LDS fragment reads per MFMA)
     V(256, 256, 2, 2, 2, EPI_BIAS, 1), V(256, 256, 2, 2, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 2, 2, EPI_MUL_COLSUM, 1),
-    // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp); prio: 0 none, 1 setprio around the MFMA groups, 2 static for wave row 1; le1: fragment reads waited for before the barrier
-    V8(EPI_BIAS, 1, false), V8(EPI_BIAS, 0, false), V8(EPI_BIAS, 2, false), V8(EPI_BIAS, 1, true), V8(EPI_BIAS, 0, true), V8(EPI_BIAS, 2, true),
-    V8(EPI_STORE, 0, true), V8(EPI_BIAS_GELU, 0, true), V8(EPI_MUL_COLSUM, 0, true),
+    // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp)
+    V8(EPI_BIAS), V8(EPI_STORE), V8(EPI_BIAS_GELU), V8(EPI_MUL_COLSUM),
 };
 static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 512 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
@@ -297,7 +296,7 @@ static void tn_tests(const char* only) {
             const int S8 = std::max(1, tn8_splits(t.M, t.N, t.K) / sdiv);
             uint16_t* d16; CK(hipMalloc(&d16, nw * 2 * S8));
             TnParams q8{dy, dx, t.N, t.K, t.M, t.N, t.K, S8, nullptr, prio ? dbias8 : nullptr, d16};
-            auto k8 = prio ? gemm_tn8_kernel<0, true> : gemm_tn8_kernel<0, false>;
+            auto k8 = prio ? gemm_tn8_kernel<true> : gemm_tn8_kernel<false>;
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, TN8_LDS_BYTES));
             const int T8 = ((t.N + 255) / 256) * ((t.K + 255) / 256), grid8 = T8 * S8;
             float hm[4] = {0, 0, 0, 0};

@@ -37,14 +37,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), N * 2, hipMemcpyHostToDevice));
     NtParams p{};
     p.A = dx[0]; p.lda = K; p.B = dw; p.ldb = K; p.nseg = N; p.kseg = K; p.M = M; p.N = N; p.K = K; p.nvalid = N; p.out = dout[0]; p.ldo = N; p.bias = db;
-#ifndef NT8_PRIO
-#define NT8_PRIO 1
-#endif
-#ifndef NT8_LE
-#define NT8_LE false
-#endif
-    auto kern = gemm_nt8_kernel<EPI_BIAS, NT8_PRIO, NT8_LE>;
-    printf("variant: prio %d, lgkm early %d\n", NT8_PRIO, (int)NT8_LE);
+    auto kern = gemm_nt8_kernel<EPI_BIAS>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NT8_LDS_BYTES));
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256), grid = tiles > 256 ? 256 : tiles;
     unsigned long long* dtr; CK(hipMalloc(&dtr, (size_t)grid * 8 * 512 * 8)); CK(hipMemset(dtr, 0, (size_t)grid * 8 * 512 * 8));
