@@ -24,6 +24,11 @@
 //     five phases after its request;
 //   * the partial tile leaves straight from the accumulators: bf16 pairs, v_permlane32_swap to 16-byte chunks, 16-byte stores.
 //
+// Measured and dropped (profiles/r05_tn8_classes.md): a slice count per tile class (cheap last-row / last-column tiles get fewer
+// slices) and a two-phase loop over three half-tiles for tiles of at most 128 rows or columns — 5-25 % shorter in the cold probe,
+// +1.2 % / +-0 on the training step (more partial tiles through HBM; the early-finishing workgroups were handing their CUs to the
+// main chain anyway).
+//
 // Limits (the launcher keeps gemm_tn_kernel otherwise): bf16 partials, no bias partials, N % 8 == 0, K % 8 == 0.
 #pragma once
 #include "gemm_nt8.hpp"

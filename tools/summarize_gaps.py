@@ -7,6 +7,15 @@ import sys
 from collections import defaultdict
 
 
+def short(name):
+    name = name.replace("cream::gemm::", "").replace("void ", "")
+    for a, b in (("vectorized_elementwise_kernel<4, FillFunctor<float>", "torch fill<float>"), ("__amd_rocclr_", "rocclr_")):
+        if name.startswith(a):
+            return b
+    cut = name.find("(")
+    return (name[:cut] if cut > 0 else name)[:56]
+
+
 def main(path, skip=0):
     rows = list(csv.DictReader(open(path)))
     key = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
@@ -28,6 +37,15 @@ def main(path, skip=0):
         print(f"queue {q}: {len(ks)} kernels, busy {1e-6 * busy:.2f} ms, gaps < 20 us: n = {len(small)}, total {1e-6 * sum(small):.3f} ms, "
               f"median {sorted(small)[len(small) // 2] / 1e3 if small else 0:.2f} us; larger gaps total {1e-6 * (sum(gaps) - sum(small)):.2f} ms")
         print("   gap histogram (us: count): " + ", ".join(f"{k}-{k + 1}: {v}" for k, v in sorted(hist.items())))
+        # which (previous -> next) kernel pairs the gaps of 2-20 us sit between
+        pairs = defaultdict(lambda: [0, 0])
+        for i, g in enumerate(gaps):
+            if 2000 <= g < 20000:
+                k = (short(ks[i][2]), short(ks[i + 1][2]))
+                pairs[k][0] += 1
+                pairs[k][1] += g
+        for (a, b), (n, tot) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:24]:
+            print(f"      {n:5d} x {tot / n / 1e3:5.2f} us = {tot / 1e6:6.3f} ms   {a}  ->  {b}")
     # union of busy intervals over all queues
     ev = sorted((s, e) for _, s, e, _ in rows)
     cov, cur_s, cur_e = 0, ev[0][0], ev[0][1]
