@@ -306,6 +306,33 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
+# The main stream has to wait for the weight-gradient stream once per backward pass.  Done right behind the first block's backward
+# the wait exposes the side stream's tail (the first block's qkv weight gradient and finalisation start when the main chain is
+# almost through: ~50 us per step in the kernel trace, profiles/r05_step_tail.md) while the stem's backward — which needs nothing from
+# the side stream — queues up behind it.  Deferred to autograd's end-of-pass callback (the hook DistributedDataParallel finalises
+# its buckets from) the stem's backward runs under that tail.  CREAM_DEFER_JOIN=0: wait where the blocks end.
+DEFER_JOIN = os.environ.get('CREAM_DEFER_JOIN', '1') != '0'
+
+
+def join_side_stream_at_end_of_backward(device, held=()):
+    """`held`: tensors the side stream may still be reading when the caller returns (allocated on the main stream).  The callback
+    keeps them referenced until the join is on the main stream, so the caching allocator cannot hand them to the kernels that now
+    run before it (record_stream would do, but it defers the reuse to an event query at the next allocation: measured 5-20 %
+    slower per step).  One callback per call, no state: a backward pass that raises leaves nothing behind."""
+    if not WGRAD_SIDE_STREAM:
+        return
+    if not DEFER_JOIN:
+        join_side_stream(device)
+        return
+    held = list(held)
+
+    def _join():
+        join_side_stream(device)
+        held.clear()
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
 def finalize_on_side_stream(jobs, blk, tensors):
     """The finalisation of the block's gradients and their announcement to the reducer, on the side stream: the main
     stream goes straight on to the previous block.  `tensors`: everything the side stream reads — they were allocated on
@@ -1213,7 +1240,7 @@ class StackFunction(torch.autograd.Function):
             prev_scale = scales[i - 1, 1] if (scales is not None and i > 0) else None
             dx, df, pb2 = _block_backward(blks[i], ctx.dims[i], dp1, tens[i * ns:(i + 1) * ns], dx, df, pb2,
                                           prev_scale, i > 0)
-        join_side_stream(dx.device)           # every parameter gradient of the run is complete
+        join_side_stream_at_end_of_backward(dx.device)   # every parameter gradient of the run is complete when the pass ends
         return (dx.view(B, N, E), None, None) + (None, None, None)[:ctx.ntail]
 
     @staticmethod
@@ -1290,7 +1317,8 @@ class StackFunction(torch.autograd.Function):
                     _notify(blks[i])
             dx, df = wp + off_dx, wp + off_dfp
             pb2, pb2_parts, pb2_stride = wp + off_pl1 + 2 * E * 4, lib.cream_ln_partials(), 3 * E
-        join_side_stream(dev)                 # every parameter gradient of the run is complete
+        # (the side stream reads the backward workspaces AND the saved forward workspaces; both are released when this returns)
+        join_side_stream_at_end_of_backward(dev, keep + [t for t in tens if t is not None and t.is_cuda])
         out = ws[off_dx:off_dx + M * E * 4].view(torch.float32).view(B, N, E)
         return (out, None, None) + (tail_grads[0], tail_grads[1], None)[:ctx.ntail]
 

@@ -46,6 +46,17 @@ def main(path, skip=0):
                 pairs[k][1] += g
         for (a, b), (n, tot) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:24]:
             print(f"      {n:5d} x {tot / n / 1e3:5.2f} us = {tot / 1e6:6.3f} ms   {a}  ->  {b}")
+        # the waits of this queue for the other one (or for the host): gaps of 20 us .. 3 ms by pair
+        waits = defaultdict(lambda: [0, 0])
+        for i, g in enumerate(gaps):
+            if 20000 <= g < 3000000:
+                k = (short(ks[i][2]), short(ks[i + 1][2]))
+                waits[k][0] += 1
+                waits[k][1] += g
+        if waits:
+            print("   waits of 20 us .. 3 ms:")
+        for (a, b), (n, tot) in sorted(waits.items(), key=lambda kv: -kv[1][1])[:12]:
+            print(f"      {n:5d} x {tot / n / 1e3:7.1f} us = {tot / 1e6:6.3f} ms   {a}  ->  {b}")
     # union of busy intervals over all queues
     ev = sorted((s, e) for _, s, e, _ in rows)
     cov, cur_s, cur_e = 0, ev[0][0], ev[0][1]
