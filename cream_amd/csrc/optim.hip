@@ -48,54 +48,73 @@ __global__ __launch_bounds__(256) void adamw_mirror_kernel(const cream_param_job
     const int c = c0 + cq * 4;
     const bool upd = update && jb.g != nullptr;
     const float decay = 1.f - lr * jb.weight_decay, step = lr * inv_bc1;
+    // three passes at a time: all twelve 16-byte loads of the three row groups are in flight before the first store (the parameter,
+    // moment and gradient pointers may alias as far as the compiler knows, so it would not move a load across a store itself)
+    const bool vec = (jb.ld & 3) == 0;
 #pragma unroll
-    for (int pass = 0; pass < TR / 16; ++pass) {
-        const int lr_ = pass * 16 + rr, r = r0 + lr_;
-        float v4[4] = {0, 0, 0, 0};
-        if (r < jb.rows && c < jb.cols) {
-            const int64_t o = (int64_t)r * jb.ld + c;
-            const int nv = min(4, jb.cols - c);
-            if (nv == 4 && (jb.ld & 3) == 0) {
-                f32x4v pv = *reinterpret_cast<const f32x4v*>(jb.p + o);
+    for (int pass0 = 0; pass0 < TR / 16; pass0 += 3) {
+        f32x4v pv[3], gv[3], mv[3], vv[3];
+        bool fast[3], in[3];
+        int64_t o[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int r = r0 + (pass0 + u) * 16 + rr;
+            in[u] = r < jb.rows && c < jb.cols;
+            o[u] = (int64_t)r * jb.ld + c;
+            fast[u] = in[u] && vec && c + 4 <= jb.cols;
+            pv[u] = f32x4v{0, 0, 0, 0};
+            if (fast[u]) {
+                pv[u] = *reinterpret_cast<const f32x4v*>(jb.p + o[u]);
                 if (upd) {
-                    const f32x4v gv = *reinterpret_cast<const f32x4v*>(jb.g + o);
-                    f32x4v mv = *reinterpret_cast<const f32x4v*>(jb.m + o), vv = *reinterpret_cast<const f32x4v*>(jb.v + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pv[e] *= decay;
-                        mv[e] = mv[e] + (gv[e] - mv[e]) * omb1;
-                        vv[e] = beta2 * vv[e] + omb2 * gv[e] * gv[e];
-                        pv[e] -= step * mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
-                    }
-                    *reinterpret_cast<f32x4v*>(jb.p + o) = pv;
-                    *reinterpret_cast<f32x4v*>(jb.m + o) = mv;
-                    *reinterpret_cast<f32x4v*>(jb.v + o) = vv;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = pv[e];
-            } else {
-                for (int e = 0; e < nv; ++e) {
-                    float pv = jb.p[o + e];
-                    if (upd) {
-                        const float gv = jb.g[o + e];
-                        float mv = jb.m[o + e], vv = jb.v[o + e];
-                        pv *= decay;
-                        mv = mv + (gv - mv) * omb1;
-                        vv = beta2 * vv + omb2 * gv * gv;
-                        pv -= step * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
-                        jb.p[o + e] = pv; jb.m[o + e] = mv; jb.v[o + e] = vv;
-                    }
-                    v4[e] = pv;
+                    gv[u] = *reinterpret_cast<const f32x4v*>(jb.g + o[u]);
+                    mv[u] = *reinterpret_cast<const f32x4v*>(jb.m + o[u]);
+                    vv[u] = *reinterpret_cast<const f32x4v*>(jb.v + o[u]);
                 }
             }
         }
-        if (jb.mir) {
-            // LDS row: parts grouped (row 3 i + j -> j * 32 + i) so that the transposed copy below writes
-            // 8 consecutive outputs of ONE part
-            const int srow = jb.deinterleave ? (lr_ % 3) * (TR / 3) + lr_ / 3 : lr_;
-            uint16_t* d = tile + srow * LP + cq * 4;
-            *reinterpret_cast<uint32_t*>(d) = f2bf_pair(v4[0], v4[1]);
-            *reinterpret_cast<uint32_t*>(d + 2) = f2bf_pair(v4[2], v4[3]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int lr_ = (pass0 + u) * 16 + rr;
+            float v4[4] = {0, 0, 0, 0};
+            if (fast[u]) {
+                if (upd) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[u][e] *= decay;
+                        mv[u][e] = mv[u][e] + (gv[u][e] - mv[u][e]) * omb1;
+                        vv[u][e] = beta2 * vv[u][e] + omb2 * gv[u][e] * gv[u][e];
+                        pv[u][e] -= step * mv[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + eps);
+                    }
+                    *reinterpret_cast<f32x4v*>(jb.p + o[u]) = pv[u];
+                    *reinterpret_cast<f32x4v*>(jb.m + o[u]) = mv[u];
+                    *reinterpret_cast<f32x4v*>(jb.v + o[u]) = vv[u];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = pv[u][e];
+            } else if (in[u]) {
+                const int nv = min(4, jb.cols - c);
+                for (int e = 0; e < nv; ++e) {
+                    float p1 = jb.p[o[u] + e];
+                    if (upd) {
+                        const float g1 = jb.g[o[u] + e];
+                        float m1 = jb.m[o[u] + e], v1 = jb.v[o[u] + e];
+                        p1 *= decay;
+                        m1 = m1 + (g1 - m1) * omb1;
+                        v1 = beta2 * v1 + omb2 * g1 * g1;
+                        p1 -= step * m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps);
+                        jb.p[o[u] + e] = p1; jb.m[o[u] + e] = m1; jb.v[o[u] + e] = v1;
+                    }
+                    v4[e] = p1;
+                }
+            }
+            if (jb.mir) {
+                // LDS row: parts grouped (row 3 i + j -> j * 32 + i) so that the transposed copy below writes
+                // 8 consecutive outputs of ONE part
+                const int srow = jb.deinterleave ? (lr_ % 3) * (TR / 3) + lr_ / 3 : lr_;
+                uint16_t* d = tile + srow * LP + cq * 4;
+                *reinterpret_cast<uint32_t*>(d) = f2bf_pair(v4[0], v4[1]);
+                *reinterpret_cast<uint32_t*>(d + 2) = f2bf_pair(v4[2], v4[3]);
+            }
         }
     }
     if (!jb.mir) return;
