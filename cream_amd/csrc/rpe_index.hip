@@ -51,6 +51,16 @@ template <> struct raw_elem<8> { using type = uint64_t; using vec = vec16_a8; };
 
 constexpr int WAVE = 64;
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a release fence for global memory as well: hipcc puts
+// s_waitcnt vmcnt(0) in front of it, so every barrier of a store loop would wait until all stores issued so far are ACKNOWLEDGED —
+// the write stream of the gather kernels drained once per plane.  Nothing here ever reads what the kernel itself stores.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------
 // forward: gather
 // ------------------------------------------------------------------------------------
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(1024) void rpe_gather_planes(
     for (int g = 0; g < G; ++g) {
         const int p = p0 + period * g;
         if (p >= BH) break;
-        __syncthreads();                                       // table g staged; table g - 1 no longer read
+        lds_barrier();                                         // table g staged; table g - 1 no longer read
         const bool more = g + 1 < G && p + period < BH;
         if (more) request(p + period);
         const unsigned char* tb = smem + (g & 1) * tstride;
@@ -264,13 +274,26 @@ __global__ __launch_bounds__(1024) void rpe_gather_planes(
                 union { u32x4 vec; E e[V]; } pk;
 #pragma unroll
                 for (int e = 0; e < V; ++e) pk.e[e] = *reinterpret_cast<const E*>(tb + toff[k][e]);
-                *reinterpret_cast<u32x4*>(ov + (int64_t)k * NT * V) = pk.vec;     // 16-byte aligned
+                // 16-byte aligned; nt: +5 % for bf16 (4.29 -> 4.50 TB/s), neutral for fp32; sc1 / sc0 sc1 (line dropped from L2 at once,
+                // which would keep the id matrix resident) run at 2.7 TB/s — profiles/r05_rpe_gather_policy_sweep.txt
+                __builtin_nontemporal_store(pk.vec, reinterpret_cast<u32x4*>(ov + (int64_t)k * NT * V));
             }
         }
         if (more) commit((g + 1) & 1);
     }
 }
 
+// (Round 5, measured and dropped — profiles/r05_rpe_gather.md: a "frontier" kernel in which every workgroup owns a fixed slice of
+//  EVERY plane and the whole chip writes `period` neighbouring planes at a time, ids once per launch in registers: 3.4-4.1 TB/s; with
+//  the gathers and the table staging compiled out its bare store stream — 1 KB per wave and plane, then a jump of `period` planes —
+//  still needs 228-267 us where a fill of the buffer needs 149.  What the fill has is not the frontier but short-lived workgroups that
+//  each write one contiguous 16 KB piece and leave.)
+//
+// (Also measured and dropped: "tiles" — the fill's own pattern, one short-lived 256-thread workgroup per contiguous 16 KB piece of one
+//  plane, ids from a byte copy of the id matrix (1 byte per element from L2, one aligned V-byte load per vector): bit-identical,
+//  4.1 TB/s fp32 / 3.2 bf16.  A workgroup that has to LOAD before it can store lives ~9 us; the fill's lives ~1.  Both kernels are kept
+//  in tools/probes/rpe_probe.hip.)
+//
 // Shape-generic fallback (very long rows or very many buckets): one thread per output
 // element, index re-read from L2.  Correct for every shape; not the measured path.
 template <int BYTES>
