@@ -79,6 +79,8 @@ struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtPar
 static const Variant VARIANTS[] = {
     V(128, 128, 2, 2, 2, EPI_BIAS, 2), V(128, 64, 2, 2, 2, EPI_BIAS, 3), V(64, 128, 2, 2, 2, EPI_BIAS, 3),
     V(128, 128, 2, 4, 2, EPI_BIAS, 2), V(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 128, 2, 2, 2, EPI_MUL_COLSUM, 2),
+    // round 5: the element-wise epilogues on the small tile, three workgroups per CU (more epilogues overlapping other workgroups' loops)
+    V(128, 64, 2, 2, 2, EPI_BIAS_GELU, 3), V(128, 64, 2, 2, 2, EPI_MUL_COLSUM, 3),
     // round 4: the 256 x 256 macro tile (8 waves, 128 KB of dynamic LDS, one workgroup per CU)
     V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
     // round 4: the same macro tile with FOUR waves of 128 x 128 (16 accumulator tiles per wave: half the LDS fragment reads per MFMA)
