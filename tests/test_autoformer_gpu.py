@@ -183,6 +183,39 @@ def test_full_size_step_is_bit_reproducible_and_respects_sampled_slices():
     assert "blocks.13.fc1.weight" not in gr or torch.count_nonzero(gr["blocks.13.fc1.weight"]) == 0
 
 
+def test_join_at_the_end_of_the_backward_pass_gives_the_same_gradients(monkeypatch):
+    """block.join_side_stream_at_end_of_backward: the main stream waits for the weight-gradient stream in autograd's end-of-pass
+    callback (the stem's backward then runs under the side stream's tail) instead of right behind the blocks.  Same step both ways
+    at the benchmark size, read back right after backward() returns: every gradient bit-identical (a missing or late join, or a
+    workspace recycled under the side stream, shows up as a difference), three times in a row."""
+    from cream_amd.autoformer import block as K
+    from cream_amd.autoformer import engine
+    dev = _dev()
+    torch.manual_seed(0)
+    m = engine.build_supernet("S", drop_path_rate=0.1).to(dev)
+    m.set_sample_config(dict(layer_num=13, embed_dim=[384] * 13, num_heads=[6] * 13, mlp_ratio=[3.5] * 13))
+    m.train()
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(128, 3, 224, 224, device=dev, generator=g)
+    t = torch.softmax(torch.randn(128, 1000, device=dev, generator=g), -1)
+
+    def grads(defer):
+        monkeypatch.setattr(K, "DEFER_JOIN", defer)
+        m.zero_grad(set_to_none=False)
+        torch.manual_seed(123)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = engine.soft_target_cross_entropy(m(x), t)
+        loss.backward()
+        # no synchronize: what the optimizer would read on this stream right after backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    ref = grads(False)
+    for _ in range(3):
+        got = grads(True)
+        for k, v in ref.items():
+            assert torch.equal(v, got[k]), k
+
+
 def test_subnet_evaluation_native_path_matches_module_path():
     """engine.evaluate (supernet_engine.py:113-160) in bf16 on the GPU: the run of blocks goes through
     the native forward sequencing (eval mode, no drop-path, no autograd graph); same sub-network and
