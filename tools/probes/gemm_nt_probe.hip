@@ -322,29 +322,37 @@ static void tn_tests(const char* only) {
                    prio, us, fl / us / 1e6, hm[0], hm[1], (hm[0] > 1.0f || hm[1] > 1e-3f) ? " <-- WRONG" : "", cold ? " [cold]" : "");
             hipFree(d16);
         }
-        // round 5 feasibility: one wave per SIMD, 128 x 128 register tile per wave (tools/probes/gemm_tn9.hpp)
-        for (int slots : {256, 128}) {
+        // round 5 feasibility: one wave per SIMD, NRB x NCB register tile per wave (tools/probes/gemm_tn9.hpp)
+        struct V9 { const char* name; int tr, tc, lds; void (*k)(const TnParams); };
+        const V9 v9s[] = {{"256x256", 256, 256, tn9_lds_bytes<4, 4>(), gemm_tn9_kernel<4, 4>}, {"256x320", 256, 320, tn9_lds_bytes<4, 5>(), gemm_tn9_kernel<4, 5>},
+                          {"256x384", 256, 384, tn9_lds_bytes<4, 6>(), gemm_tn9_kernel<4, 6>}, {"320x256", 320, 256, tn9_lds_bytes<5, 4>(), gemm_tn9_kernel<5, 4>},
+                          {"384x256", 384, 256, tn9_lds_bytes<6, 4>(), gemm_tn9_kernel<6, 4>}};
+        for (const V9& v : v9s) {
+            const int T9 = ((t.N + v.tr - 1) / v.tr) * ((t.K + v.tc - 1) / v.tc);
             const int T8 = ((t.N + 255) / 256) * ((t.K + 255) / 256);
-            const int S9 = std::max(1, std::min(slots / T8, (t.M + 63) / 64)), grid9 = T8 * S9;
+            if (t.M % 32) continue;                                                      // (whole pairs of 16-token sub-steps only)
+            if (v.tr != 256 || v.tc != 256) { if (T9 >= T8) continue; }                  // only where the wide tile saves tiles
+            const int slots = 128;
+            const int S9 = std::max(1, std::min(slots / T9, (t.M + 63) / 64)), grid9 = T9 * S9;
             uint16_t* d16; CK(hipMalloc(&d16, nw * 2 * S9));
             TnParams q9{dy, dx, t.N, t.K, t.M, t.N, t.K, S9, nullptr, nullptr, d16};
-            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn9_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, TN9_LDS_BYTES));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
             float hm[4] = {0, 0, 0, 0};
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipMemset(d16, 0xFF, nw * 2 * S9)); CK(hipMemset(dmax, 0, 16));
-                hipLaunchKernelGGL(gemm_tn9_kernel<6>, dim3(grid9), dim3(256), TN9_LDS_BYTES, 0, q9);
+                hipLaunchKernelGGL(v.k, dim3(grid9), dim3(256), v.lds, 0, q9);
                 check_tn16<<<(unsigned)((nw + 255) / 256), 256>>>(dmax, dref, q9);
                 float h1[4]; CK(hipMemcpy(h1, dmax, 16, hipMemcpyDeviceToHost));
                 hm[0] = std::max(hm[0], h1[0]);
             }
             auto rot9 = [&](int i) { TnParams q = q9; q.dY = ry[i % R]; q.X = rxx[i % R]; return q; };
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_tn9_kernel<6>, dim3(grid9), dim3(256), TN9_LDS_BYTES, 0, rot9(i));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(v.k, dim3(grid9), dim3(256), v.lds, 0, rot9(i));
             hipEventRecord(e0);
-            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(gemm_tn9_kernel<6>, dim3(grid9), dim3(256), TN9_LDS_BYTES, 0, rot9(i + 3));
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(v.k, dim3(grid9), dim3(256), v.lds, 0, rot9(i + 3));
             hipEventRecord(e1); hipEventSynchronize(e1);
             const double us = ms(e0, e1) / 20 * 1e3, fl = 2.0 * t.M * t.N * t.K;
-            printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  tn9 4 waves x 128x128 (probe)     %7.1f us %6.0f TF/s  worst partial error %.2f bf16 ulp %s%s\n", t.what, t.M, t.N, t.K, S9, grid9,
-                   us, fl / us / 1e6, hm[0], hm[0] > 1.0f ? " <-- WRONG" : "", cold ? " [cold]" : "");
+            printf("%-34s M=%5d N=%4d K=%4d S=%2d grid %4d  tn9 tile %s (probe)            %7.1f us %6.0f TF/s  worst partial error %.2f bf16 ulp %s%s\n", t.what, t.M, t.N, t.K, S9, grid9,
+                   v.name, us, fl / us / 1e6, hm[0], hm[0] > 1.0f ? " <-- WRONG" : "", cold ? " [cold]" : "");
             hipFree(d16);
         }
         hipFree(dbias8);

@@ -13,7 +13,6 @@
 namespace cream {
 namespace gemm {
 
-constexpr int TN9_LDS_BYTES = 8 * 16384;
 
 // one 1-KB piece by LDS-DMA: scalar base + 32-bit lane offset (gemm_nt8's request form), destination in M0
 __device__ __forceinline__ void tn9_dma(const void* base, uint32_t off, uint32_t lds_dst) {
@@ -22,14 +21,30 @@ __device__ __forceinline__ void tn9_dma(const void* base, uint32_t off, uint32_t
                  : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(base) : "memory");
 }
 
-// v2: the ring is kept per SUB-STEP of 16 tokens (8 buffers of 16 KB = [Y_q0 | Y_q1 | X_q0 | X_q1] x 16 tokens x 256 B): every wave
-// requests one 1-KB piece of each of the four slots per sub-step, DEPTH sub-steps ahead (counted vmcnt), one barrier per sub-step
-// (16 MFMAs per wave), the fragment reads of sub-step s + 1 interleaved one by one with the MFMAs of sub-step s.
-template <int DEPTH = 6>
+// v2: the ring is kept per SUB-STEP of 16 tokens (buffers of NSLOT x 4 KB = [Y slots | X slots] x 16 tokens x 256 B): every wave
+// requests one 1-KB piece of each slot per sub-step, DEPTH sub-steps ahead (counted vmcnt), one barrier per sub-step, the fragment
+// reads of sub-step s + 1 interleaved one by one with the MFMAs of sub-step s.
+// v3: the register tile of a wave is NRB x NCB blocks of 32 x 32 (4 x 4, 4 x 5, 4 x 6, 5 x 4, 6 x 4): the workgroup tile is
+// 64 NRB (n) x 64 NCB (k), up to 256 x 384 or 384 x 256 — E = 320 / 384 wide operands in ONE tile instead of a full and a narrow one:
+// fewer operand bytes from L2 per flop (256 x 384: 80 KB per 12.6 MFLOP against 64 KB per 8.4).
+// The MFMAs are inline asm: hipcc puts every MFMA destination of a function either in AGPRs or in VGPRs, so more than 16 accumulator
+// tiles (256 AGPRs) turn into accvgpr copies around every instruction (1,072 of them in the 4 x 5 build).  Here the first 16 tiles
+// are pinned to AGPRs ("+a"), the rest to VGPRs ("+v").  (The compiler does not know these are MFMAs: the epilogue waits out the
+// last one's latency itself.)
+template <bool AG>
+__device__ __forceinline__ void tn9_mma(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int NRB = 4, int NCB = 4, int DEPTH = 6>
 __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
 {
-    constexpr uint32_t SUB = 16384, SLOT = 4096, RING = 8;
-    static_assert(DEPTH >= 2 && DEPTH <= 7, "ring of 8 sub-step buffers");
+    constexpr int TR = 64 * NRB, TC = 64 * NCB;                  // workgroup tile (rows n, columns k)
+    constexpr int YS = (TR + 127) / 128, XS = (TC + 127) / 128, NSLOT = YS + XS;
+    constexpr uint32_t SLOT = 4096, SUB = NSLOT * SLOT, RING = NSLOT == 4 ? 8 : (163840 / SUB);
+    static_assert(DEPTH >= 2 && DEPTH + 2 <= (int)RING, "a buffer is overwritten two sub-steps after its last read at the earliest");
+    static_assert(NRB * NCB <= 24, "accumulators");
     extern __shared__ __attribute__((aligned(1024))) char tn9_lds[];
     char* const smem = tn9_lds;
 
@@ -37,120 +52,120 @@ __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem));
-    const int ntc = (p.K + 255) / 256, T = ntc * ((p.N + 255) / 256);
+    const int ntc = (p.K + TC - 1) / TC, T = ntc * ((p.N + TR - 1) / TR);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid % T, split = bid / T;
-    const int r0 = (tile / ntc) * 256, c0 = (tile % ntc) * 256;
+    const int r0 = (tile / ntc) * TR, c0 = (tile % ntc) * TC;
     const int tsteps = (p.M + 63) / 64;
     const int s_lo = (int)((int64_t)tsteps * split / p.S), s_hi = (int)((int64_t)tsteps * (split + 1) / p.S);
-    const int ns = (s_hi - s_lo) * 4;                            // sub-steps of this slice
-    if (ns <= 0) return;
+    if (s_hi <= s_lo) return;
     const int tok0 = s_lo * 64;                                  // first token of the slice
+    const int ns = (min(p.M, s_hi * 64) - tok0) / 16;            // sub-steps of this slice, an even number (M % 32 == 0: the caller checks)
 
-    // ---- staging: per sub-step this wave's piece (token rows 4 wave .. + 3 of the 16) of each of the four slots
+    // ---- staging: per sub-step this wave's piece (token rows 4 wave .. + 3 of the 16) of every slot
     const int prow = wave * 4 + (lane >> 4);                     // token row inside a sub-step
     const int pc = (lane & 15) ^ ((prow & 3) << 2);              // source 16-byte chunk of the 256-byte row (swizzled image)
-    uint32_t poff[4];                                            // byte offsets from the sub-step's first token row
+    uint32_t poff[NSLOT];                                        // byte offsets from the sub-step's first token row
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        poff[q] = (uint32_t)(prow * (int)p.ldy + min(r0 + 128 * q + pc * 8, p.N - 8)) * 2u;
-        poff[2 + q] = (uint32_t)(prow * (int)p.ldx + min(c0 + 128 * q + pc * 8, p.K - 8)) * 2u;
-    }
-    auto request = [&](int s) {                                  // sub-step s of the slice -> ring buffer s % RING
-        const int tok = tok0 + s * 16;
-        const uint32_t dst = lds0 + (uint32_t)(s & (RING - 1)) * SUB + wave * 1024;
+    for (int q = 0; q < YS; ++q) poff[q] = (uint32_t)(prow * (int)p.ldy + min(r0 + 128 * q + pc * 8, p.N - 8)) * 2u;
+#pragma unroll
+    for (int q = 0; q < XS; ++q) poff[YS + q] = (uint32_t)(prow * (int)p.ldx + min(c0 + 128 * q + pc * 8, p.K - 8)) * 2u;
+    // requests stay DEPTH sub-steps ahead; past the end of the slice the last sub-step is requested again into a buffer nobody reads
+    // any more (keeps the vmcnt arithmetic uniform)
+    auto request_or_dummy = [&](int sr, uint32_t ring_buf) {     // sub-step sr of the slice -> the buffer at byte ring_buf
+        const uint32_t dst = lds0 + ring_buf + wave * 1024;
+        const int tok = tok0 + min(sr, ns - 1) * 16;
         const char* by = reinterpret_cast<const char*>(p.dY) + (int64_t)tok * p.ldy * 2;
         const char* bx = reinterpret_cast<const char*>(p.X) + (int64_t)tok * p.ldx * 2;
-        if (tok + 16 <= p.M) {
-            tn9_dma(by, poff[0], dst); tn9_dma(by, poff[1], dst + SLOT);
-            tn9_dma(bx, poff[2], dst + 2 * SLOT); tn9_dma(bx, poff[3], dst + 3 * SLOT);
-        } else {                                                 // rows beyond M are zeros
-            const bool in = tok + prow < p.M;
-            const char* z = reinterpret_cast<const char*>(g_nt8_zero);
-            nt8_dma(in ? by + poff[0] : z, dst); nt8_dma(in ? by + poff[1] : z, dst + SLOT);
-            nt8_dma(in ? bx + poff[2] : z, dst + 2 * SLOT); nt8_dma(in ? bx + poff[3] : z, dst + 3 * SLOT);
-        }
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) tn9_dma(q < YS ? by : bx, poff[q], dst + q * SLOT);
     };
 
-    // ---- transpose-read fragments (gemm_tn8's, inside one 16-token slot)
+    // ---- transpose-read fragments (gemm_tn8's, inside one 16-token x 128-column slot)
     const int gi = lane & 15, q4 = lane >> 4;
-    auto frag_off = [&](int col) -> uint32_t {
-        const int cc = col + 16 * (q4 & 1) + (gi & 3) * 4;
+    auto frag_off = [&](int col) -> uint32_t {                   // col: column inside the operand's part of the buffer
+        const int sl = col >> 7, cin = col & 127;
+        const int cc = cin + 16 * (q4 & 1) + (gi & 3) * 4;
         const int m = 8 * (q4 >> 1) + (gi >> 2);
-        return (uint32_t)(m * 128 + ((((cc >> 3) ^ ((m & 3) << 2)) << 3) | (cc & 7))) * 2u;
+        return sl * SLOT + (uint32_t)(m * 128 + ((((cc >> 3) ^ ((m & 3) << 2)) << 3) | (cc & 7))) * 2u;
     };
-    uint32_t offB[4];
+    uint32_t offY[NRB], offX[NCB];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) offB[t] = frag_off(32 * t);
+    for (int t = 0; t < NRB; ++t) offY[t] = frag_off(32 * (NRB * wm + t));
+#pragma unroll
+    for (int t = 0; t < NCB; ++t) offX[t] = YS * SLOT + frag_off(32 * (NCB * wn + t));
     auto ldfrag = [&](uint32_t off) -> bf16x8 {
         const bf16x4 lo = tr16(reinterpret_cast<const uint16_t*>(smem + off)), hi = tr16(reinterpret_cast<const uint16_t*>(smem + off + 1024));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    const uint32_t yslot = wm * SLOT, xslot = (2 + wn) * SLOT;
 
-    f32x16 acc[4][4];                                            // [tn][tm]
+    constexpr int NT = NRB * NCB, NAG = NT < 16 ? NT : 16;       // accumulator tiles [tn * NRB + tm]: the first 16 in AGPRs
+    f32x16 accA[NAG], accV[NT > 16 ? NT - 16 : 1];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NAG; ++a) accA[a] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8 fyA[4], fxA[4], fyB[4], fxB[4];                       // fragments of the current / the next sub-step
+    for (int a = 0; a < (NT > 16 ? NT - 16 : 1); ++a) accV[a] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 fyA[NRB], fyB[NRB], fx[NCB];                          // Y fragments of the current / the next sub-step; X fragments are replaced
+                                                                 // in place, column by column, as soon as their MFMAs are issued
 
-    // requests stay DEPTH sub-steps ahead; past the end of the slice four dummy pieces (zeros into a ring slot nobody reads any more)
-    // keep the vmcnt arithmetic uniform
-    auto request_or_dummy = [&](int sr) {
-        if (sr < ns) { request(sr); return; }
-        const uint32_t dst = lds0 + (uint32_t)(sr & (RING - 1)) * SUB + wave * 1024;
-        const char* z = reinterpret_cast<const char*>(g_nt8_zero);
-        nt8_dma(z, dst); nt8_dma(z, dst + SLOT); nt8_dma(z, dst + 2 * SLOT); nt8_dma(z, dst + 3 * SLOT);
-    };
     // ---- prologue: sub-steps 0 .. DEPTH - 1 requested, sub-step 0 read
+    uint32_t rq = 0;                                             // ring buffer (bytes) of the next request
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) request_or_dummy(d);
-    wait_vmcnt<4 * (DEPTH - 1)>();
+    for (int d = 0; d < DEPTH; ++d) { request_or_dummy(d, rq); rq = rq + SUB == RING * SUB ? 0u : rq + SUB; }
+    wait_vmcnt<NSLOT * (DEPTH - 1)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { fyA[t] = ldfrag(yslot + offB[t]); fxA[t] = ldfrag(xslot + offB[t]); }
+    for (int t = 0; t < NRB; ++t) fyA[t] = ldfrag(offY[t]);
+#pragma unroll
+    for (int t = 0; t < NCB; ++t) fx[t] = ldfrag(offX[t]);
+    uint32_t rd = SUB;                                           // ring buffer of sub-step s + 1
 
-    auto substep = [&](int s, bf16x8 (&fy)[4], bf16x8 (&fx)[4], bf16x8 (&ny)[4], bf16x8 (&nx)[4]) {
-        request_or_dummy(s + DEPTH);
-        wait_vmcnt<4 * (DEPTH - 1)>();                           // own pieces of sub-step s + 1
-        __builtin_amdgcn_s_barrier();                            // ... everyone's; and nobody reads sub-step s - 1's buffer any more
+    auto substep = [&](int s, bf16x8 (&fy)[NRB], bf16x8 (&ny)[NRB]) {
+        request_or_dummy(s + DEPTH, rq);
+        rq = rq + SUB == RING * SUB ? 0u : rq + SUB;
+        wait_vmcnt<NSLOT * (DEPTH - 1)>();                       // own pieces of sub-step s + 1
+        __builtin_amdgcn_s_barrier();                            // ... everyone's
         asm volatile("" ::: "memory");
-        const uint32_t nb = (uint32_t)((s + 1) & (RING - 1)) * SUB;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { ny[t] = ldfrag(nb + yslot + offB[t]); nx[t] = ldfrag(nb + xslot + offB[t]); }
+        for (int tn = 0; tn < NCB; ++tn) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[tn], fy[tm], acc[tn][tm], 0, 0, 0);
-        // one fragment read behind every MFMA
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            for (int tm = 0; tm < NRB; ++tm) {
+                constexpr int dummy = 0; (void)dummy;
+                const int id = tn * NRB + tm;
+                if (id < 16) tn9_mma<true>(accA[id < 16 ? id : 0], fx[tn], fy[tm]);
+                else tn9_mma<false>(accV[id >= 16 ? id - 16 : 0], fx[tn], fy[tm]);
+            }
+            fx[tn] = ldfrag(rd + offX[tn]);                      // the next sub-step's fragment, into the registers just read
+            if (tn < NRB) ny[tn] = ldfrag(rd + offY[tn]);
+            if (tn + NCB < NRB) ny[tn + NCB] = ldfrag(rd + offY[tn + NCB]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        rd = rd + SUB == RING * SUB ? 0u : rd + SUB;
     };
+    static_assert(NRB <= 2 * NCB, "Y fragments ride behind the columns");
     int s = 0;
     for (; s + 1 < ns; s += 2) {
-        substep(s, fyA, fxA, fyB, fxB);
-        substep(s + 1, fyB, fxB, fyA, fxA);
+        substep(s, fyA, fyB);
+        substep(s + 1, fyB, fyA);
     }
-    if (s < ns) substep(s, fyA, fxA, fyB, fxB);                  // (ns is a multiple of 4: not taken; kept for clarity)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may outlive the workgroup's LDS
 
-    // ---- the partial tile (gemm_tn8's epilogue on the 4 x 4 block layout)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may outlive the workgroup's LDS
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (16 passes each)
+
+    // ---- the partial tile (gemm_tn8's epilogue on the NRB x NCB block layout)
     uint16_t* const out = p.parts16 + (int64_t)split * p.N * p.K;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int n = r0 + 128 * wm + 32 * tm + c32;
+    for (int tm = 0; tm < NRB; ++tm) {
+        const int n = r0 + 32 * (NRB * wm + tm) + c32;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int kb = c0 + 128 * wn + 32 * tn;
+        for (int tn = 0; tn < NCB; ++tn) {
+            const int kb = c0 + 32 * (NCB * wn + tn);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16& a = acc[tn][tm];
+                const int id = tn * NRB + tm;
+                const f32x16& a = id < 16 ? accA[id < 16 ? id : 0] : accV[id >= 16 ? id - 16 : 0];
                 uint32_t a0 = f2bf_pair(a[8 * j], a[8 * j + 1]), a1 = f2bf_pair(a[8 * j + 2], a[8 * j + 3]);
                 uint32_t b0 = f2bf_pair(a[8 * j + 4], a[8 * j + 5]), b1 = f2bf_pair(a[8 * j + 6], a[8 * j + 7]);
                 auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
@@ -160,6 +175,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
             }
         }
     }
+}
+
+template <int NRB, int NCB> constexpr int tn9_lds_bytes() {
+    constexpr int ns = (64 * NRB + 127) / 128 + (64 * NCB + 127) / 128;
+    return ns == 4 ? 8 * 16384 : (163840 / (ns * 4096)) * ns * 4096;
 }
 
 }  // namespace gemm
