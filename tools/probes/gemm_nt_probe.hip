@@ -3,7 +3,7 @@
 // next to the GEMM library (best of the heuristic's top 16 algorithms) on the same problem and buffers.
 // Also pins the lane mapping of ds_read_b64_tr_b16 (needed by the transposing weight-gradient kernel).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icream_amd/csrc tools/probes/gemm_nt_probe.hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icream_amd/csrc -Itools/probes tools/probes/gemm_nt_probe.hip \
 //         -L/opt/rocm/lib -lhipblaslt -o tools/probes/gemm_nt_probe && tools/probes/gemm_nt_probe
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
@@ -324,9 +324,9 @@ static void tn_tests(const char* only) {
         }
         // round 5 feasibility: one wave per SIMD, NRB x NCB register tile per wave (tools/probes/gemm_tn9.hpp)
         struct V9 { const char* name; int tr, tc, lds; void (*k)(const TnParams); };
-        const V9 v9s[] = {{"256x256", 256, 256, tn9_lds_bytes<4, 4>(), gemm_tn9_kernel<4, 4>}, {"256x320", 256, 320, tn9_lds_bytes<4, 5>(), gemm_tn9_kernel<4, 5>},
-                          {"256x384", 256, 384, tn9_lds_bytes<4, 6>(), gemm_tn9_kernel<4, 6>}, {"320x256", 320, 256, tn9_lds_bytes<5, 4>(), gemm_tn9_kernel<5, 4>},
-                          {"384x256", 384, 256, tn9_lds_bytes<6, 4>(), gemm_tn9_kernel<6, 4>}};
+        const V9 v9s[] = {{"256x256", 256, 256, tn9_lds_bytes<4, 4>(), gemm_tn9_kernel<4, 4, false>}, {"256x320", 256, 320, tn9_lds_bytes<4, 5>(), gemm_tn9_kernel<4, 5, false>},
+                          {"256x384", 256, 384, tn9_lds_bytes<4, 6>(), gemm_tn9_kernel<4, 6, false>}, {"320x256", 320, 256, tn9_lds_bytes<5, 4>(), gemm_tn9_kernel<5, 4, false>},
+                          {"384x256", 384, 256, tn9_lds_bytes<6, 4>(), gemm_tn9_kernel<6, 4, false>}};
         for (const V9& v : v9s) {
             const int T9 = ((t.N + v.tr - 1) / v.tr) * ((t.K + v.tc - 1) / v.tc);
             const int T8 = ((t.N + 255) / 256) * ((t.K + 255) / 256);

@@ -1,12 +1,19 @@
-// gemm_tn9.hpp — feasibility probe (round 5, NOT in the library): the weight-gradient product with ONE wave per SIMD and a 128 x 128
-// register tile per wave.
+// gemm_tn9.hpp — probe kernel (round 5, NOT in the library; profiles/r05_tn9.md): the weight-gradient (TN) product with ONE wave per
+// SIMD and a register tile of up to 4 x 6 blocks per wave (gfx950).
 //
-// gemm_tn8's loop is bound by LDS bandwidth as much as by the matrix pipe: 8 waves of 64 x 128 read 24 fragments per 32 MFMAs
-// (0.75 per MFMA; 196 KB of fragment reads + 64 KB of DMA writes per K-tile ~ 2,050 of its ~3,100 cycles at 128 B/clk).  Four
-// waves of 128 x 128 (16 accumulator tiles = 256 registers, AGPRs) read 8 fragments per 16 MFMAs (0.5 per MFMA: 131 KB per K-tile).
-// No SIMD partner: the wave's own fragment reads for sub-step ms + 1 are issued in front of the MFMAs of sub-step ms.
-//   tile 256 (n) x 256 (k), waves 2 (n) x 2 (k); LDS = 2 K-tile buffers x [Y_q0 | Y_q1 | X_q0 | X_q1] as in gemm_tn8.hpp
-//   per K-tile: barrier -> request K-tile t + 1 (16 LDS-DMA per wave) -> 4 sub-steps of 16 MFMAs -> vmcnt(0)
+// Same product, same LDS images and the same bf16 partial tiles as gemm_tn8.hpp.  What changes is the tile: with the accumulators in
+// AGPRs a wave holds NRB x NCB 32 x 32 blocks (4 x 4, 4 x 5, 4 x 6, 5 x 4, 6 x 4), four waves make a workgroup tile of 64 NRB (n) x
+// 64 NCB (k) — up to 256 x 384 or 384 x 256: the E = 320 / 384 wide operand of a layer in ONE tile instead of a full 256 and a narrow
+// one.  The weight gradient is bound by its L2 -> LDS operand stream (profiles/r05_tn9.md: gemm_tn8 and a 256 x 256 build of this
+// kernel end up at the same ~20 B/clk per CU); a 256 x 384 tile moves 80 KB per 12.6 MFLOP where 256 x 256 moves 64 KB per 8.4.
+//   * ring of 16-token SUB-STEP buffers ([Y slots | X slots] x 16 tokens x 256 B, 8 of them): every wave requests one 1-KB piece of
+//     each slot per sub-step, DEPTH sub-steps ahead (counted vmcnt), ONE barrier per sub-step;
+//   * no SIMD partner to hide behind: the fragment reads of sub-step s + 1 follow the MFMAs of sub-step s column by column (the X
+//     fragment of a column is replaced in place as soon as its MFMAs are issued, the Y fragments are double-buffered);
+//   * the MFMAs are inline asm (see tn9_mma);
+//   * BIAS: the column sums of dY ride along as v_dot2c_f32_bf16 against (1, 1) on the Y fragments of the first column tile's
+//     wave column 0 (fp32 per lane, fixed order).
+// Limits: M % 32 == 0 (whole pairs of sub-steps), bf16 partials, N % 8 == 0, K % 8 == 0.
 #pragma once
 #include "gemm_tn8.hpp"
 
@@ -21,12 +28,6 @@ __device__ __forceinline__ void tn9_dma(const void* base, uint32_t off, uint32_t
                  : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(base) : "memory");
 }
 
-// v2: the ring is kept per SUB-STEP of 16 tokens (buffers of NSLOT x 4 KB = [Y slots | X slots] x 16 tokens x 256 B): every wave
-// requests one 1-KB piece of each slot per sub-step, DEPTH sub-steps ahead (counted vmcnt), one barrier per sub-step, the fragment
-// reads of sub-step s + 1 interleaved one by one with the MFMAs of sub-step s.
-// v3: the register tile of a wave is NRB x NCB blocks of 32 x 32 (4 x 4, 4 x 5, 4 x 6, 5 x 4, 6 x 4): the workgroup tile is
-// 64 NRB (n) x 64 NCB (k), up to 256 x 384 or 384 x 256 — E = 320 / 384 wide operands in ONE tile instead of a full and a narrow one:
-// fewer operand bytes from L2 per flop (256 x 384: 80 KB per 12.6 MFLOP against 64 KB per 8.4).
 // The MFMAs are inline asm: hipcc puts every MFMA destination of a function either in AGPRs or in VGPRs, so more than 16 accumulator
 // tiles (256 AGPRs) turn into accvgpr copies around every instruction (1,072 of them in the 4 x 5 build).  Here the first 16 tiles
 // are pinned to AGPRs ("+a"), the rest to VGPRs ("+v").  (The compiler does not know these are MFMAs: the epilogue waits out the
@@ -37,7 +38,7 @@ __device__ __forceinline__ void tn9_mma(f32x16& c, const bf16x8& a, const bf16x8
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-template <int NRB = 4, int NCB = 4, int DEPTH = 6>
+template <int NRB = 4, int NCB = 4, bool BIAS = false, int DEPTH = 6>
 __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
 {
     constexpr int TR = 64 * NRB, TC = 64 * NCB;                  // workgroup tile (rows n, columns k)
@@ -108,6 +109,22 @@ __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
     bf16x8 fyA[NRB], fyB[NRB], fx[NCB];                          // Y fragments of the current / the next sub-step; X fragments are replaced
                                                                  // in place, column by column, as soon as their MFMAs are issued
 
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    float bsum[NRB];
+#pragma unroll
+    for (int t = 0; t < NRB; ++t) bsum[t] = 0.f;
+    const bool want_bias = BIAS && p.bias_parts != nullptr && c0 == 0 && wn == 0;
+    auto colsum = [&](const bf16x8 (&fy)[NRB]) {                 // + the 8 tokens this lane holds of every row block
+        const bf2 ones = __builtin_bit_cast(bf2, 0x3F803F80u);
+#pragma unroll
+        for (int t = 0; t < NRB; ++t) {
+            union { bf16x8 f; uint32_t u[4]; } x;
+            x.f = fy[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x.u[e]), ones, bsum[t], false);
+        }
+    };
+
     // ---- prologue: sub-steps 0 .. DEPTH - 1 requested, sub-step 0 read
     uint32_t rq = 0;                                             // ring buffer (bytes) of the next request
 #pragma unroll
@@ -128,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
         __builtin_amdgcn_s_barrier();                            // ... everyone's
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BIAS) { if (want_bias) colsum(fy); }
 #pragma unroll
         for (int tn = 0; tn < NCB; ++tn) {
 #pragma unroll
@@ -154,6 +172,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn9_kernel(const TnParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may outlive the workgroup's LDS
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (16 passes each)
 
+    if constexpr (BIAS) {
+        if (want_bias) {                                         // lanes c32 and c32 + 32 hold the two token halves of a sub-step
+#pragma unroll
+            for (int t = 0; t < NRB; ++t) {
+                const float tot = bsum[t] + __shfl_xor(bsum[t], 32);
+                const int n = r0 + 32 * (NRB * wm + t) + c32;
+                if (g == 0 && n < p.N) p.bias_parts[(int64_t)split * p.N + n] = tot;
+            }
+        }
+    }
     // ---- the partial tile (gemm_tn8's epilogue on the NRB x NCB block layout)
     uint16_t* const out = p.parts16 + (int64_t)split * p.N * p.K;
 #pragma unroll
