@@ -95,6 +95,19 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return fmaf(x * 0.3989422804014327f, e, c);
 }
 
+// 16-byte output store of the NT epilogues.  CREAM_NT_OUT_NT (compile-time, measured in profiles/r05_nt_out_stores.md): non-temporal,
+// so that the output stream is the first thing the L2 evicts instead of the operand panels its column-tile neighbours still want.
+#ifndef CREAM_NT_OUT_NT
+#define CREAM_NT_OUT_NT 1
+#endif
+__device__ __forceinline__ void st_out16(uint16_t* dst, const u32x4v& v) {
+#if CREAM_NT_OUT_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4v*>(dst));
+#else
+    *reinterpret_cast<u32x4v*>(dst) = v;
+#endif
+}
+
 // XCD-aware tile order (bijective for any grid size): workgroup ids are dealt round-robin to the 8
 // XCDs; the remap gives every XCD a CONTIGUOUS range of tiles.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
@@ -366,8 +379,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                 if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bv[e];
-                    *reinterpret_cast<u32x4v*>(o) =
-                        u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])};
+                    st_out16(o, u32x4v{f2bf_pair(v[0], v[1]), f2bf_pair(v[2], v[3]), f2bf_pair(v[4], v[5]), f2bf_pair(v[6], v[7])});
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
                     // fc1 under autocast yields bf16 h; gelu runs in fp32 ON that bf16 value and casts back
                     // (supernet_transformer.py:14-16, :276-277).  gelu'(h) = Phi(h) + h phi(h) reuses Phi and the
@@ -391,8 +403,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                             gb[e] &= keep;
                         }
                     }
-                    if (p.out) *reinterpret_cast<u32x4v*>(o) = pb;          // (no gelu' without a backward: inference, frozen teacher)
-                    *reinterpret_cast<u32x4v*>(p.out2 + (int64_t)m * p.ldo + n) = gb;
+                    if (p.out) st_out16(o, pb);                             // (no gelu' without a backward: inference, frozen teacher)
+                    st_out16(p.out2 + (int64_t)m * p.ldo + n, gb);
                 } else {   // EPI_MUL_COLSUM
                     const u32x4v fb = auxv[j];
                     u32x4v db;
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                         cs[2 * e] += __uint_as_float(db[e] << 16);              // sums of the ROUNDED values written
                         cs[2 * e + 1] += __uint_as_float(db[e] & 0xFFFF0000u);
                     }
-                    *reinterpret_cast<u32x4v*>(o) = db;
+                    st_out16(o, db);
                 }
             }
             if constexpr (EPI == EPI_MUL_COLSUM) {

@@ -392,8 +392,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const NtParams p)
                         }
                     }
                 }
-                if (full) *reinterpret_cast<u32x4v*>(o) = v;
-                else if (m < p.M && ncol_ok) *reinterpret_cast<u32x4v*>(o) = v;
+                if (full) st_out16(o, v);
+                else if (m < p.M && ncol_ok) st_out16(o, v);
             }
         };
 #pragma unroll

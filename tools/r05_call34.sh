@@ -1,0 +1,15 @@
+#!/bin/bash
+# non-temporal output stores in the NT epilogues: isolated HBM traffic (probe), parity tests, same-call step A/B against the previous library
+REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=$OUT bash tools/r05_call33.sh 2>&1 | tail -4
+cd $REPO
+cp cream_amd/libcream_amd.so /tmp/new.so
+timeout 900 python -m pytest tests/test_block_gpu.py -x -q -m gpu 2>&1 | tail -2
+run() { timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-host-leg 2> $OUT/ab_$1.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']
+print('$1', d['ms_per_step'], {n: k[n]['avg_us'] for n in ('gemm_nt','gemm_nt_gelu','gemm_nt_mul','gemm_tn_wgrad','ln_bwd','attn_rpe2d_bwd')})"; }
+for rep in 1 2 3; do
+  cp gpurun_prev/libcream_amd_prev.so cream_amd/libcream_amd.so; run plain_$rep
+  cp /tmp/new.so cream_amd/libcream_amd.so; run nt_$rep
+done
