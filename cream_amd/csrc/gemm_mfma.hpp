@@ -347,7 +347,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int m = cur_m0 + half * HM + r0 + j * RPP;
-                    auxv[j] = (m < p.M && ncol_ok) ? *reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n) : u32x4v{0, 0, 0, 0};
+                    // (read once: non-temporal, like the outputs — profiles/r05_nt_out_stores.md)
+                    auxv[j] = (m < p.M && ncol_ok) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n)) : u32x4v{0, 0, 0, 0};
                 }
             }
             if (half) __syncthreads();                          // the previous pass has been read
