@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(TY* __restrict__ y, float* 
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
-        v[i] = c < nch ? *reinterpret_cast<const f32x4v*>(xr + 4 * c) : f32x4v{0, 0, 0, 0};
+        // the fp32 residual stream is read and written once per pass: non-temporal, so that what the L2 keeps is the bf16 output
+        // the next GEMM reads (profiles/r05_nt_out_stores.md)
+        v[i] = c < nch ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(xr + 4 * c)) : f32x4v{0, 0, 0, 0};
         if (res && c < nch) {
             float r[4];
-            unpack_bf16x4(*reinterpret_cast<const u32x2v*>(res + (int64_t)row * E + 4 * c), r);
+            unpack_bf16x4(__builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(res + (int64_t)row * E + 4 * c)), r);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] += sc * r[e];
-            *reinterpret_cast<f32x4v*>(xsum + (int64_t)row * E + 4 * c) = v[i];
+            __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4v*>(xsum + (int64_t)row * E + 4 * c));
         }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
@@ -164,9 +166,9 @@ __device__ __forceinline__ void ln_row_request(LnRowIn<MAXC, TD>& in, int row, i
     for (int i = 0; i < MAXC; ++i) {
         const unsigned c = lane + 64 * i;
         if (c < (unsigned)nch) {
-            in.x[i] = *reinterpret_cast<const f32x4v*>(xr + 4u * c);
+            in.x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(xr + 4u * c));
             in.dy[i] = Io4<TD>::load(dyr + 4u * c);
-            if (WITH_RES) in.r[i] = dres ? *reinterpret_cast<const f32x4v*>(rr + 4u * c) : f32x4v{0, 0, 0, 0};
+            if (WITH_RES) in.r[i] = dres ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(rr + 4u * c)) : f32x4v{0, 0, 0, 0};
         }
     }
     in.mu = mean[row];
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
             const unsigned c = lane + 64 * i;
             if (c < (unsigned)nch) {
                 f32x4v r;
-                if (PRE == 0) r = dres ? *reinterpret_cast<const f32x4v*>(dres + ro + 4u * c) : f32x4v{0, 0, 0, 0};
+                if (PRE == 0) r = dres ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dres + ro + 4u * c)) : f32x4v{0, 0, 0, 0};
                 else r = in.r[i];
                 float o[4];
 #pragma unroll
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
                     r[e] += rs * (d[i][e] - s1 - xh[i][e] * s2);
                     o[e] = r[e] * sc;
                 }
-                *reinterpret_cast<f32x4v*>(dxr + 4u * c) = r;
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4v*>(dxr + 4u * c));
                 if (dxs) {
                     Io4<TD>::store(dxsr + 4u * c, o);                  // (o now holds the values as written)
 #pragma unroll
