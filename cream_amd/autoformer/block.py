@@ -325,12 +325,22 @@ def join_side_stream_at_end_of_backward(device, held=()):
         join_side_stream(device)
         return
     held = list(held)
+    # the stream the backward of the blocks RUNS on (this call is made from StackFunction.backward): the callback may be run by
+    # another thread / under another current stream, and the workspaces in `held` belong to this stream's allocator pool
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device)
 
     def _join():
-        join_side_stream(device)
+        main.wait_stream(side)
+        cur = torch.cuda.current_stream(device)
+        if cur != main:
+            cur.wait_stream(side)
         held.clear()
 
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
+    except RuntimeError:                     # not inside an engine pass (backward driven by hand): join here
+        _join()
 
 
 def finalize_on_side_stream(jobs, blk, tensors):
@@ -1119,10 +1129,11 @@ def _block_grads(blk):
 
 def _ws_layout(d):
     """(fwd bytes, off_x, off_x1, off_f, bwd bytes, off_dx, off_df_prev, off_pl1) of a configuration."""
-    key = (d.B, d.N, d.E, d.H, d.F)
+    lib = _lib.load()
+    # (the split counts of the weight gradients are part of the backward layout: cream_gemm_tn8 moves the epoch)
+    key = (d.B, d.N, d.E, d.H, d.F, lib.cream_block_layout_epoch())
     hit = _ws_cache.get(key)
     if hit is None:
-        lib = _lib.load()
         o = [ctypes.c_int64() for _ in range(6)]
         ft = lib.cream_block_fwd_workspace(ctypes.byref(d), ctypes.byref(o[0]), ctypes.byref(o[1]), ctypes.byref(o[2]))
         bt = lib.cream_block_bwd_workspace(ctypes.byref(d), ctypes.byref(o[3]), ctypes.byref(o[4]), ctypes.byref(o[5]))

@@ -268,8 +268,9 @@ int cream_linear_dgrad_mul(void* dh, float* colsum_parts, const void* dy, const 
 
 namespace {
 // the weight-gradient product on the macro tile of gemm_tn8.hpp (bf16 partial tiles, no bias partials).
-// CREAM_GEMM_TN8 in the environment / cream_gemm_tn8(): 0 = never, 1 = problems of at least six 256 x 256 tiles (default)
+// CREAM_GEMM_TN8 in the environment / cream_gemm_tn8(): 0 = never, 1 = problems of at least six 256 x 256 tiles, 2 = every problem (default)
 std::atomic<int> g_tn8{-1};
+std::atomic<int> g_layout_epoch{0};      // bumped whenever a switch changes cream_linear_wgrad_splits_bf16 (= the backward workspace layout)
 int tn8_mode()
 {
     int m = g_tn8.load(std::memory_order_relaxed);
@@ -308,9 +309,14 @@ extern "C" {
 int cream_gemm_tn8(int mode)
 {
     const int prev = tn8_mode();
-    if (mode >= 0) g_tn8.store(mode, std::memory_order_relaxed);
+    if (mode >= 0 && mode != prev) {
+        g_tn8.store(mode, std::memory_order_relaxed);
+        g_layout_epoch.fetch_add(1, std::memory_order_relaxed);
+    }
     return prev;
 }
+
+int cream_block_layout_epoch(void) { return g_layout_epoch.load(std::memory_order_relaxed); }
 
 int cream_linear_wgrad_splits_bf16(int M, int N, int K)
 {

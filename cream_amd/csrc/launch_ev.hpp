@@ -33,17 +33,37 @@ extern thread_local hipEvent_t tl_start_event;
     } while (0)
 
 namespace cream {
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remembered per device (one process may
-// drive several GPUs, block_seq.cpp: MAX_DEV), not per process
-template <typename K>
-bool raise_dynamic_lds(K kern, int bytes)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a KERNEL: remembered per (kernel address, device)
+// — one process may drive several GPUs (block_seq.cpp: MAX_DEV), and kernels of the same signature (every gemm_nt8_kernel<EPI>
+// is a void(*)(NtParams)) must not share a record: a static per template instantiation over the pointer TYPE did.
+// A small open-addressed table of atomics: no lock on the launch path, a lost race only repeats the host-side call.
+inline bool raise_dynamic_lds_addr(const void* kern, int bytes)
 {
-    static std::atomic<uint32_t> done{0};                      // bit d: raised on device d (per instantiation of this template)
+    constexpr int SLOTS = 256;                                 // (the library has ~40 kernels that ask for dynamic LDS)
+    static std::atomic<const void*> key[SLOTS];
+    static std::atomic<uint32_t> done[SLOTS];                  // bit d: raised on device d
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev >= 0 && dev < 32 && (done.load(std::memory_order_relaxed) >> dev & 1u)) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-    if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+    int slot = -1;
+    if (dev >= 0 && dev < 32) {
+        uintptr_t h = reinterpret_cast<uintptr_t>(kern);
+        h = (h >> 4) * 0x9E3779B97F4A7C15ull >> 40;
+        for (int probe = 0; probe < SLOTS; ++probe) {
+            const int s = (int)((h + probe) % SLOTS);
+            const void* k = key[s].load(std::memory_order_acquire);
+            if (k == nullptr) {
+                const void* expect = nullptr;
+                if (key[s].compare_exchange_strong(expect, kern, std::memory_order_acq_rel) || expect == kern) { slot = s; break; }
+                continue;
+            }
+            if (k == kern) { slot = s; break; }
+        }
+        if (slot >= 0 && (done[slot].load(std::memory_order_acquire) >> dev & 1u)) return true;
+    }
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (slot >= 0) done[slot].fetch_or(1u << dev, std::memory_order_release);
     return true;
 }
+template <typename K>
+bool raise_dynamic_lds(K kern, int bytes) { return raise_dynamic_lds_addr(reinterpret_cast<const void*>(kern), bytes); }
 }  // namespace cream

@@ -350,9 +350,13 @@ int cream_gemm_nt256(int on);
  * (256 x 256 tiles, 8 waves in two staggered rows, a whole K-tile of LDS-DMA requests in flight across every barrier, K-tile
  * stream continuous over output tiles, barrier-free per-wave epilogue).  0 = never (the kernels above), 1 = wherever its
  * limits allow (31-bit element offsets), 2 = plain and bias products everywhere, the GELU / x gelu' epilogues only on long
- * contractions (K >= 1024) — the default; mode < 0 only queries; returns the previous setting; the initial one
- * comes from CREAM_GEMM_NT8 in the environment.  Forward, bias, bias + GELU results are identical to the other kernels';
- * cream_linear_dgrad_mul rounds dy . W to bf16 before the multiplication (the reference's two operators do). */
+ * contractions (K >= 1024); 3 = plain and bias products whose 256-wide column tiles carry at most 1/8 padding; 4 = the forward
+ * products (bias epilogue) under the same padding bound — the DEFAULT (no weight-gradient stream runs beside the forward).
+ * mode < 0 only queries; returns the previous setting; the initial one comes from CREAM_GEMM_NT8 in the environment.
+ * Forward, bias, bias + GELU results are identical to the other kernels'.  cream_linear_dgrad_mul: when this kernel serves it
+ * (modes 1 and 2) dy . W is rounded to bf16 before the multiplication by gelu' (as the reference's two operators do); the
+ * two-stage kernels (modes 0, 3, 4 — the default) multiply the fp32 accumulator and round once — the results differ by at
+ * most one bf16 rounding of the product. */
 int cream_gemm_nt8(int mode);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
@@ -383,7 +387,8 @@ int cream_linear_wgrad_parts_bf16(void* parts_bf16, float* bias_parts, const voi
  * the phase-interleaved loop, one 8-wave workgroup per CU, token slices for half the CUs — the weight gradients share the chip
  * with the main chain and every slice is another partial tile through HBM); bias partials ride along.  With any other S, or with
  * fp32 partials (cream_linear_wgrad_parts), the 128 x 128 kernel runs.  Same partial-tile layout and rounding either way.
- * cream_gemm_tn8(0 | 1 | 2): never / problems of at least six 256 x 256 tiles / every problem (default); < 0 queries. */
+ * cream_gemm_tn8(0 | 1 | 2): never / problems of at least six 256 x 256 tiles / every problem (default); < 0 queries.
+ * Changing it changes cream_linear_wgrad_splits_bf16 and with it the backward workspace layout (cream_block_layout_epoch). */
 int cream_linear_wgrad_splits_bf16(int M, int N, int K);
 int cream_gemm_tn8(int mode);
 
@@ -561,6 +566,14 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* g, const
 /* cream_block_bwd writes the split-K partial tiles of the four weight gradients as bf16 (1) or fp32 (0); returns the
  * previous setting; on < 0 only queries.  Initial value: CREAM_WGRAD_BF16 in the environment, else 1. */
 int cream_block_wgrad_bf16(int on);
+
+/* Workspace-layout rule.  The byte size and the internal offsets of the backward workspace depend on the split counts of the
+ * four weight gradients (cream_linear_wgrad_splits_bf16), i.e. on cream_gemm_tn8() and on the device's CU count: these must NOT
+ * change between cream_block_bwd_workspace and the cream_block_bwd call that uses a workspace of that size (cream_block_bwd
+ * recomputes the layout; a workspace sized under another mode is overrun).  cream_block_layout_epoch() returns a counter that
+ * moves whenever such a switch changes value: callers that cache workspace sizes key the cache on it (cream_amd/autoformer/
+ * block.py:_ws_layout does). */
+int cream_block_layout_epoch(void);
 
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).
