@@ -58,6 +58,14 @@ SIGNATURES = {
     "cream_attn_rpe2d_bwd": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                   _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cream_attn_rpe2d_fwd_img": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp,
+                                      _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cream_attn_rpe2d_bwd_img": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                      _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cream_attn_rpe2d_table_image_bytes": (_i64, []),
+    "cream_attn_rpe2d_table_images": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "cream_attn_rpe2d_fwd_mode": (_i, [_i]),
     "cream_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cream_ln_partials": (_i, []),
     "cream_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -133,7 +141,7 @@ class BlockDesc(ctypes.Structure):
                 [(n, _i64) for n in ("ld_qkv", "ld_qkv_t", "seg_qkv", "seg_qkv_t", "ld_proj", "ld_proj_t", "ld_w1",
                                      "ld_w1_t", "ld_w2", "ld_w2_t")] +
                 [(n, _vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "tkv", "tkh", "tvv", "tvh")] +
-                [("ldt", _i64)])
+                [("ldt", _i64), ("timg", _vp)])
 
 
 class IrpeAttnDesc(ctypes.Structure):

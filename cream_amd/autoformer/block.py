@@ -476,13 +476,34 @@ class BlockOperands:
                 self.w.append(torch.empty((out_f, in_f), **bf))
                 self.wt.append(torch.empty((in_f, out_f), **bf))
             self.b.append(torch.empty((out_f,), **bf) if m.bias is not None else None)
+        # bf16 operand images of the four relative-position tables (include/cream_amd.h: cream_attn_rpe2d_table_images layout):
+        # rows and transposed copies are exactly what cream_adamw_step writes for any parameter (mir / mir_t), so the images
+        # are kept current by the optimizer kernel like the GEMM operand copies — the attention forward then runs the
+        # ping-pong kernel and the backward saves its image launch
+        self.tables, self.timg, self._timg_views = (), None, ()
+        if getattr(at, 'relative_position', False):
+            tabs = _tables(at)
+            nb = tabs[0].shape[0]
+            if all(t.shape == (nb, 64) and t.is_contiguous() and t.dtype == torch.float32 for t in tabs) and nb <= 32:
+                self.tables = tabs
+                self.timg = torch.zeros((_lib.load().cream_attn_rpe2d_table_image_bytes() // 2,), **bf)
+                views = []
+                for i in range(4):
+                    base = (i // 2) * 8192 + (i % 2) * 32 * 64
+                    base_t = (i // 2) * 8192 + 4096 + (i % 2) * 32
+                    views.append((self.timg[base:base + nb * 64].view(nb, 64),
+                                  torch.as_strided(self.timg, (64, nb), (64, 1), base_t)))
+                self._timg_views = tuple(views)
         self.key = self._key()
         self.versions = None
         self._table = None
         _register(self)
 
     def _key(self):
-        return tuple(m.weight.data_ptr() for m in self.mods)
+        return tuple(m.weight.data_ptr() for m in self.mods) + tuple(t.data_ptr() for t in self.tables)
+
+    def _params(self):
+        return [p for m in self.mods for p in (m.weight, m.bias) if p is not None] + list(self.tables)
 
     def jobs(self, grads=False, states=None, weight_decay=0.0):
         """cream_param_jobs of this block's 8 projection tensors (weights with both copies, biases with
@@ -495,6 +516,9 @@ class BlockOperands:
             if m.bias is not None:
                 st = states[m.bias] if states else (None, None)
                 out.append((m.bias, param_job(m.bias.detach(), m.bias.grad if grads else None, st[0], st[1], b, None)))
+        for t, (rows, rows_t) in zip(self.tables, self._timg_views):
+            st = states[t] if states else (None, None)
+            out.append((t, param_job(t.detach(), t.grad if grads else None, st[0], st[1], rows, rows_t)))
         return out
 
     def refresh(self):
@@ -504,10 +528,10 @@ class BlockOperands:
         self.mark_fresh()
 
     def mark_fresh(self):
-        self.versions = tuple(p._version for m in self.mods for p in (m.weight, m.bias) if p is not None)
+        self.versions = tuple(p._version for p in self._params())
 
     def stale(self):
-        return self.versions != tuple(p._version for m in self.mods for p in (m.weight, m.bias) if p is not None)
+        return self.versions != tuple(p._version for p in self._params())
 
 
 _OPS_KEY = '_cream_operands'
@@ -976,7 +1000,7 @@ def _block_forward(blk, x2d, pend, dp1, B, N):
     # (qkv_super.py:72-77); bias is the plain prefix (qkv_super.py:80-83)
     qkv = linear_fwd_seg(a, wqkv, bqkv, 3 * Q, E, Q)
     tabs = tuple(t.detach() for t in _tables(at))
-    o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr)
+    o, lse, sp = fused_attention.attn_fwd_raw(qkv.view(B, N, 3, H, 64), *tabs, at.sample_scale, mr, timg=ops.timg)
     p = linear_fwd(o.view(M, Q), wproj, bproj, E, Q)
     x1, c, mean2, rstd2 = add_ln_fwd(x, p, dp1, N, ln2.weight[:E], ln2.bias[:E], ln2.eps)
     h, g = linear_gelu_fwd(c, w1, b1, F_, E)                 # h = gelu'(pre-activation), g = gelu(pre-activation)
@@ -1030,7 +1054,7 @@ def _block_backward(blk, dims, dp1, saved, dx2, df, pb2, prev_scale, want_prev):
     tabs_p = _tables(at)
     dqkv, dtab = fused_attention.attn_bwd_raw(do.view(B, N, H, 64), qkv.view(B, N, 3, H, 64),
                                               *(t.detach() for t in tabs_p), o, lse, sp, scale, mr,
-                                              reduce_tables=False)
+                                              reduce_tables=False, timg=operands(blk).timg)
     nb = tabs_p[0].shape[0]
     for i, t in enumerate(tabs_p):                                     # dtab (workgroup partials, 4, 32, 64)
         jobs.add(t, dtab, dtab.shape[0], 4 * 32 * 64, nb, 64, src_offset=i * 32 * 64)
@@ -1095,6 +1119,7 @@ def _block_desc(blk, B, N):
         tabs = _tables(at)
         t.tkv, t.tkh, t.tvv, t.tvh = (x.data_ptr() for x in tabs)
         t.ldt = tabs[0].stride(0)
+        t.timg = ops.timg.data_ptr() if ops.timg is not None else 0
         t.eps1, t.eps2 = ln1.eps, ln2.eps
         t.mr = at.max_relative_position
         ent = blk.__dict__[_DESC_KEY] = (t, key)

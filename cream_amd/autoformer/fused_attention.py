@@ -61,9 +61,28 @@ def _flops(B, H, N):
     return B * H * (4 * N * N * 64 + 4 * N * 64 * 60)
 
 
-def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
-    """qkv (B, N, 3, H, 64) -> (out (B, N, H, 64), lse (B, H, N), sp (B, H, 64, NP)).  One launch."""
+def table_images(tkv, tkh, tvv, tvh, mr):
+    """bf16 operand images of the four tables (cream_attn_rpe2d_table_images): one small launch.  The block path keeps
+    them current through the optimizer kernel instead (block.BlockOperands.timg)."""
+    lib = _lib.load()
+    img = torch.empty((lib.cream_attn_rpe2d_table_image_bytes() // 2,), dtype=torch.bfloat16, device=tkv.device)
+    with torch.cuda.device(tkv.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.cream_attn_rpe2d_table_images(_ptr(img), _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0), mr, st),
+                   "cream_attn_rpe2d_table_images")
+    return img
+
+
+def _wants_images(qkv, N, mr):
+    return qkv.dtype == torch.bfloat16 and N == 197 and mr == 14
+
+
+def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr, timg=None):
+    """qkv (B, N, 3, H, 64) -> (out (B, N, H, 64), lse (B, H, N), sp (B, H, 64, NP)).  One launch (plus the image
+    launch when the AutoFormer geometry is asked for in bf16 without images: the ping-pong kernel needs them)."""
     B, N, _, H, D = qkv.shape
+    if timg is None and _wants_images(qkv, N, mr):
+        timg = table_images(tkv, tkh, tvv, tvh, mr)
     gh, gw = grid_of(N, mr)
     NP = padded_len(N)
     out = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
@@ -74,14 +93,14 @@ def attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr):
     lib = _lib.load()
     with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_fwd", flops=_flops(B, H, N)):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(lib.cream_attn_rpe2d_fwd(
+        _lib.check(lib.cream_attn_rpe2d_fwd_img(
             _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
-            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
-            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_fwd")
+            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0), _ptr(timg) if timg is not None else None,
+            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_fwd_img")
     return out, lse, sp
 
 
-def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_tables=True):
+def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_tables=True, timg=None):
     """-> (dqkv (B, N, 3, H, 64), dtab (4, 32, 64) fp32 = gradients of [tkv, tkh, tvv, tvh] rows;
     with reduce_tables=False the per-workgroup partials (cream_attn_rpe2d_dtab_parts(B, H), 4, 32, 64) for
     cream_grad_finalize)."""
@@ -103,12 +122,12 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_
     lib = _lib.load()
     with torch.cuda.device(qkv.device), timing.region("attn_rpe2d_bwd", flops=int(2.5 * _flops(B, H, N))):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(lib.cream_attn_rpe2d_bwd(
+        _lib.check(lib.cream_attn_rpe2d_bwd_img(
             _ptr(dq), _ptr(dk), _ptr(dv), dsb, dsn, dsh, _ptr(dtab),
             _ptr(dlt), _ptr(qe), _ptr(de), _ptr(delta),
             _ptr(dout), _ptr(out), _ptr(lse), _ptr(sp), _ptr(q), _ptr(k), _ptr(v), sb, sn, sh,
-            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0),
-            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd")
+            _ptr(tkv), _ptr(tkh), _ptr(tvv), _ptr(tvh), tkv.stride(0), _ptr(timg) if timg is not None else None,
+            B, H, N, gh, gw, mr, float(scale), _DT[qkv.dtype], st), "cream_attn_rpe2d_bwd_img")
     if not reduce_tables:
         return dqkv, dtab
     return dqkv, dtab.sum(dim=0)                              # fixed-order reduction over the workgroups' partials
@@ -117,15 +136,17 @@ def attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, scale, mr, reduce_
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, tkv, tkh, tvv, tvh, scale, mr):
-        out, lse, sp = attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr)
+        B, N = qkv.shape[:2]
+        timg = table_images(tkv, tkh, tvv, tvh, mr) if _wants_images(qkv, N, mr) else None
+        out, lse, sp = attn_fwd_raw(qkv, tkv, tkh, tvv, tvh, scale, mr, timg=timg)
         ctx.save_for_backward(qkv, tkv, tkh, tvv, tvh, out, lse, sp)
-        ctx.scale, ctx.mr = float(scale), mr
+        ctx.scale, ctx.mr, ctx.timg = float(scale), mr, timg
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, tkv, tkh, tvv, tvh, out, lse, sp = ctx.saved_tensors
-        dqkv, dt = attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, ctx.scale, ctx.mr)
+        dqkv, dt = attn_bwd_raw(dout, qkv, tkv, tkh, tvv, tvh, out, lse, sp, ctx.scale, ctx.mr, timg=ctx.timg)
         nb = tkv.shape[0]
         return (dqkv, dt[0, :nb].to(tkv.dtype), dt[1, :nb].to(tkh.dtype), dt[2, :nb].to(tvv.dtype),
                 dt[3, :nb].to(tvh.dtype), None, None)

@@ -68,6 +68,7 @@ struct FwdArgs {
     RelGeom G;
     float scale;
     int nitems;                                      // B * H (forward: persistent workgroups walk them)
+    const void* timg;                                // bf16 operand images of the four tables (cream_attn_rpe2d_table_images) or NULL
 };
 
 struct BwdArgs {
@@ -89,6 +90,7 @@ struct BwdArgs {
     float scale;
     int nitems;                                      // B * H (dQ kernel: persistent workgroups walk them)
     int stagger;                                     // one-pass kernel: start offset between the 8 phase groups (x 64 cycles)
+    const void* timg;                                // bf16 operand images of the four tables or NULL (then built into dlt)
 };
 
 // ---- pieces shared by forward and backward ---------------------------------------------
@@ -910,6 +912,30 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
 }
 
 #include "attn_rpe2d_bwd1.hpp"
+#include "attn_rpe2d_fwd2.hpp"
+
+// 1: the ping-pong online-softmax forward (attn_rpe2d_fwd2.hpp) whenever the caller hands over the table images
+// (AutoFormer geometry, bf16); 0: attn_rpe2d_fwd14.  CREAM_ATTN_FWD2 in the environment sets the initial value.
+std::atomic<int> g_fwd2{-1};
+int fwd2_mode() {
+    int m = g_fwd2.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_ATTN_FWD2");
+        m = e ? (atoi(e) != 0) : 1;
+        g_fwd2.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+int fwd_persistent_grid();
+int launch_fwd2(const FwdArgs& a, int B, hipStream_t st) {
+    if (!cream::raise_dynamic_lds(v3::attn_rpe2d_fwd2_kernel, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
+    FwdArgs aa = a;
+    aa.nitems = B * a.H;
+    const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
+    CREAM_LAUNCH(v3::attn_rpe2d_fwd2_kernel, dim3(grid), dim3(v3::F2_THREADS), v3::F2_LDS_B, st, aa, reinterpret_cast<const short*>(a.timg));
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
 
 int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
     if (!cream::raise_dynamic_lds(attn_rpe2d_fwd14_kernel, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
@@ -928,7 +954,7 @@ int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
         // (the tile-streamed kernel's own FAST instantiation, launch_fwd_nt<T, 7, true>: 46.5 us against 40.6 us at B = 128, H = 6;
         //  10.56 vs 10.48 ms per step in a same-box A/B x3)
-        if (fast_geometry(a.G)) return launch_fwd14(a, B, st);
+        if (fast_geometry(a.G)) return a.timg && fwd2_mode() ? launch_fwd2(a, B, st) : launch_fwd14(a, B, st);
     }
     if (nt <= 7) return launch_fwd_nt<T, 7>(a, B, st);
     return launch_fwd_nt<T, 8>(a, B, st);
@@ -1441,11 +1467,15 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
     BwdArgs aa = a;
     aa.nitems = B * a.H;
     aa.stagger = 0;                                  // (de-phasing the workgroups' first items was measured: no gain, profiles/r04_attn_bwd1.md)
-    short* img = reinterpret_cast<short*>(a.dlt);
-    hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, img, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
-    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    const short* img = reinterpret_cast<const short*>(a.timg);
+    if (!img) {                                      // no images from the caller: built into the side buffer, one more launch
+        short* own = reinterpret_cast<short*>(a.dlt);
+        hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, st, own, a.tkv, a.tkh, a.tvv, a.tvh, a.ldt, a.nb);
+        if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+        img = own;
+    }
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    CREAM_LAUNCH(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, (const short*)img);
+    CREAM_LAUNCH(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, img);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -1485,10 +1515,37 @@ int cream_attn_rpe2d_dtab_parts(int B, int H)
     return (int)(items < fwd_persistent_grid() ? items : fwd_persistent_grid());
 }
 
+int cream_attn_rpe2d_fwd_mode(int fwd2)
+{
+    const int prev = fwd2_mode();
+    if (fwd2 >= 0) g_fwd2.store(fwd2 != 0, std::memory_order_relaxed);
+    return prev;
+}
+
+int64_t cream_attn_rpe2d_table_image_bytes(void) { return (int64_t)v2::IMG_ELEMS * 2; }
+
+int cream_attn_rpe2d_table_images(void* img, const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt,
+                                  int mr, void* stream)
+{
+    if (!img || !tkv || !tkh || !tvv || !tvh || ldt < 64 || mr < 0 || 2 * mr + 2 > 32 || ((uintptr_t)img) % 16) return CREAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(v2::table_images_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<short*>(img), tkv, tkh,
+                       tvv, tvh, ldt, 2 * mr + 2);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const void* k, const void* v,
                          int64_t sb, int64_t sn, int64_t sh, const float* tkv, const float* tkh,
                          const float* tvv, const float* tvh, int ldt, int B, int H, int N, int gh, int gw,
                          int mr, float scale, int dtype, void* stream)
+{
+    return cream_attn_rpe2d_fwd_img(out, lse, sp, q, k, v, sb, sn, sh, tkv, tkh, tvv, tvh, ldt, nullptr, B, H, N, gh, gw, mr, scale,
+                                    dtype, stream);
+}
+
+int cream_attn_rpe2d_fwd_img(void* out, float* lse, void* sp, const void* q, const void* k, const void* v,
+                             int64_t sb, int64_t sn, int64_t sh, const float* tkv, const float* tkh,
+                             const float* tvv, const float* tvh, int ldt, const void* timg, int B, int H, int N, int gh, int gw,
+                             int mr, float scale, int dtype, void* stream)
 {
     if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
     if (B == 0 || H == 0) return CREAM_OK;
@@ -1499,8 +1556,9 @@ int cream_attn_rpe2d_fwd(void* out, float* lse, void* sp, const void* q, const v
     // 16-byte vector loads of operand rows
     if ((sb * esz) % 16 || (sn * esz) % 16 || (sh * esz) % 16) return CREAM_ERR_BAD_ARG;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16) return CREAM_ERR_BAD_ARG;
-    if (ldt % 4 || ((uintptr_t)tkv | (uintptr_t)tkh) % 16) return CREAM_ERR_BAD_ARG;
+    if (ldt % 4 || ((uintptr_t)tkv | (uintptr_t)tkh) % 16 || ((uintptr_t)timg) % 16) return CREAM_ERR_BAD_ARG;
     FwdArgs a;
+    a.timg = timg;
     a.q = q; a.k = k; a.v = v; a.sb = sb; a.sn = sn; a.sh = sh;
     a.out = out; a.lse = lse; a.sp = sp;
     a.tkv = tkv; a.tkh = tkh; a.tvv = tvv; a.tvh = tvh; a.ldt = ldt; a.nb = 2 * mr + 2;
@@ -1522,6 +1580,17 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
                          const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt,
                          int B, int H, int N, int gh, int gw, int mr, float scale, int dtype, void* stream)
 {
+    return cream_attn_rpe2d_bwd_img(dq, dk, dv, dsb, dsn, dsh, dtab, dlt, qe, de, delta, dout, out, lse, sp, q, k, v, sb, sn, sh, tkv, tkh,
+                                    tvv, tvh, ldt, nullptr, B, H, N, gh, gw, mr, scale, dtype, stream);
+}
+
+int cream_attn_rpe2d_bwd_img(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh, float* dtab,
+                             void* dlt, void* qe, void* de, float* delta,
+                             const void* dout, const void* out, const float* lse, const void* sp,
+                             const void* q, const void* k, const void* v, int64_t sb, int64_t sn, int64_t sh,
+                             const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt, const void* timg,
+                             int B, int H, int N, int gh, int gw, int mr, float scale, int dtype, void* stream)
+{
     if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
     if (B == 0 || H == 0) return CREAM_OK;
     if (!dq || !dk || !dv || !dtab || !dlt || !qe || !de || !delta || !dout || !out || !lse || !sp || !q || !k ||
@@ -1535,9 +1604,10 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
         return CREAM_ERR_BAD_ARG;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv |
          (uintptr_t)dout | (uintptr_t)out | (uintptr_t)sp | (uintptr_t)dlt | (uintptr_t)qe | (uintptr_t)de |
-         (uintptr_t)dtab | (uintptr_t)tkv | (uintptr_t)tkh | (uintptr_t)tvv | (uintptr_t)tvh) % 16)
+         (uintptr_t)dtab | (uintptr_t)tkv | (uintptr_t)tkh | (uintptr_t)tvv | (uintptr_t)tvh | (uintptr_t)timg) % 16)
         return CREAM_ERR_BAD_ARG;
     BwdArgs a{};
+    a.timg = timg;
     a.q = q; a.k = k; a.v = v; a.sb = sb; a.sn = sn; a.sh = sh;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dsb = dsb; a.dsn = dsn; a.dsh = dsh;
     a.dout = dout; a.out = out; a.lse = lse; a.sp = sp;

@@ -314,8 +314,8 @@ int cream_block_fwd(const cream_block_desc* d, void* ws, const float* x_in, cons
                              stream));
     const uint16_t* qkv = at<uint16_t>(ws, L.qkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
-    PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd(at<void>(ws, L.o), at<float>(ws, L.lse), d->inference ? nullptr : at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
-                             d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
+    PTRY(K_ATTN_FWD, stream, attn_flops(d), 0, cream_attn_rpe2d_fwd_img(at<void>(ws, L.o), at<float>(ws, L.lse), d->inference ? nullptr : at<void>(ws, L.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64,
+                             d->tkv, d->tkh, d->tvv, d->tvh, (int)d->ldt, d->timg, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale,
                              CREAM_BF16, stream));
     PTRY(K_GEMM_NT, stream, 2.0 * M * E * Q, 0, cream_linear_fwd(at<void>(ws, L.p), at<void>(ws, L.o), d->wproj, d->bproj, M, E, Q, d->ld_proj, stream));
     // x1 = x + s1 * p ; c = LN2(x1)
@@ -387,10 +387,10 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     uint16_t* dqkv = at<uint16_t>(ws, L.dqkv);
     const int64_t sn = 3 * (int64_t)Q, sb = (int64_t)N * sn;
     if (!f_dqkv.arm()) return CREAM_ERR_LAUNCH;
-    PTRY(K_ATTN_BWD, main, 2.5 * attn_flops(d), 0, cream_attn_rpe2d_bwd(dqkv, dqkv + Q, dqkv + 2 * Q, sb, sn, 64, at<float>(ws, L.dtab), at<void>(ws, L.dlt), at<void>(ws, L.qe),
+    PTRY(K_ATTN_BWD, main, 2.5 * attn_flops(d), 0, cream_attn_rpe2d_bwd_img(dqkv, dqkv + Q, dqkv + 2 * Q, sb, sn, 64, at<float>(ws, L.dtab), at<void>(ws, L.dlt), at<void>(ws, L.qe),
                              at<void>(ws, L.de), at<float>(ws, L.delta), at<void>(ws, L.dout), at<void>(fws, FL.o),
                              at<float>(fws, FL.lse), at<void>(fws, FL.sp), qkv, qkv + Q, qkv + 2 * Q, sb, sn, 64, d->tkv, d->tkh,
-                             d->tvv, d->tvh, (int)d->ldt, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
+                             d->tvv, d->tvh, (int)d->ldt, d->timg, d->B, d->H, N, d->gh, d->gw, d->mr, d->attn_scale, CREAM_BF16, main));
     if (!f_dqkv.join()) return CREAM_ERR_LAUNCH;                          // dqkv complete on main
     // qkv weight gradient (rows [q | k | v]); the bias gradient (column sums of dqkv) rides on it
     PTRY(K_GEMM_TN, side, 2.0 * M * 3 * Q * E, 0, wgrad_parts(wb16, at<float>(ws, L.pwq), at<float>(ws, L.pbq), dqkv, at<void>(fws, FL.a), M, 3 * Q, E, Sq, side));

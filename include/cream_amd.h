@@ -146,6 +146,40 @@ int cream_attn_rpe2d_bwd(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn,
                          int ldt, int B, int H, int N, int gh, int gw, int mr,
                          float scale, int dtype, void* stream);
 
+/* bf16 OPERAND IMAGES of the four tables (the rows of RelativePosition2D_super's embeddings_table_v / _h,
+ * multihead_super.py:22-26, as the matrix cores read them): cream_attn_rpe2d_table_image_bytes() bytes (32 KB),
+ *   [key rows (64 u' x 64 d) | key^T (64 d x 64 u') | value rows | value^T],  u' = bucket of the vertical table (0..31)
+ *   or 32 + bucket of the horizontal table, rows >= 2*mr+2 zero.
+ * cream_attn_rpe2d_table_images builds them in one small launch; cream_adamw_step keeps them current for free when the
+ * caller registers them as the bf16 copies of the four table parameters (mir = rows, mir_t = transposed at ld 64:
+ * cream_amd/autoformer/block.py: BlockOperands) — the layout is exactly that of the GEMM operand copies.
+ * The *_img entry points are cream_attn_rpe2d_fwd / _bwd with such an image (timg; NULL = the plain entry points):
+ *   - forward, AutoFormer geometry (N = 197, 14 x 14 grid, mr = 14) in bf16: runs csrc/attn_rpe2d_fwd2.hpp — 32-key tiles with
+ *     an online (lazy-maximum) softmax, two 7-wave half-workgroups per CU in ping-pong (one multiplies while the other does
+ *     the element-wise / memory work), K / V by LDS-DMA; without an image (or with cream_attn_rpe2d_fwd_mode(0)) the
+ *     whole-row-block kernel attn_rpe2d_fwd14 runs.  Same outputs up to the rounding of the softmax numerators' reference
+ *     point (both within the bf16 bounds of tests/test_attn_gpu.py).
+ *   - backward (one-pass kernel): reads the image instead of building one into dlt with an extra launch.
+ * cream_attn_rpe2d_fwd_mode(1 | 0): as above; < 0 queries; returns the previous value; initial: CREAM_ATTN_FWD2, else 1. */
+int64_t cream_attn_rpe2d_table_image_bytes(void);
+int cream_attn_rpe2d_table_images(void* img, const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt,
+                                  int mr, void* stream);
+int cream_attn_rpe2d_fwd_mode(int fwd2);
+int cream_attn_rpe2d_fwd_img(void* out, float* lse, void* sp,
+                             const void* q, const void* k, const void* v,
+                             int64_t sb, int64_t sn, int64_t sh,
+                             const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                             int ldt, const void* timg, int B, int H, int N, int gh, int gw, int mr,
+                             float scale, int dtype, void* stream);
+int cream_attn_rpe2d_bwd_img(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh,
+                             float* dtab, void* dlt, void* qe, void* de, float* delta,
+                             const void* dout, const void* out, const float* lse, const void* sp,
+                             const void* q, const void* k, const void* v,
+                             int64_t sb, int64_t sn, int64_t sh,
+                             const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                             int ldt, const void* timg, int B, int H, int N, int gh, int gw, int mr,
+                             float scale, int dtype, void* stream);
+
 /* ---- the two ends of the supernet around the block stack (csrc/stem_tail.hip) --------------------
  * Reference: Vision_TransformerSuper.forward_features, AutoFormer/model/supernet_transformer.py:147-172
  * (patch embedding embedding_super.py:27-40, class token + position embedding :150-155, final LayerNorm and
@@ -524,6 +558,9 @@ typedef struct cream_block_desc {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* attn_layer_norm / ffn_layer_norm (fp32)     */
     const float *tkv, *tkh, *tvv, *tvh;             /* rel_pos_embed_{k,v}.embeddings_table_{v,h}  */
     int64_t ldt;
+    const void* timg;             /* bf16 operand images of the four tables (cream_attn_rpe2d_table_images layout, kept current
+                                     by cream_adamw_step) or NULL: with them the forward runs the ping-pong kernel and the
+                                     backward saves its image launch (round 6; NULL = the behaviour before) */
 } cream_block_desc;
 
 /* fp32 gradients of the block's parameters (super shapes; accumulated into, never overwritten) */
