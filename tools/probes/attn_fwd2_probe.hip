@@ -97,35 +97,6 @@ static int run_case(int B, int H, int rounds, float qscale, bool spike) {
         fail |= d;
         hipFree(o2);
     }
-#ifdef ATTN_PROFILE
-    if (rounds > 0) {
-        const int grid = std::min(B * H, 256);
-        long long* dprof;
-        hipMalloc(&dprof, (size_t)grid * 16 * 16 * 8);
-        hipMemset(dprof, 0, (size_t)grid * 16 * 16 * 8);
-        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &dprof, sizeof(dprof));
-        fwd(1, o1, l1, sp1); hipDeviceSynchronize();
-        std::vector<long long> hp((size_t)grid * 256);
-        hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost);
-        long long* nul = nullptr;
-        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &nul, sizeof(nul));
-        // half 0 of a workgroup with 3 items: two iterations (7 stamps each) + the tail pair
-        const char* names[] = {"epilogue(prev)", "prologue", "barrier", "request K,V", "tile loop", "dma wait", "barrier+",
-                               "epilogue(prev)", "prologue", "barrier", "request K,V", "tile loop", "dma wait", "barrier+", "tail epilogue"};
-        for (int half = 0; half < 2; ++half) {
-            std::vector<double> sum(16, 0.0); int cnt = 0;
-            for (int blk = 0; blk < grid; ++blk) for (int w = 0; w < 7; ++w) {
-                long long* d = &hp[((size_t)blk * 16 + half * 7 + w) * 16];
-                if (d[1] <= d[0]) continue;
-                for (int i = 0; i < 15; ++i) sum[i] += d[i + 1] > 0 ? (double)(d[i + 1] - d[i]) : 0.0;
-                ++cnt;
-            }
-            printf("  fwd2 half %d, cycles per wave (%d waves):\n", half, cnt);
-            for (int i = 0; i < 15; ++i) if (sum[i] != 0) printf("    %-16s %9.0f\n", names[i], sum[i] / std::max(cnt, 1));
-        }
-        hipFree(dprof);
-    }
-#endif
     if (rounds > 0) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         std::vector<float> t[2];
