@@ -96,6 +96,8 @@ SIGNATURES = {
     "cream_linear_wgrad_splits_bf16": (_i, [_i, _i, _i]),
     "cream_gemm_tn8": (_i, [_i]),
     "cream_block_layout_epoch": (_i, []),
+    "cream_cu_reserve": (_i, [_i]),
+    "cream_cu_count": (_i, []),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_param_job_tiles": (_i, [_i, _i]),

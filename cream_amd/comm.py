@@ -375,6 +375,49 @@ class GradReducer:
         self.works = []
 
 
+# CU budget with world > 1.  Every hot kernel of the library is a persistent grid of one or two workgroups per CU holding most of
+# the CU's LDS, so an RCCL kernel launched beside them (one workgroup per channel) gets a CU only when a grid drains.  The
+# data-parallel driver therefore reserves R CUs (cream_cu_reserve: every persistent grid is sized for CUs - R) and caps RCCL at
+# R channels.  R = 16 by default: 2 CUs per XCD, 6 % of the chip; the per-step message is 52-139 MB in ~27 buckets, i.e. a few
+# MB per bucket over 7 xGMI links x ~50 GB/s effective — 16 channels are more than the links need (unmeasured on hardware: gpurun
+# boxes have one GPU; CREAM_COMM_CUS overrides, 0 = no reserve / RCCL defaults).  bench.py records the values in config.comm.
+DEFAULT_COMM_CUS = 16
+_comm_budget = {"reserved_cus": 0, "rccl_channels": None, "cus_for_kernels": None}
+
+
+def comm_cu_budget():
+    """What init_distributed reserved: {'reserved_cus', 'rccl_channels', 'cus_for_kernels'}."""
+    return dict(_comm_budget)
+
+
+def reserve_comm_cus(world, backend):
+    import os
+    r = int(os.environ.get("CREAM_COMM_CUS", DEFAULT_COMM_CUS if (world > 1 and backend == "nccl") else 0))
+    if r > 0 and backend == "nccl":
+        # must be in the environment before RCCL initialises (first collective of the process group)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(r))
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(r, 4)))
+        _comm_budget["rccl_channels"] = {"max": int(os.environ["NCCL_MAX_NCHANNELS"]), "min": int(os.environ["NCCL_MIN_NCHANNELS"])}
+    if torch.cuda.is_available():
+        from . import _lib
+        lib = _lib.load()
+        lib.cream_cu_reserve(max(r, 0))
+        _comm_budget["cus_for_kernels"] = lib.cream_cu_count()
+    _comm_budget["reserved_cus"] = max(r, 0)
+    return r
+
+
+def default_comm_mode(world):
+    """'allreduce' (one collective per bucket) or 'rs_ag' (reduce-scatter + all-gather: every xGMI link carries 1 / world of a
+    bucket in each phase).  Selectable at run time: CREAM_COMM_MODE=allreduce|rs_ag (bench.py --comm-mode auto reads it).  The
+    default is 'allreduce' at every world size: a step moves 52-139 MB in ~9 ms, i.e. < 30 GB/s per GPU against 7 links of
+    ~50 GB/s — the exchange is launch-count-bound, not link-bound, and rs_ag doubles the collectives per bucket (no multi-GPU
+    measurement exists to overrule this; both modes are bit-identical in the gloo tests)."""
+    import os
+    m = os.environ.get("CREAM_COMM_MODE")
+    return m if m in ("allreduce", "rs_ag") else "allreduce"
+
+
 def init_distributed(backend=None):
     """torch.distributed bootstrap from the torchrun environment (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_*), as AutoFormer/lib/utils.py:209-235 does for the reference.
@@ -390,6 +433,7 @@ def init_distributed(backend=None):
         if backend == "nccl":
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks of a node (see bench.py)
             torch.cuda.set_device(local)
+        reserve_comm_cus(world, backend)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         dist.barrier()

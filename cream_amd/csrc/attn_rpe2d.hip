@@ -31,6 +31,7 @@
 #include "attn_common.hpp"
 #include "cream_amd.h"
 #include "launch_ev.hpp"
+#include "cu_budget.hpp"
 
 namespace {
 using namespace cream;
@@ -885,16 +886,7 @@ __global__ __launch_bounds__(W14_THREADS) void attn_rpe2d_fwd14_kernel(const Fwd
 }
 
 // one persistent workgroup per CU (the forward's LDS footprint allows exactly one)
-int fwd_persistent_grid() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+int fwd_persistent_grid() { return cream::cu_count(); }
 
 bool fast_geometry(const RelGeom& G) { return G.n == 197 && G.gh == G14 && G.gw == G14 && G.mr == G14; }
 

@@ -24,12 +24,12 @@
 #include "gemm_nt8.hpp"
 #include "gemm_tn8.hpp"
 #include "launch_ev.hpp"
+#include "cu_budget.hpp"
 
 namespace {
-using namespace cream;
-using namespace cream::gemm;
-
-int num_cus()
+std::atomic<int> g_cu_reserve{0};
+std::atomic<int> g_layout_epoch{0};      // bumped whenever a switch changes cream_linear_wgrad_splits_bf16 (= the backward workspace layout)
+int physical_cus()
 {
     static int cus = 0;
     if (!cus) {
@@ -40,6 +40,20 @@ int num_cus()
     }
     return cus;
 }
+}  // namespace
+namespace cream {
+int cu_count()
+{
+    int c = (physical_cus() - g_cu_reserve.load(std::memory_order_relaxed)) / 8 * 8;
+    return c < 8 ? 8 : c;
+}
+}  // namespace cream
+
+namespace {
+using namespace cream;
+using namespace cream::gemm;
+
+int num_cus() { return cream::cu_count(); }
 
 // persistent launch: as many workgroups as the chip holds at once (OCC per CU, a multiple of 8 so that a
 // workgroup's tiles stay on its XCD), or one per tile if there are fewer tiles.  Same-box A/B of the step with
@@ -270,7 +284,6 @@ namespace {
 // the weight-gradient product on the macro tile of gemm_tn8.hpp (bf16 partial tiles, no bias partials).
 // CREAM_GEMM_TN8 in the environment / cream_gemm_tn8(): 0 = never, 1 = problems of at least six 256 x 256 tiles, 2 = every problem (default)
 std::atomic<int> g_tn8{-1};
-std::atomic<int> g_layout_epoch{0};      // bumped whenever a switch changes cream_linear_wgrad_splits_bf16 (= the backward workspace layout)
 int tn8_mode()
 {
     int m = g_tn8.load(std::memory_order_relaxed);
@@ -317,6 +330,18 @@ int cream_gemm_tn8(int mode)
 }
 
 int cream_block_layout_epoch(void) { return g_layout_epoch.load(std::memory_order_relaxed); }
+
+int cream_cu_reserve(int reserve)
+{
+    const int prev = g_cu_reserve.load(std::memory_order_relaxed);
+    if (reserve >= 0 && reserve != prev) {
+        g_cu_reserve.store(reserve, std::memory_order_relaxed);
+        g_layout_epoch.fetch_add(1, std::memory_order_relaxed);       // (the weight gradients' token slices follow the CU count)
+    }
+    return prev;
+}
+
+int cream_cu_count(void) { return cream::cu_count(); }
 
 int cream_linear_wgrad_splits_bf16(int M, int N, int K)
 {

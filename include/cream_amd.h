@@ -612,6 +612,16 @@ int cream_block_wgrad_bf16(int on);
  * block.py:_ws_layout does). */
 int cream_block_layout_epoch(void);
 
+/* CU budget of the persistent kernels.  Every hot kernel of the library launches one or two persistent workgroups per compute
+ * unit and takes most of its LDS, so a collective kernel launched beside them (RCCL's per-step gradient all-reduce,
+ * AutoFormer/supernet_train.py:286-289) only runs once a grid drains.  cream_cu_reserve(R) makes every grid of the library size
+ * itself for (CUs - R) rounded down to a multiple of 8 (one share per XCD); the caller tells RCCL to use at most R channels
+ * (cream_amd/comm.py: init_distributed exports NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS before the process group is created).
+ * R < 0 queries; returns the previous reserve; moves cream_block_layout_epoch (the weight-gradient token slices follow the count).
+ * cream_cu_count(): what the grids are sized for now. */
+int cream_cu_reserve(int reserve);
+int cream_cu_count(void);
+
 /* Optional in-step kernel timing of the two calls above (measurement aid; no reference counterpart — the
  * reference's step is timed by `MetricLogger`, AutoFormer/lib/utils.py:58-170, at step granularity).
  * While enabled, every launch of cream_block_fwd / cream_block_bwd is bracketed by a pair of HIP events

@@ -153,6 +153,29 @@ def test_switches_without_a_device():
     assert lib.cream_linear_wgrad_splits_bf16(0, 8, 8) == 0
 
 
+def test_cu_reserve_sizes_every_persistent_grid_and_moves_the_layout_epoch():
+    """cream_cu_reserve (the data-parallel driver reserves CUs for RCCL's channels, cream_amd/comm.py): the grids follow — the
+    attention kernels' workgroup count (= number of table-gradient partial blocks), the weight gradients' token slices — and the
+    workspace-layout epoch moves, so cached workspace sizes are re-queried."""
+    from cream_amd import _lib
+    lib = _lib.load()
+    prev = lib.cream_cu_reserve(-1)
+    try:
+        lib.cream_cu_reserve(0)
+        full, e0 = lib.cream_cu_count(), lib.cream_block_layout_epoch()
+        s0 = lib.cream_linear_wgrad_splits_bf16(25216, 1344, 384)
+        assert full % 8 == 0 and lib.cream_attn_rpe2d_dtab_parts(128, 6) == min(768, full)
+        assert lib.cream_cu_reserve(16) == 0
+        assert lib.cream_cu_count() == full - 16 and lib.cream_block_layout_epoch() == e0 + 1
+        assert lib.cream_attn_rpe2d_dtab_parts(128, 6) == min(768, full - 16)
+        assert lib.cream_linear_wgrad_splits_bf16(25216, 1344, 384) <= s0
+        assert lib.cream_cu_reserve(16) == 16 and lib.cream_block_layout_epoch() == e0 + 1      # unchanged value: no move
+        lib.cream_cu_reserve(10 ** 6)
+        assert lib.cream_cu_count() == 8                                                         # never below one CU per XCD
+    finally:
+        lib.cream_cu_reserve(prev)
+
+
 def test_library_has_no_undefined_kernel_stubs():
     """Every kernel instantiation the host code launches must have its host stub in the library: clang silently drops the stub
     of a __global__ template whose body fails a DEFERRED host-side check (round 4: a target builtin inside a lambda called under

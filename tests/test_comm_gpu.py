@@ -118,3 +118,42 @@ def test_two_ranks_rccl():
         print(f"[2 ranks, RCCL] rank {rank}: reducer vs mean of local gradients {err:.2e}, in sync {in_sync}, sent {sent / 1e6:.1f} MB")
         assert err < 1e-5 and in_sync and 0 < sent <= full
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_n4_code_path_rehearsed_over_gloo(tmp_path):
+    """bench.py's N > 1 path end to end with FOUR ranks — all on cuda:0, gradients over gloo (CREAM_DIST_BACKEND): init,
+    rank-0 broadcast, the timed region with its barriers and the MAX over ranks, the in-step kernel-timing pass (every rank
+    runs it: its steps contain collectives), the gathered device list and the compact headline.  The first real 8-GPU run
+    of the driver must not die on a code path nobody executed; the numbers mean nothing."""
+    import json
+    import subprocess
+    world = 4
+    port = 31300 + (os.getpid() % 300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_RANK="0",
+               CREAM_DIST_BACKEND="gloo", CREAM_BENCH_EXTRA=str(tmp_path / "extra.json"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-host-leg"]
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} exit {p.returncode}\n{se[-3000:]}"
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 8 * world and line["config"]["comm"]["world"] == world
+    assert line["config"]["comm"]["backend"] == "gloo"
+    assert line["roofline"] and line["roofline"]["launches"] > 0          # the timing pass ran on every rank
+    assert len(json.dumps(line)) < 4096                                   # the compact headline
+    for r in range(1, world):
+        assert outs[r][0].strip() == "", "only rank 0 prints"
+    extra = json.load(open(tmp_path / "extra.json"))
+    assert len(extra["config_full"]["comm"]["devices"]) == world

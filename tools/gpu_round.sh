@@ -13,17 +13,17 @@ echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1
 echo "smoke exit $?"; tail -2 $OUT/${TAG}_smoke.log
-timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+CREAM_BENCH_EXTRA=$OUT/${TAG}_bench_extra.json timeout 600 python bench.py --steps $STEPS --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?"; cat $OUT/${TAG}_bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-leg > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+CREAM_BENCH_EXTRA=/dev/null timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o step -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-leg > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 echo "rocprof exit $?"; cat $OUT/${TAG}_prof_bench.json
 # QUICK=1: tests, bench line, kernel stats, the rpe_index HBM counters and config 2 only (the other records are unchanged)
 # counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 [ -z "$QUICK" ] && for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
   # full-size steps only (no batch-4 host leg, no extra legs): the per-kernel means are those of the benchmarked shapes
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|table_images|gemm_|ln_|adamw|grad_finalize|soft_ce|tail_|stem_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-host-leg --no-kernel-timing > /dev/null 2> $OUT/${TAG}_pmc_$N.err
+  CREAM_BENCH_EXTRA=/dev/null   timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'attn_|table_images|gemm_|ln_|adamw|grad_finalize|soft_ce|tail_|stem_' -d $OUT/${TAG}_pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-host-leg --no-kernel-timing > /dev/null 2> $OUT/${TAG}_pmc_$N.err
   echo "pmc $N exit $?"
   # config 4: the fused iRPE attention kernels and the rpe_index kernels under the same counters (bench.py reads their mfma_util / traffic)
   timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex 'irpe_' -d $OUT/${TAG}_pmc_irpe_$N -o pmc --output-format csv -- python $REPO/tools/bench_irpe_attention.py > /dev/null 2> $OUT/${TAG}_pmc_irpe_$N.err
@@ -42,7 +42,7 @@ done
 cd $REPO
 # the other measured configurations: config 2 (supernet-T, fixed subnet), config 4 (rpe_index
 # micro-benchmark + one RPEAttention layer), sub-network evaluation, host-side profile of the step
-timeout 300 python bench.py --supernet T --subnet T --steps 40 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
+CREAM_BENCH_EXTRA=$OUT/${TAG}_bench_config2_extra.json timeout 300 python bench.py --supernet T --subnet T --steps 40 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
 echo "config2 exit $?"; cat $OUT/${TAG}_bench_config2.json | cut -c1-400
 timeout 300 python tools/bench_rpe_index.py > $OUT/${TAG}_rpe_index_microbench.jsonl 2> $OUT/${TAG}_rpe_index_microbench.err
 echo "rpe microbench exit $?"; cut -c1-300 $OUT/${TAG}_rpe_index_microbench.jsonl
