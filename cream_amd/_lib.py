@@ -97,6 +97,7 @@ SIGNATURES = {
     "cream_gemm_tn8": (_i, [_i]),
     "cream_block_layout_epoch": (_i, []),
     "cream_cu_reserve": (_i, [_i]),
+    "cream_mixup_cutmix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _f, _vp]),
     "cream_cu_count": (_i, []),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -104,9 +104,31 @@ class Mixup:
         y.scatter_(1, target.long().view(-1, 1), on)
         return y * lam + y.flip(0) * (1.0 - lam)
 
+    def _native(self, x, target, lam, use_cutmix):
+        """Device tensors: images mixed in place and the soft targets built by ONE launch (csrc/mixup.hip)."""
+        import ctypes
+        from .. import _lib
+        B, C, H, W = x.shape
+        box = (0, 0, 0, 0)
+        if lam != 1.0 and use_cutmix:
+            box = self.rand_bbox(H, W, lam)
+            lam = 1.0 - (box[1] - box[0]) * (box[3] - box[2]) / float(H * W)                  # corrected for the clipped box
+        y = torch.empty((B, self.num_classes), device=x.device, dtype=torch.float32)
+        t = target.to(torch.int64).contiguous()
+        with torch.cuda.device(x.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.load().cream_mixup_cutmix(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                                      ctypes.c_void_p(t.data_ptr()), B, C, H, W, self.num_classes, float(lam),
+                                                      1 if use_cutmix else 0, box[0], box[1], box[2], box[3],
+                                                      float(self.label_smoothing), st), "cream_mixup_cutmix")
+        return x, y
+
     def __call__(self, x, target):
         assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
         lam, use_cutmix = self._params_per_batch()
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.shape[-1] % 4 == 0
+                and x.data_ptr() % 16 == 0 and target.dim() == 1):
+            return self._native(x, target, lam, use_cutmix)
         if lam != 1.0:
             if use_cutmix:
                 yl, yh, xl, xh = self.rand_bbox(x.shape[-2], x.shape[-1], lam)

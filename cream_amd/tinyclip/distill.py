@@ -31,6 +31,27 @@ def hard_clip_loss(image_features, text_features, logit_scale, rank=0, group=Non
     return (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
 
 
+def tower_bucket_of(name, blocks_per_bucket=4):
+    """Bucket key of a student parameter: the reference wraps the image tower, the text tower and the logit scale in three
+    separate DDP instances (`ddpify`, open_clip/model.py:977-988), so each tower's gradients travel as soon as THAT tower's
+    backward has produced them.  Here: one GradReducer whose buckets never cross a tower — `<tower>.tr<k>` for every
+    `blocks_per_bucket` consecutive transformer blocks (a ViT-39M/16 block is ~7 MB of fp32 gradients: 4 per message keeps
+    the xGMI links busy without waiting for the whole tower), `<tower>.rest` for embeddings / projections / final norm."""
+    parts = name.split(".")
+    tower = parts[0]
+    if "resblocks" in parts:
+        return f"{tower}.tr{int(parts[parts.index('resblocks') + 1]) // blocks_per_bucket:02d}"
+    return tower if tower == "_logit_scale" else f"{tower}.rest"
+
+
+def make_reducer(student, group=None, mode="allreduce", blocks_per_bucket=4):
+    """`ddpify` of the step (model.py:977-988): per-tower gradient buckets on the side-stream reducer (cream_amd/comm.py).  No
+    active-slice packing: TinyCLIP's towers are dense."""
+    from ..comm import GradReducer
+    return GradReducer(student, process_group=group, mode=mode, slice_of=None,
+                       bucket_of=lambda n: tower_bucket_of(n, blocks_per_bucket))
+
+
 class DistillStep:
     def __init__(self, student, teacher, optimizer, *, logit_scale=50.0, distillation_alpha=1.0, distillation_weight=1.0,
                  norm_gradient_clip=5.0, amp_dtype=torch.bfloat16, rank=0, world_size=1, group=None, reducer=None):

@@ -47,6 +47,76 @@ class _AllGatherCat(torch.autograd.Function):
         return g[rank * b:(rank + 1) * b].clone(), None
 
 
+class _GatherStarted(torch.autograd.Function):
+    """The differentiable view of a gather that was posted asynchronously and has COMPLETED: forward hands out the receive buffer,
+    backward is _AllGatherCat's reduce-scatter."""
+
+    @staticmethod
+    def forward(ctx, x, out, group):
+        ctx.group = group
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _AllGatherCat.backward(ctx, g)[0], None, None
+
+
+class FeatureGather:
+    """Both towers' features of every rank with ONE collective that runs UNDER the local block of the similarity products
+    (all-gather / similarity-GEMM overlap): start() posts the asynchronous all-gather of the (B_local, 2 D) buffer —
+    RCCL runs it on its own stream over xGMI —, the caller multiplies its LOCAL rows against its LOCAL columns meanwhile (they need
+    nothing from the other ranks), wait() orders the current stream behind the collective and returns (all_image, all_text)."""
+
+    def __init__(self, image_features, text_features, with_grad=True, group=None):
+        self.d = image_features.shape[1]
+        self.local = (image_features, text_features)
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.work = None
+        if self.world == 1:
+            return
+        both = torch.cat([image_features, text_features], dim=1).contiguous()
+        out = both.new_empty((self.world * both.shape[0], both.shape[1]))
+        self.work = dist.all_gather_into_tensor(out, both.detach(), group=group, async_op=True)
+        self._both, self._out, self._group = both, out, group      # (the send buffer must outlive the collective)
+        self._with_grad = with_grad and both.requires_grad
+
+    def wait(self):
+        if self.world == 1:
+            return self.local
+        self.work.wait()
+        # the differentiable view is attached once the buffer is complete (autograd forbids in-place writes under a custom view)
+        allf = _GatherStarted.apply(self._both, self._out, self._group) if self._with_grad else self._out
+        return allf[:, :self.d], allf[:, self.d:]
+
+
+def overlapped_similarities(image_features, text_features, with_grad=True, group=None):
+    """(image_local . all_text^T, text_local . all_image^T) with the feature gather running under the two LOCAL blocks.  Column
+    blocks of an NT product are independent (same contraction order per element), so the values equal the unoverlapped path's."""
+    g = FeatureGather(image_features, text_features, with_grad, group)
+    if g.world == 1:
+        return similarity(image_features, text_features), similarity(text_features, image_features)
+    # rows x OWN columns: needs nothing from the other ranks.  Without gather_with_grad the column operand carries no gradient, the
+    # local block included (loss.py:96-103 puts the local tensor back only when `not local_loss`; ClipSoftLoss asserts local_loss)
+    col_t = text_features if with_grad else text_features.detach()
+    col_i = image_features if with_grad else image_features.detach()
+    loc_it = similarity(image_features, col_t)
+    loc_ti = similarity(text_features, col_i)
+    all_image, all_text = g.wait()
+    b, r, w = image_features.shape[0], g.rank, g.world
+
+    def assemble(a, all_b, local_block):
+        parts = []
+        if r > 0:
+            parts.append(similarity(a, all_b[:r * b]))
+        parts.append(local_block)
+        if r < w - 1:
+            parts.append(similarity(a, all_b[(r + 1) * b:]))
+        return torch.cat(parts, dim=1)
+
+    return assemble(image_features, all_text, loc_it), assemble(text_features, all_image, loc_ti)
+
+
 def gather_features_with_grad(image_features, text_features, with_grad=True, group=None):
     """-> (all_image, all_text): both towers' features of every rank with ONE collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -115,8 +185,11 @@ class ClipSoftLoss(nn.Module):
         assert not use_horovod, "RCCL through torch.distributed only"
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self.group = group
+        self.overlap = True                   # the feature gather runs under the local similarity blocks (False: gather, then multiply)
 
     def compute_sim(self, image_features, text_features, with_grad):
+        if self.overlap:
+            return overlapped_similarities(image_features, text_features, with_grad, self.group)
         all_image, all_text = gather_features_with_grad(image_features, text_features, with_grad, self.group)
         return similarity(image_features, all_text), similarity(text_features, all_image)
 

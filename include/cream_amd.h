@@ -470,6 +470,19 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- batch-mode Mixup / CutMix + smoothed soft targets, one launch (csrc/mixup.hip) -----------------
+ * `samples, targets = mixup_fn(samples, targets)` of the step body (AutoFormer/supernet_engine.py:52-53; timm.data.Mixup as
+ * constructed at supernet_train.py:245-251: mode 'batch' — third-party, not vendored, restated; parity unpinned by the reference,
+ * pinned against the host restatement cream_amd/autoformer/data.py).  In place on x (B, Cimg, H, W) fp32, B even, W % 4 == 0:
+ *   use_cutmix == 0:  x_b <- lam x_b + (1 - lam) x_{B-1-b}
+ *   use_cutmix != 0:  x_b[:, yl:yh, xl:xh] <- x_{B-1-b}[:, yl:yh, xl:xh]   (the caller passes lam corrected for the clipped box)
+ *   lam == 1: images untouched.
+ * y (B, num_classes) fp32 <- lam onehot_s(target_b) + (1 - lam) onehot_s(target_{B-1-b}), onehot_s = label_smoothing / C off,
+ * 1 - label_smoothing + label_smoothing / C on; target (B) int64 class indices.  lambda and the box are drawn by the caller
+ * (numpy's global RNG in timm's order: data.Mixup). */
+int cream_mixup_cutmix(float* x, float* y, const int64_t* target, int B, int Cimg, int H, int W, int num_classes, float lam,
+                       int use_cutmix, int yl, int yh, int xl, int xh, float label_smoothing, void* stream);
+
 /* ---- soft-target cross entropy (loss rows + logit gradient in one launch) --------------------------
  * criterion(outputs, targets) of the step body (AutoFormer/supernet_engine.py:60-66) with timm's
  * SoftTargetCrossEntropy (third-party, not vendored: restated from its published definition —

@@ -136,7 +136,18 @@ def _worker(rank, world, port, q):
     ok2 = (torch.allclose(loss2.detach(), ref.detach(), rtol=1e-6, atol=1e-7)
            and torch.allclose(img2.grad, ri.grad[sl], rtol=1e-4, atol=5e-6)
            and torch.allclose(txt2.grad, rt.grad[sl], rtol=1e-4, atol=5e-6))
-    q.put((rank, bool(ok), bool(ok2), float((loss - losses[rank]).abs()), float((img.grad - full_i.grad[sl]).abs().max()), float((txt.grad - full_t.grad[sl]).abs().max())))
+    # the feature gather running UNDER the local similarity blocks (ClipSoftLoss.overlap, the default) against gather-then-multiply:
+    # column blocks of an NT product are independent and world = 2 adds the same two gradient terms either way -> same bits
+    img3, txt3 = feats[0][sl].clone().requires_grad_(), feats[1][sl].clone().requires_grad_()
+    plain = ClipSoftLoss(gather_with_grad=True)
+    plain.overlap = False
+    loss3 = plain(img3, txt3, s, feats[2][sl], feats[3][sl], ts)
+    loss3.backward()
+    same_bits = bool(torch.equal(loss3.detach(), loss.detach()) and torch.equal(img3.grad, img.grad) and torch.equal(txt3.grad, txt.grad))
+    close = bool(torch.allclose(loss3.detach(), loss.detach(), rtol=1e-6, atol=1e-7) and torch.allclose(img3.grad, img.grad, rtol=1e-5, atol=1e-7)
+                 and torch.allclose(txt3.grad, txt.grad, rtol=1e-5, atol=1e-7))
+    ok = ok and close
+    q.put((rank, bool(ok), bool(ok2), same_bits, float((loss - losses[rank]).abs()), float((img.grad - full_i.grad[sl]).abs().max()), float((txt.grad - full_t.grad[sl]).abs().max())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -152,7 +163,7 @@ def test_soft_loss_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, ok2, *dbg in res:
-        print(rank, dbg)
+    for rank, ok, ok2, same_bits, *dbg in res:
+        print(rank, "overlapped == plain bit for bit:", same_bits, dbg)
         assert ok, f"rank {rank}: gather_with_grad loss / gradients differ from the global-batch computation"
         assert ok2, f"rank {rank}: local-gradient mode differs"

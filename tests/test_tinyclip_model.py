@@ -204,7 +204,11 @@ def _distill_worker(rank, world, port, q):
     opt = torch.optim.SGD(student.parameters(), lr=0.05)
     # the REAL reducer (flat arena, per-bucket hooks): DistillStep must zero-fill and arm it every step — with
     # zero_grad(set_to_none=True) the gradients leave the arena, no collective runs and the ranks diverge
-    reducer = GradReducer(student, bucket_of=lambda name: name.split(".")[0])
+    # per-tower buckets (the reference's three DDP wrappers, model.py:977-988): no bucket crosses a tower
+    from cream_amd.tinyclip.distill import make_reducer
+    reducer = make_reducer(student, blocks_per_bucket=1)
+    assert all(b.split(".")[0] in ("_image_encoder", "_text_encoder", "_logit_scale") for b in reducer.bucket_names)
+    assert len(reducer.bucket_names) == 2 * (2 + 1) + 1, reducer.bucket_names
     step = DistillStep(student, teacher, opt, logit_scale=None, distillation_alpha=0.7, amp_dtype=torch.float32, rank=rank, world_size=world,
                        reducer=reducer)
     images, texts = _tiny_batch()
