@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=28.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the tiny-batch pass that measures the unstalled host cost of a step")
+    ap.add_argument("--no-mixup", action="store_true", help="feed precomputed soft targets instead of running the step body's mixup_fn "
+                    "(supernet_engine.py:52-53) on the device inside the timed region")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-wgrad-stream", action="store_true", help="weight-gradient GEMMs on the main stream")
     ap.add_argument("--comm-mode", default="auto", choices=["auto", "allreduce", "rs_ag"],
@@ -513,6 +515,7 @@ def compact_line(line):
     head["config"] = {"workload": cfg.get("workload"), "global_batch": cfg.get("global_batch"), "parallelism": cfg.get("parallelism"),
                       "comm": {k: comm.get(k) for k in ("world", "backend", "mode", "cu_budget", "grad_bytes_per_step_last") if k in comm},
                       "wgrad_partials": "bf16 split-K partial tiles (within 1.9e-3 of fp32 partials)",
+                      "mixup": "on-device, in the timed region" if str(cfg.get("mixup", "")).startswith("in the timed") else "off",
                       "kernel_choice": cfg.get("kernel_choice")}
     head["extra"] = "bench_extra.json (side legs: rpe_index / iRPE config 4, TinyCLIP config 5, host leg, per-kernel table, notes)"
     return head, extra
@@ -547,7 +550,16 @@ def main():
         a.comm_mode = comm.default_comm_mode(world)
     reducer = comm.GradReducer(model, mode=a.comm_mode)
     amp = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    trainer = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES[a.supernet]["choices"], reducer, amp_dtype=amp)
+    mixup_fn = None
+    if not a.no_mixup:
+        # the step body's `samples, targets = mixup_fn(samples, targets)` (supernet_engine.py:52-53) with the recipe of
+        # supernet_train.py:245-251 (mixup 0.8, cutmix 1.0, prob 1.0, switch 0.5, batch mode, label smoothing 0.1): the resident
+        # batch is mixed in place by one launch per step, which also builds the soft targets (csrc/mixup.hip)
+        from cream_amd.autoformer.data import Mixup
+        import numpy as _np
+        _np.random.seed(0 + rank)                             # supernet_train.py:197-199 seeds numpy with seed + rank
+        mixup_fn = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, prob=1.0, switch_prob=0.5, label_smoothing=0.1, num_classes=1000)
+    trainer = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES[a.supernet]["choices"], reducer, amp_dtype=amp, mixup_fn=mixup_fn)
     if a.subnet:                                              # BASELINE config 2: one fixed sub-network
         assert a.subnet == a.supernet, "--subnet X needs --supernet X"
         fixed = SUBNETS[a.subnet]
@@ -562,8 +574,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g)
     labels = torch.randint(0, 1000, (a.batch,), device=dev, generator=g)
-    target = torch.full((a.batch, 1000), 0.1 / 1000, device=dev)
-    target[torch.arange(a.batch, device=dev), labels] += 0.9
+    if mixup_fn is not None:
+        target = labels                                       # class indices: the mixup launch builds the smoothed soft targets
+    else:
+        target = torch.full((a.batch, 1000), 0.1 / 1000, device=dev)
+        target[torch.arange(a.batch, device=dev), labels] += 0.9
 
     def sync():
         if world > 1:
@@ -709,6 +724,8 @@ def main():
                                 # what RCCL was told (unset = library defaults): read a SCALE record against these
                                 "rccl_env": {k: os.environ[k] for k in sorted(os.environ)
                                              if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG")}},
+                       "mixup": ("in the timed region: batch-mode Mixup 0.8 / CutMix 1.0 + label smoothing 0.1 on the device, one launch "
+                                 "per step (csrc/mixup.hip; supernet_engine.py:52-53)" if mixup_fn is not None else "off (precomputed soft targets)"),
                        "gemm": "own MFMA kernels (csrc/gemm_mfma.hpp, gemm_nt8.hpp, gemm_tn8.hpp), no vendor GEMM library",
                        "wgrad_partials": "bf16 token-sliced partial tiles of the weight gradients, added in fp32 in fixed order "
                                          "(cream_block_wgrad_bf16; within 1.9e-3 of fp32 partials, tests/test_block_gpu.py)",

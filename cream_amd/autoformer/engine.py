@@ -201,7 +201,11 @@ class SupernetTrainer:
     """One process = one GPU.  `step(images, target)` is the body of the reference's hot
     loop; gradient averaging across ranks goes through `reducer` (cream_amd.comm)."""
 
-    def __init__(self, model, optimizer, choices, reducer=None, amp_dtype=torch.bfloat16, max_norm=0.0):
+    def __init__(self, model, optimizer, choices, reducer=None, amp_dtype=torch.bfloat16, max_norm=0.0, mixup_fn=None):
+        # mixup_fn: `samples, targets = mixup_fn(samples, targets)` of supernet_engine.py:52-53 (cream_amd.autoformer.data.Mixup:
+        # device batches are mixed in place and the soft targets built by ONE launch, csrc/mixup.hip); None: `target` is
+        # already the (B, classes) soft target
+        self.mixup_fn = mixup_fn
         self.model = model
         self.optimizer = optimizer
         self.choices = choices
@@ -240,7 +244,9 @@ class SupernetTrainer:
         return loss
 
     def step(self, images, target):
-        self.sample()
+        self.sample()                        # (the reference's order: sample, then mixup — supernet_engine.py:43-53)
+        if self.mixup_fn is not None:
+            images, target = self.mixup_fn(images, target)
         loss = self.forward_backward(images, target)
         if self.max_norm and self.max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
