@@ -125,9 +125,48 @@ int launch_nt8(const NtParams& p, hipStream_t st)
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+// Round 6: a 256 x 192 tile (4 x 2 waves of 64 x 96, 112 KB of LDS, one workgroup per CU) for the products whose output is E = 384 or
+// 320 wide (proj, fc2, the fc1 / qkv / proj input gradients): two column tiles, 198 workgroups like the 256-wide tile, but 0 / 17 %
+// padding instead of 25 / 37 %, five fragment reads per six MFMAs, 96 accumulator registers.  Cold probe
+// (profiles/r06_nt_256x192.md): 14-21 % shorter than the kernel chosen before on every such shape, 0.78-1.01 x the vendor library.
+// Measured next to it and dropped: 256 x 160 as 8 x 1 waves of 32 x 160 (80-column wave tiles are no multiple of the 32-wide MFMA
+// block): six reads per five MFMAs want 300 B/clk from a 256 B/clk LDS — slower than every other tile; 256 x 224 the same way needs
+// 98 more registers than a wave has.  E = 448 stays on the 256-wide tiles (12 % padding).
+// Same contraction order per output element as every other tile: bit-identical results.
+// CREAM_GEMM_NTHALF in the environment / cream_gemm_nthalf(): 0 = off, 1 = on (plain and bias epilogues, M >= 1024).
+std::atomic<int> g_nthalf{-1};
+int nthalf_mode()
+{
+    int m = g_nthalf.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_NTHALF");
+        // default 1: same-call step A/B x3 (profiles/r06_nt_256x192.md): 8.945 / 8.952 / 8.903 -> 8.763 / 8.770 / 8.770 ms (-2.0 %)
+        m = e ? atoi(e) : 1;
+        g_nthalf.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+template <int EPI, int BN, int WM, int WN>
+int launch_nt_half(const NtParams& p, hipStream_t st)
+{
+    constexpr int BM = 256;
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1>;
+    constexpr int lds = nt_lds_bytes(BM, BN, 2);
+    if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
+    CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(WM * WN * 64), lds, st, p);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t st)
 {
+    if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
+        if (nthalf_mode() > 0 && p.M >= 1024) {
+            if (p.N == 384 || p.N == 320) return launch_nt_half<EPI, 192, 4, 2>(p, st);
+        }
+    }
     {
         // mode 2: where the cold probe has it ahead (profiles/r05_gemm_probe_cold.txt): every plain / bias product; the two
         // epilogues with element-wise work on the whole tile (GELU, x gelu') stay on the kernels whose second workgroup per CU
@@ -194,6 +233,13 @@ int cream_gemm_nt256(int on)
 {
     const int prev = nt256_mode();
     if (on >= 0) g_nt256.store(on, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_gemm_nthalf(int on)
+{
+    const int prev = nthalf_mode();
+    if (on >= 0) g_nthalf.store(on != 0, std::memory_order_relaxed);
     return prev;
 }
 

@@ -152,17 +152,22 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;                 // MFMA tiles per wave
     constexpr int STAGE = (BM + BN) * BK;                       // bf16 elements per stage
-    constexpr int NPIECE = (BM + BN) / 8 / NW;                  // 1-KB pieces (8 rows) per wave and stage
+    constexpr int PIECES = (BM + BN) / 8;                       // 1-KB pieces (8 rows) per stage
+    constexpr int NPIECE = (PIECES + NW - 1) / NW;              // ... per wave (the last one only for waves < PIECES % NW when ragged)
+    constexpr bool RAGGED = PIECES % NW != 0;
     constexpr int NCH = BN / 4;                                 // 4-float chunks per epilogue row
+    constexpr bool POW2 = (BN & (BN - 1)) == 0;                 // BN = E / 2 tiles (160 / 192 / 224): rotation instead of XOR swizzle
     // the epilogue takes the fp32 tile through ONE stage's LDS in passes of HM rows: as many 32-row MFMA tiles of a wave
-    // row as fit (128 x 128, 128 x 64: 64 rows = a whole wave row, two passes; 256 x 256: 64 of a wave's 128 rows, four)
+    // row as fit (128 x 128, 128 x 64: 64 rows = a whole wave row, two passes; 256 x 256: 64 of a wave's 128 rows, four), or
+    // a whole number of wave rows where a wave row is shorter than what fits (256 x 160 / 224 with eight wave rows of 32: two)
     constexpr int HM_FIT = (STAGE * 2) / (BN * 4) / 32 * 32;
-    constexpr int HM = HM_FIT < WTM ? HM_FIT : WTM;             // rows of one epilogue pass
-    constexpr int NPASS = BM / HM, TMP = HM / 32;               // passes per tile, MFMA row tiles per pass
+    constexpr int HM = HM_FIT < WTM ? HM_FIT : (HM_FIT / WTM) * WTM > BM ? BM : (HM_FIT / WTM) * WTM;   // rows of one epilogue pass
+    constexpr int WR = HM > WTM ? HM / WTM : 1;                 // wave rows that write in one pass
+    constexpr int NPASS = BM / HM, TMP = (HM > WTM ? WTM : HM) / 32;   // passes per tile, MFMA row tiles per wave and pass
     constexpr int SLAB = 128;                                   // rows of one column-sum slab (cream_gemm_rows_per_colsum_slab)
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % (8 * NW) == 0 && (BM / 8) % NW == 0, "tile");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM + BN) % 8 == 0 && (BM / 8) % NW == 0, "tile");
     static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
-    static_assert(HM >= 32 && WTM % HM == 0 && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles of one wave row, inside one stage");
+    static_assert(HM >= 32 && (WTM % HM == 0 || HM % WTM == 0) && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles, inside one stage");
     static_assert(EPI != EPI_MUL_COLSUM || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
     char* const smem = LdsBlock<NST * STAGE * 2>::get();
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             if (row < BM) {
                 src[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + cch[i];
             } else {
-                const int n = min(n0 + row - BM, p.N - 1);
+                const int n = min(n0 + min(row - BM, BN - 1), p.N - 1);    // (ragged last piece: past the tile, never issued)
                 const int seg = (n >= p.nseg) + (n >= 2 * p.nseg);  // at most 3 row segments (q | k | v): no division
                 src[i] = p.B + seg * p.nseg_stride + (int64_t)(n - seg * p.nseg) * p.ldb + cch[i];
             }
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
             const bool isA = i < BM / 8 / NW;                    // pieces wave + NW i < BM / 8 hold A rows
+            if constexpr (RAGGED) { if (i == NPIECE - 1 && wave + NW * i >= PIECES) continue; }    // (wave-uniform)
             const uint16_t* s = src[i] + (isA ? (int64_t)k0 : kb);
             if constexpr (decltype(tail)::value) s += min(0, K - 8 - (k0 + cch[i]));
             __builtin_amdgcn_global_load_lds(
@@ -271,8 +277,15 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     // epilogue geometry: a thread owns an 8-column chunk of rows r0, r0 + RPP, ... of each half tile
     constexpr int CPR = BN / 8;                                 // chunks per tile row
     constexpr int RPP = NT / CPR;                               // rows per pass of the workgroup
-    constexpr int NJ = HM / RPP;                                // rows per thread and half
+    constexpr int NJ = (HM + RPP - 1) / RPP;                    // rows per thread and half
+    constexpr bool EXACT = NT % CPR == 0 && HM % RPP == 0;      // every thread has a chunk in every row group (power-of-two tiles)
     const int cc = tid % CPR, r0 = tid / CPR;
+    const bool epi_thread = EXACT || tid < CPR * RPP;           // (BN = 160 / 192 / 224: 500 / 504 / 504 of 512 threads)
+    // chunk position inside a staged fp32 row: XOR with the row for power-of-two rows, rotation by the row otherwise
+    auto cpos = [&](int ch, int row) -> int {
+        if constexpr (POW2) return ch ^ (row & (NCH - 1));
+        else return (ch + row) % NCH;
+    };
 
     int orig = blockIdx.x;
     const uint16_t* src[NPIECE];
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
 
         // ---- next tile: its first K-step goes to stage 0 now, behind a barrier (every wave is done with the stages)
         const int n = n0 + cc * 8;
-        const bool ncol_ok = n < p.N;                           // N % 8 == 0: a chunk is all in or all out
+        const bool ncol_ok = n < p.N && epi_thread;             // N % 8 == 0: a chunk is all in or all out
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = orig + (int)gridDim.x;
         const bool has_next = next < ntiles;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
 #pragma unroll
         for (int half = 0; half < NPASS; ++half) {
             constexpr int dummy_ = 0; (void)dummy_;
-            const int wm_of_pass = (half * HM) / WTM, tm0 = ((half * HM) % WTM) / 32;     // which wave row / MFMA tiles hold these rows
+            const int wm_of_pass = (half * HM) / WTM, tm0 = WR > 1 ? 0 : ((half * HM) % WTM) / 32;   // which wave row(s) / MFMA tiles hold these rows
             // side inputs of this thread's chunks are requested before the LDS round trip of the accumulators
             u32x4v auxv[EPI == EPI_MUL_COLSUM ? NJ : 1];
             if constexpr (EPI == EPI_MUL_COLSUM) {
@@ -348,21 +361,21 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                 for (int j = 0; j < NJ; ++j) {
                     const int m = cur_m0 + half * HM + r0 + j * RPP;
                     // (read once: non-temporal, like the outputs — profiles/r05_nt_out_stores.md)
-                    auxv[j] = (m < p.M && ncol_ok) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n)) : u32x4v{0, 0, 0, 0};
+                    auxv[j] = (m < p.M && ncol_ok && (EXACT || r0 + j * RPP < HM)) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n)) : u32x4v{0, 0, 0, 0};
                 }
             }
             if (half) __syncthreads();                          // the previous pass has been read
-            if (wm == wm_of_pass) {
+            if (wm >= wm_of_pass && wm < wm_of_pass + WR) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int tmp = 0; tmp < TMP; ++tmp) {
-                        const int ml = tmp * 32 + c32;
+                        const int ml = (WR > 1 ? (wm - wm_of_pass) * WTM : 0) + tmp * 32 + c32;
                         const f32x16& av = acc[tn][tm0 + tmp];
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int ch = (wn * WTN + tn * 32 + 8 * r4 + 4 * g) >> 2;
-                            *reinterpret_cast<f32x4v*>(ctile + ml * BN + ((ch ^ (ml & (NCH - 1))) << 2)) =
+                            *reinterpret_cast<f32x4v*>(ctile + ml * BN + (cpos(ch, ml) << 2)) =
                                 f32x4v{av[4 * r4], av[4 * r4 + 1], av[4 * r4 + 2], av[4 * r4 + 3]};
                         }
                     }
@@ -372,9 +385,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             for (int j = 0; j < NJ; ++j) {
                 const int row = r0 + j * RPP, m = cur_m0 + half * HM + row;
                 if (m >= p.M || !ncol_ok) continue;
-                const int swz = row & (NCH - 1);
-                const f32x4v lo = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (((2 * cc) ^ swz) << 2));
-                const f32x4v hi = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (((2 * cc + 1) ^ swz) << 2));
+                if constexpr (!EXACT) { if (row >= HM) continue; }
+                const f32x4v lo = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (cpos(2 * cc, row) << 2));
+                const f32x4v hi = *reinterpret_cast<const f32x4v*>(ctile + row * BN + (cpos(2 * cc + 1, row) << 2));
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 uint16_t* o = p.out + (int64_t)m * p.ldo + n;
                 if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS) {
@@ -422,8 +435,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                 if (((half + 1) * HM) % SLAB == 0) {            // a 128-row slab is complete: its column sums leave
                     __syncthreads();                            // the fp32 pass has been consumed
                     float* red = ctile;                         // [RPP][BN]
+                    if (epi_thread) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { red[r0 * BN + cc * 8 + e] = cs[e]; cs[e] = 0.f; }
+                        for (int e = 0; e < 8; ++e) { red[r0 * BN + cc * 8 + e] = cs[e]; cs[e] = 0.f; }
+                    }
                     __syncthreads();
                     const int slab = (cur_m0 + (half + 1) * HM) / SLAB - 1;
                     if (slab * SLAB < p.M) {

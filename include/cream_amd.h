@@ -391,6 +391,9 @@ int cream_gemm_nt256(int on);
  * (modes 1 and 2) dy . W is rounded to bf16 before the multiplication by gelu' (as the reference's two operators do); the
  * two-stage kernels (modes 0, 3, 4 — the default) multiply the fp32 accumulator and round once — the results differ by at
  * most one bf16 rounding of the product. */
+/* Round 6: 256 x (E / 2) tiles (column tiles that divide N) for the plain / bias products whose output is 320 / 384 / 448 wide
+ * (csrc/gemm_mfma.hip: launch_nt_half).  1 = on, 0 = off, < 0 queries; returns the previous value; initial: CREAM_GEMM_NTHALF. */
+int cream_gemm_nthalf(int on);
 int cream_gemm_nt8(int mode);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);

@@ -86,10 +86,15 @@ static const Variant VARIANTS[] = {
     V(256, 256, 2, 4, 2, EPI_BIAS, 1), V(256, 256, 2, 4, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 4, 2, EPI_MUL_COLSUM, 1),
     // round 4: the same macro tile with FOUR waves of 128 x 128 (16 accumulator tiles per wave: half the LDS fragment reads per MFMA)
     V(256, 256, 2, 2, 2, EPI_BIAS, 1), V(256, 256, 2, 2, 2, EPI_BIAS_GELU, 1), V(256, 256, 2, 2, 2, EPI_MUL_COLSUM, 1),
+    // round 6: 256 x 192 (two column tiles for N = 384 / 320); 256 x 160 as 8 x 1 waves measured next to it (LDS-read bound, dropped)
+    V(256, 192, 4, 2, 2, EPI_BIAS, 1), V(256, 192, 4, 2, 2, EPI_STORE, 1), V(256, 160, 8, 1, 2, EPI_BIAS, 1),
+    V(256, 192, 4, 2, 2, EPI_BIAS_GELU, 1), V(256, 192, 4, 2, 2, EPI_MUL_COLSUM, 1),
+    V(128, 192, 2, 2, 2, EPI_BIAS, 2), V(128, 192, 2, 2, 2, EPI_BIAS_GELU, 2), V(128, 192, 2, 2, 2, EPI_MUL_COLSUM, 2),
+    V(256, 256, 2, 4, 2, EPI_STORE, 1), V(128, 64, 2, 2, 2, EPI_STORE, 3),
     // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp)
     V8(EPI_BIAS), V8(EPI_STORE), V8(EPI_BIAS_GELU), V8(EPI_MUL_COLSUM),
 };
-static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 512 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
+static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 384 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
     const int ntn = (p.N + v.bn - 1) / v.bn, ntm = (p.M + v.bm - 1) / v.bm, tiles = ntn * ntm;
     static const int persist = getenv("GEMM_ONE_TILE_PER_WG") ? 0 : 1;
@@ -387,6 +392,12 @@ int main(int argc, char** argv)
         {M, 960, 320, 448, 1 << 30, 1 << 30, "fc1 fwd   E320 R3"},
         {M, 320, 320, 448, 1 << 30, 1 << 30, "proj fwd  E320 Q320"},
         {M, 320, 1120, 1792, 1 << 30, 1 << 30, "fc2 fwd   E320 R3.5 (K tail 32)"},
+        // round 6: the input gradients whose output is E wide (transposed operand copies: ldb = the super width of the contraction)
+        {M, 384, 1536, 1792, 1 << 30, 1 << 30, "fc1 dgrad E384 R4"},
+        {M, 320, 960, 1792, 1 << 30, 1 << 30, "fc1 dgrad E320 R3"},
+        {M, 320, 320, 448, 1 << 30, 1 << 30, "proj dgrad E320 Q320"},
+        {1000, 320, 136, 144, 1 << 30, 1 << 30, "ragged check N320 (M edge, K tail 8)"},
+        {1000, 384, 200, 208, 1 << 30, 1 << 30, "ragged check N384 (M edge, K tail 8)"},
     };
     hipblasLtHandle_t lt;
     hipblasLtCreate(&lt);
