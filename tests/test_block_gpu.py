@@ -901,3 +901,47 @@ def test_macro_tile_weight_gradient_kernel_writes_correctly_rounded_partial_tile
     assert worst <= 2.0 ** -7
     assert _rel(bparts.sum(0), dy.float().sum(0)) < 1e-4
     assert _rel(parts.float().sum(0), dy.float().t() @ x.float()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,ldw", [(25216, 384, 1536, 1792), (25216, 320, 960, 1792), (25216, 384, 384, 448), (197 * 8, 320, 320, 448),
+                                        (1000 + 24, 384, 200, 208), (2048 + 8, 320, 136, 144)])
+def test_256x192_nt_tile_matches_fp32_and_the_other_tiles(M, N, K, ldw):
+    """csrc/gemm_mfma.hip launch_nt_half (cream_gemm_nthalf(1), round 6): the 256 x 192 tile — column tiles that are no power of two
+    (rotated fp32 staging rows, 504 of 512 epilogue threads, ragged DMA pieces) — for the plain / bias products whose output is
+    384 or 320 wide (Linear_super.py:38-54, :71-81: proj, fc2, the input gradients of fc1 / qkv / proj): against plain PyTorch fp32
+    and, bit for bit, against the tiles chosen without it; row edges (M % 256 != 0), the 192 + 128 split of N = 320, K tails
+    (200, 136 % 64 != 0), twice in a row."""
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K_
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    wsup = (torch.randn(N + 64, ldw, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N + 64, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, K, device=DEV, generator=g).bfloat16()            # gradient of an (M, K)-wide output: dx = dy . W^T is N wide
+    W = wsup[:N, :K].float()
+
+    def run():
+        out = K_.linear_fwd(x, wsup, bias, N, K)                           # EPI_BIAS, N wide
+        out0 = K_.linear_fwd(x, wsup, None, N, K)
+        # dgrad with an N-wide result: dx (M x N) = dy (M x K) . Wt^T with Wt = wsup[:N, :K] as the (N x K) "transposed copy"
+        dx = K_.linear_dgrad(dy, wsup, K, N)                               # EPI_STORE, N wide
+        return out, out0, dx
+
+    was = lib.cream_gemm_nthalf(-1)
+    try:
+        lib.cream_gemm_nthalf(0)
+        ref = run()
+        lib.cream_gemm_nthalf(1)
+        new = run()
+        again = run()
+    finally:
+        lib.cream_gemm_nthalf(was)
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)
+    out, out0, dx = new
+    assert _rel(out.float(), x.float() @ W.t() + bias[:N].float()) < 1e-2
+    assert _rel(out0.float(), x.float() @ W.t()) < 1e-2
+    assert _rel(dx.float(), dy.float() @ W.t()) < 1e-2
+    for a, b in zip(new, ref):                                             # same contraction order per element, one rounding
+        assert torch.equal(a, b)
