@@ -218,21 +218,37 @@ class CLIP(nn.Module):
         self._image_encoder = ImageEncoder(embed_dim, vision_cfg, quick_gelu)
         self._text_encoder = TextEncoder(embed_dim, text_cfg, quick_gelu)
         self._logit_scale = LogitScale()
+        # per-tower precision (model.py:883-896; train.py:91-99 passes get_autocast(args.image_precision / text_precision /
+        # logit_precision)): context-manager FACTORIES, entered around each tower
+        from contextlib import nullcontext
+        self.image_autocast = self.text_autocast = self.logit_autocast = nullcontext
+
+    def set_autocast(self, image_autocast, text_autocast, logit_autocast):      # model.py:893-896
+        self.image_autocast, self.text_autocast, self.logit_autocast = image_autocast, text_autocast, logit_autocast
 
     visual = property(lambda self: self._image_encoder.visual)
     transformer = property(lambda self: self._text_encoder.transformer)
     logit_scale = property(lambda self: self._logit_scale.logit_scale)
 
-    def encode_image(self, image, normalized=False):
-        return self._image_encoder(image, normalized=normalized)
+    def encode_image(self, image, normalized=False):                            # model.py:1003-1005
+        with self.image_autocast():
+            return self._image_encoder(image, normalized=normalized)
 
-    def encode_text(self, text, normalized=False):
-        return self._text_encoder(text, normalized=normalized)
+    def encode_text(self, text, normalized=False):                              # model.py:1007-1009
+        with self.text_autocast():
+            return self._text_encoder(text, normalized=normalized)
 
-    def forward(self, image, text, normalized=True):
-        fi = self._image_encoder(image, normalized=normalized) if image is not None else None
-        ft = self._text_encoder(text, normalized=normalized) if text is not None else None
-        return fi, ft, self._logit_scale().exp()
+    def forward(self, image, text, normalized=True):                            # model.py:990-1001
+        fi = ft = None
+        if image is not None:
+            with self.image_autocast():
+                fi = self._image_encoder(image, normalized=normalized)
+        if text is not None:
+            with self.text_autocast():
+                ft = self._text_encoder(text, normalized=normalized)
+        with self.logit_autocast():
+            scale = self._logit_scale()
+        return fi, ft, scale.exp()
 
     def load_state_dict(self, state_dict, strict=True):                         # model.py:1049-1070
         return super().load_state_dict(convert_to_new_checkpoint(state_dict), strict=strict)

@@ -266,3 +266,19 @@ def test_checkpoint_layouts_convert_like_the_reference():
     dst = CLIP(c["embed_dim"], dict(c["vision_cfg"]), dict(c["text_cfg"]), quick_gelu=True)
     dst.load_state_dict(old)
     assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+
+
+def test_per_tower_autocast_like_the_reference():
+    """CLIP.set_autocast (model.py:893-896, entered at :990-1001): every tower runs under its OWN precision context — here the image
+    tower under bf16 autocast, the text tower without: the features come back in the dtype the context's matmuls produce, and the
+    defaults (nullcontext) leave the step's outer autocast in charge."""
+    from functools import partial
+    student, _ = _tiny_pair()
+    images, texts = _tiny_batch(4)
+    fi0, ft0, s0 = student(images, texts)
+    assert fi0.dtype == torch.float32 and ft0.dtype == torch.float32
+    student.set_autocast(partial(torch.autocast, "cpu", dtype=torch.bfloat16), __import__("contextlib").nullcontext, __import__("contextlib").nullcontext)
+    fi, ft, s = student(images, texts)
+    assert fi.dtype == torch.bfloat16 and ft.dtype == torch.float32 and s.dtype == torch.float32
+    assert torch.equal(ft, ft0) and torch.allclose(fi.float(), fi0, atol=5e-2, rtol=5e-2)
+    assert student.encode_image(images).dtype == torch.bfloat16 and student.encode_text(texts).dtype == torch.float32
