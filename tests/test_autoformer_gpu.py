@@ -311,3 +311,51 @@ def test_whole_step_at_bench_size_matches_oracle(name):
         assert gb is None or torch.count_nonzero(gb) == 0
     for k, tol in STEP128_TOL.items():
         assert errs[k] < tol, (k, errs[k], worst)
+
+
+def test_checkpoint_resume_on_the_device_continues_bit_for_bit(tmp_path):
+    """SURVEY 8f-4 on the device: the dictionary of supernet_train.py:363-370 written from a model that has trained on the native path
+    (one-launch AdamW with its bf16 operand copies and table images), loaded into a FRESH model + optimizer by the resume rule of
+    :316-330 — the operand copies are derived data, re-derived on load — and both take the same next steps: identical losses and
+    identical weights, bit for bit.  The device Mixup / CutMix launch runs in the step body (numpy-seeded identically)."""
+    import random
+    import numpy as np
+    from cream_amd import comm
+    from cream_amd.autoformer import engine
+    from cream_amd.autoformer.data import Mixup
+
+    def make():
+        torch.manual_seed(0)
+        model = engine.build_supernet("T", drop_path_rate=0.0).to(_dev())
+        opt = engine.build_optimizer(model, batch_size=8)
+        tr = engine.SupernetTrainer(model, opt, engine.SEARCH_SPACES["T"]["choices"], comm.GradReducer(model), mixup_fn=Mixup())
+        return model, opt, tr
+
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    images = torch.randn(8, 3, 224, 224, device=_dev(), generator=g)
+    labels = torch.randint(0, 1000, (8,), device=_dev(), generator=g)
+    model, opt, tr = make()
+    tr.start_epoch(0)
+    np.random.seed(0)
+    for _ in range(2):
+        tr.step(images.clone(), labels)
+    path = engine.save_checkpoint(str(tmp_path / "checkpoint.pth"), model, opt, None, epoch=0, args={"model": "T"})
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert "blocks.0.attn.rel_pos_embed_k.embeddings_table_v" in ck["model"] and not any("bf16" in k or "timg" in k for k in ck["model"])
+    rng_py, rng_np = random.getstate(), np.random.get_state()
+    more = [float(tr.step(images.clone(), labels)) for _ in range(2)]
+
+    model2, opt2, tr2 = make()
+    with torch.no_grad():                                        # a fresh model with OTHER weights: everything must come from the file
+        for p in model2.parameters():
+            p.add_(0.01)
+    ck2 = dict(ck)
+    ck2.setdefault("lr_scheduler", {})                           # (the resume rule wants all three entries)
+    assert engine.load_checkpoint(ck2, model2, opt2, None) == 1
+    tr2.start_epoch(0)
+    random.setstate(rng_py)
+    np.random.set_state(rng_np)
+    again = [float(tr2.step(images.clone(), labels)) for _ in range(2)]
+    assert again == more, (again, more)
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
