@@ -331,7 +331,7 @@ def native_kernel_choice():
     from cream_amd import _lib
     lib = _lib.load()
     return {"cream_gemm_nt8": lib.cream_gemm_nt8(-1), "cream_gemm_nt256": lib.cream_gemm_nt256(-1), "cream_gemm_tn8": lib.cream_gemm_tn8(-1),
-            "cream_gemm_nthalf": lib.cream_gemm_nthalf(-1),
+            "cream_gemm_nthalf": lib.cream_gemm_nthalf(-1), "cream_gemm_ntopt": lib.cream_gemm_ntopt(-1),
             "cream_block_wgrad_bf16": lib.cream_block_wgrad_bf16(-1), "cream_attn_rpe2d_bwd_mode": lib.cream_attn_rpe2d_bwd_mode(-1)}
 
 

@@ -96,6 +96,8 @@ SIGNATURES = {
     "cream_linear_wgrad_splits_bf16": (_i, [_i, _i, _i]),
     "cream_gemm_tn8": (_i, [_i]),
     "cream_gemm_nthalf": (_i, [_i]),
+    "cream_gemm_ntopt": (_i, [_i]),
+    "cream_gemm_stagger": (_i, [_i]),
     "cream_block_layout_epoch": (_i, []),
     "cream_cu_reserve": (_i, [_i]),
     "cream_mixup_cutmix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _f, _vp]),

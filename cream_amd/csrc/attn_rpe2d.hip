@@ -904,6 +904,7 @@ int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
 }
 
 #include "attn_rpe2d_bwd1.hpp"
+#include "attn_rpe2d_bwd2.hpp"
 #include "attn_rpe2d_fwd2.hpp"
 
 // 1: the ping-pong online-softmax forward (attn_rpe2d_fwd2.hpp) whenever the caller hands over the table images
@@ -1446,7 +1447,7 @@ int bwd_onepass_mode() {
     int m = g_bwd_onepass.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("CREAM_ATTN_BWD1");
-        m = e ? (atoi(e) != 0) : 1;              // default ON: same time as the two-launch pair, half its HBM traffic, no side buffers
+        m = e ? atoi(e) : 1;                     // 1: bwd1 (7 waves, both roles per wave); 2: bwd2 (12 waves, the roles on separate waves)
         g_bwd_onepass.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -1467,7 +1468,12 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
         img = own;
     }
     const int grid = aa.nitems < fwd_persistent_grid() ? aa.nitems : fwd_persistent_grid();
-    CREAM_LAUNCH(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, img);
+    if (bwd_onepass_mode() == 2) {
+        if (!cream::raise_dynamic_lds(v4::attn_rpe2d_bwd2_kernel, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
+        CREAM_LAUNCH(v4::attn_rpe2d_bwd2_kernel, dim3(grid), dim3(v4::THREADS), v4::LDS_B, st, aa, img);
+    } else {
+        CREAM_LAUNCH(v2::attn_rpe2d_bwd1_kernel, dim3(grid), dim3(v2::THREADS), v2::LDS_B, st, aa, img);
+    }
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
@@ -1496,7 +1502,7 @@ int cream_attn_rpe2d_padded_len(int N) { return N <= 0 ? 0 : ((N + 31) / 32) * 3
 int cream_attn_rpe2d_bwd_mode(int onepass)
 {
     const int prev = bwd_onepass_mode();
-    if (onepass >= 0) g_bwd_onepass.store(onepass != 0, std::memory_order_relaxed);
+    if (onepass >= 0) g_bwd_onepass.store(onepass > 2 ? 1 : onepass, std::memory_order_relaxed);
     return prev;
 }
 

@@ -78,11 +78,40 @@ int nt256_mode()
     return m;
 }
 
+// Round 6: the two-stage kernels with their tile epilogue off the memory counters (gemm_mfma.hpp, "OPT"): asm LDS-DMA, LDS-only
+// epilogue barriers, side inputs requested under the first K-step, counted wait for the first K-step behind an epilogue
+// (bit 0), and gelu / gelu' of the fc1 epilogue from a 16 KB LDS table instead of ~31 VALU instructions per element (bit 1).
+// Outputs are bit-identical to the OPT = 0 kernels (test_nt_epilogue_variants_are_bit_identical, exhaustive over the bf16
+// values for the table).  CREAM_GEMM_NTOPT in the environment / cream_gemm_ntopt(): 0 = off, 1 = bit 0, 3 = both (default).
+std::atomic<int> g_ntopt{-1};
+int ntopt_mode()
+{
+    int m = g_ntopt.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_NTOPT");
+        m = e ? atoi(e) : 3;
+        g_ntopt.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+// CREAM_GEMM_STAGGER / cream_gemm_stagger(): the second half of a two-workgroups-per-CU grid starts n x 64 clocks late
+std::atomic<int> g_stagger{-1};
+int stagger_mode()
+{
+    int m = g_stagger.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("CREAM_GEMM_STAGGER");
+        m = e ? atoi(e) : 0;
+        g_stagger.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 template <int EPI>
 int launch_nt256(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256, BN = 256;
-    auto kern = gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
+    auto kern = (ntopt_mode() & 1) ? gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
     if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
@@ -151,7 +180,7 @@ template <int EPI, int BN, int WM, int WN>
 int launch_nt_half(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256;
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1>;
+    auto kern = (ntopt_mode() & 1) ? gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
     if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
@@ -188,14 +217,31 @@ int launch_nt(const NtParams& p, hipStream_t st)
         //  9.50 / 9.51 ms per step — the step does not follow the probe there)
         if ((m256 == 1 && p.N >= 960) || (m256 == 2 && p.K >= 1152) || (m256 == 3 && p.K >= 960)) return launch_nt256<EPI>(p, st);
     }
+    const int opt = ntopt_mode();
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
-        CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        NtParams q = p;
+        q.stagger = tiles > slots / 2 ? stagger_mode() : 0;
+        if (EPI == EPI_BIAS_GELU && (opt & 3) == 3) {
+            // + the 16 KB table: 2 x 80 KB = the CU's whole LDS, still two workgroups per CU
+            auto kern = gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC, 3>;
+            constexpr int lds = nt_lds_bytes(BM, BN, 2) + GELU_TAB_BYTES;
+            if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
+            CREAM_LAUNCH(kern, dim3(tiles < slots ? tiles : slots), dim3(256), lds, st, q);
+        } else if (opt & 1) {
+            CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC, 1>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, q);
+        } else {
+            CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, q);
+        }
     } else {
         constexpr int BM = 128, BN = 64, OCC = 3;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
-        CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        if (opt & 1) {
+            CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC, 1>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        } else {
+            CREAM_LAUNCH((gemm_nt_kernel<BM, BN, 2, 2, 2, EPI, OCC>), dim3(tiles < slots ? tiles : slots), dim3(256), 0, st, p);
+        }
     }
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
@@ -240,6 +286,20 @@ int cream_gemm_nthalf(int on)
 {
     const int prev = nthalf_mode();
     if (on >= 0) g_nthalf.store(on != 0, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_gemm_ntopt(int mode)
+{
+    const int prev = ntopt_mode();
+    if (mode >= 0) g_ntopt.store(mode & 3, std::memory_order_relaxed);
+    return prev;
+}
+
+int cream_gemm_stagger(int n)
+{
+    const int prev = stagger_mode();
+    if (n >= 0) g_stagger.store(n, std::memory_order_relaxed);
     return prev;
 }
 

@@ -71,6 +71,7 @@ struct NtParams {
     int64_t ldaux;
     float* colsum;          // EPI_MUL_COLSUM: [ceil(M / BM)][N] per-row-tile column sums of `out`
     int nvalid;             // EPI_BIAS_GELU: columns n >= nvalid are written as zeros (N padded up to a multiple of 8)
+    int stagger;            // > 0: the second half of the grid starts stagger x 64 clocks late (two workgroups per CU out of phase)
 };
 
 // erf-GELU in the epilogues: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26
@@ -119,6 +120,41 @@ __host__ __device__ constexpr int nt_lds_bytes(int BM, int BN, int NST) { return
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- OPT (round 6, last template parameter of gemm_nt_kernel): the tile epilogue off the memory counters ------------------
+// What the ISA of the OPT = 0 kernels shows (tools/isa.sh): the epilogue of a tile is serialised THREE times on memory
+// round trips that have nothing to do with it — __syncthreads() drains vmcnt, so (1) the first epilogue barrier waits for
+// the NEXT tile's first K-step (requested just before: a full L2 / HBM latency), (2) the barrier between the passes waits
+// for the write-back acknowledgement of the first pass's stores, (3) the first K-step of the next tile (vmcnt(0)) waits
+// for the second pass's — and under the GELU epilogue every SIMD spends ~2,000 VALU instructions per wave and tile on
+// erf / exp.  With OPT & 1:
+//   * the LDS-DMA of the operand tiles is an asm statement (the compiler orders every later LDS access behind a BUILTIN
+//     LDS-DMA with vmcnt(0)); every read of a stage already sits behind an explicit wait + barrier;
+//   * the epilogue's barriers wait for LDS traffic only (lgkmcnt(0) + s_barrier);
+//   * the side inputs of the epilogue (bias chunk, the x gelu' factor rows) are requested under the first K-step and are
+//     in registers before the next tile's DMA is issued (a compiler-placed wait for them behind that DMA would drain it);
+//   * the first K-step after the epilogue of a full tile waits with vmcnt(stores of the epilogue): the stores drain under it.
+// With OPT & 2 (EPI_BIAS_GELU): gelu(h) and gelu'(h) of the bf16-ROUNDED h come from a 16 KB LDS table over
+// [sign | exponent 115..130 | mantissa] = every bf16 value with 2^-12 <= |h| < 16, filled once per workgroup by the very
+// phi_parts() the direct path evaluates (identical bits); |h| < 2^-12: gelu' = 1/2 and gelu = h / 2 exactly (both roundings
+// proven by the exhaustive test, tests/test_block_gpu.py); |h| >= 16, inf, nan: the wave falls back to the direct evaluation
+// of that chunk.  ~8 VALU + 1 LDS gather per element instead of ~31 VALU.
+constexpr int GELU_TAB_BYTES = 16384;
+constexpr uint32_t GELU_TAB_LO = 115u << 7;                     // bf16 bits of 2^-12
+
+__device__ __forceinline__ void nt_dma16(const uint16_t* src, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+// LDS-only workgroup barrier (global loads / stores / DMA stay in flight across it)
+__device__ __forceinline__ void nt_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+typedef short nt_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short nt_u16x2 __attribute__((ext_vector_type(2)));
+
 // BM x BN tile, WM x WN waves, NST LDS stages (prefetch distance NST - 1 K-steps, counted vmcnt: the
 // loads of later steps stay in flight across the per-step barrier), OCC = workgroups per CU wanted.
 //
@@ -144,10 +180,13 @@ template <int BYTES> struct LdsBlock<BYTES, true> {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int NST, int EPI, int OCC>
+template <int BM, int BN, int WM, int WN, int NST, int EPI, int OCC, int OPT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const NtParams p)
 {
     constexpr int BK = 64;
+    constexpr bool OPT1 = (OPT & 1) != 0;                       // epilogue off the memory counters (see above)
+    constexpr bool TAB = (OPT & 2) != 0 && EPI == EPI_BIAS_GELU;   // gelu / gelu' from the LDS table
+    static_assert(!(OPT & 2) || OPT1, "the table epilogue builds on the OPT & 1 schedule");
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;                 // MFMA tiles per wave
@@ -169,7 +208,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
     static_assert(NST == 2, "the epilogue borrows stage 1 while stage 0 receives the next tile");
     static_assert(HM >= 32 && (WTM % HM == 0 || HM % WTM == 0) && BM % HM == 0 && HM * BN * 4 <= STAGE * 2, "epilogue passes: whole MFMA tiles, inside one stage");
     static_assert(EPI != EPI_MUL_COLSUM || (BM % SLAB == 0 && SLAB % HM == 0), "column sums leave per 128-row slab");
-    char* const smem = LdsBlock<NST * STAGE * 2>::get();
+    char* const smem = LdsBlock<NST * STAGE * 2 + (TAB ? GELU_TAB_BYTES : 0)>::get();
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem));
     uint16_t* const lds = reinterpret_cast<uint16_t*>(smem);
     float* const ctile = reinterpret_cast<float*>(smem + STAGE * 2);           // stage 1
 
@@ -212,6 +252,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             if constexpr (RAGGED) { if (i == NPIECE - 1 && wave + NW * i >= PIECES) continue; }    // (wave-uniform)
             const uint16_t* s = src[i] + (isA ? (int64_t)k0 : kb);
             if constexpr (decltype(tail)::value) s += min(0, K - 8 - (k0 + cch[i]));
+            if constexpr (OPT1) nt_dma16(s, lds0 + (uint32_t)((buf * STAGE + (wave + NW * i) * 8 * BK) * 2));
+            else
             __builtin_amdgcn_global_load_lds(
                 s, reinterpret_cast<__attribute__((address_space(3))) void*>(
                        reinterpret_cast<uintptr_t>(lds + buf * STAGE + (wave + NW * i) * 8 * BK)), 16, 0, 0);
@@ -287,6 +329,33 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         else return (ch + row) % NCH;
     };
 
+    // younger vector-memory instructions every wave is sure to have issued behind the next tile's first K-step when the
+    // epilogue of a FULL tile is over (a lower bound keeps the counted wait safe): the row stores
+    constexpr int NSTMIN = (EXACT ? NJ : NJ - 1) * NPASS;
+    static_assert(!OPT1 || 2 * NSTMIN <= 63, "vmcnt immediate");
+    // the x gelu' factor rows of ALL passes requested under the first K-step (up to 32 registers; the larger tiles keep the per-pass loads)
+    constexpr bool SIDE_ALL = OPT1 && EPI == EPI_MUL_COLSUM && NPASS * NJ <= 8;
+    bool epi_pending = false;                                   // (wave-uniform) the previous tile's stores may still be draining
+    bool epi_two = false;
+    if constexpr (TAB) {
+        // gelu / gelu' of every bf16 h with 2^-12 <= |h| < 16: entry [sign | exponent - 115 | mantissa] = gelu'(h) << 16 | gelu(h)
+        uint32_t* tab = reinterpret_cast<uint32_t*>(smem + NST * STAGE * 2);
+        for (int i = tid; i < GELU_TAB_BYTES / 4; i += NT) {
+            const uint32_t bits = ((uint32_t)(i >> 11) << 15) | (GELU_TAB_LO + (uint32_t)(i & 0x7FF));
+            const float h = __uint_as_float(bits << 16);
+            float c, e;
+            phi_parts(h, c, e);
+            const uint32_t g16 = f2bf_pair(h * c, 0.f) & 0xFFFFu, p16 = f2bf_pair(fmaf(h * 0.3989422804014327f, e, c), 0.f) & 0xFFFFu;
+            tab[i] = (p16 << 16) | g16;
+        }
+        // (visible to everybody behind the first K-step's barrier)
+    }
+    if (p.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2) {
+        // co-resident workgroups run equal tiles in the same phases (both in the loop, both in the epilogue): the second
+        // half of the grid — the second workgroup of every CU under the dispatcher's round-robin — starts `stagger` x 64 clocks late
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+
     int orig = blockIdx.x;
     const uint16_t* src[NPIECE];
     int t = xcd_remap(orig, ntiles);
@@ -304,11 +373,36 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         //      barrier (the other stage is then free for everyone — on the first step of a tile that is the
         //      previous tile's epilogue LDS), issue step s+1 into it, multiply step s.  Raw s_barrier:
         //      __syncthreads() would drain vmcnt.
+        // side inputs of this tile's epilogue (OPT & 1): requested under the first K-step, in registers before the next
+        // tile's DMA is issued
+        u32x4v braw = u32x4v{0, 0, 0, 0};
+        u32x4v auxall[SIDE_ALL ? NPASS * NJ : 1];
+        auto side_inputs = [&]() {
+            const int n_ = n0 + cc * 8;
+            const bool ok_ = n_ < p.N && epi_thread;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+                if (p.bias && ok_) braw = *reinterpret_cast<const u32x4v*>(p.bias + n_);
+            }
+            if constexpr (SIDE_ALL) {
+#pragma unroll
+                for (int h_ = 0; h_ < NPASS; ++h_)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int m = m0 + h_ * HM + r0 + j * RPP;
+                        auxall[h_ * NJ + j] = (m < p.M && ok_ && (EXACT || r0 + j * RPP < HM)) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n_)) : u32x4v{0, 0, 0, 0};
+                    }
+            }
+        };
         auto top_of_step = [&](int s) {
-            wait_vmcnt<0>();
+            if constexpr (OPT1) {
+                // the first K-step behind an epilogue: only ITS loads (older than the epilogue's stores) are waited for
+                if (s == 0 && epi_pending) { if (epi_two) wait_vmcnt<2 * NSTMIN>(); else wait_vmcnt<NSTMIN>(); }
+                else wait_vmcnt<0>();
+            } else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s + 1 < nk) { if (s + 1 < nfull) issue(src, (s + 1) * BK, (s + 1) & 1, No{}); else issue(src, (s + 1) * BK, (s + 1) & 1, Yes{}); }
+            if constexpr (OPT1) { if (s == 0) side_inputs(); }
         };
         for (int s = 0; s < nfull; ++s) {                       // (the tail step lives outside the loop: one
             top_of_step(s);                                     //  accumulator live range, no phi copies)
@@ -328,7 +422,19 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = orig + (int)gridDim.x;
         const bool has_next = next < ntiles;
-        __syncthreads();
+        if constexpr (OPT1) {
+            nt_lds_barrier();
+            // the side inputs are used HERE (the compiler places its wait for them in front of the next tile's DMA, where
+            // nothing else is outstanding; a wait behind the DMA — which it cannot see — would drain it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(braw[e]));
+            if constexpr (SIDE_ALL) {
+#pragma unroll
+                for (int i = 0; i < NPASS * NJ; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(auxall[i][e]));
+            }
+        } else __syncthreads();
         if (has_next) {
             orig = next;
             t = xcd_remap(orig, ntiles);
@@ -339,8 +445,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         }
 
         // ---- epilogue: two passes of HM rows: accumulators -> LDS (fp32, swizzled [HM][BN]) -> (row, 8 columns) chunks
-        u32x4v braw = u32x4v{0, 0, 0, 0};
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        auto epi_sync = [&]() { if constexpr (OPT1) nt_lds_barrier(); else __syncthreads(); };
+        if constexpr (!OPT1 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU)) {
             if (p.bias && ncol_ok) braw = *reinterpret_cast<const u32x4v*>(p.bias + n);
         }
         float bv[8];
@@ -356,7 +462,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             const int wm_of_pass = (half * HM) / WTM, tm0 = WR > 1 ? 0 : ((half * HM) % WTM) / 32;   // which wave row(s) / MFMA tiles hold these rows
             // side inputs of this thread's chunks are requested before the LDS round trip of the accumulators
             u32x4v auxv[EPI == EPI_MUL_COLSUM ? NJ : 1];
-            if constexpr (EPI == EPI_MUL_COLSUM) {
+            if constexpr (SIDE_ALL) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) auxv[j] = auxall[half * NJ + j];
+            } else if constexpr (EPI == EPI_MUL_COLSUM) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int m = cur_m0 + half * HM + r0 + j * RPP;
@@ -364,7 +473,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     auxv[j] = (m < p.M && ncol_ok && (EXACT || r0 + j * RPP < HM)) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p.aux + (int64_t)m * p.ldaux + n)) : u32x4v{0, 0, 0, 0};
                 }
             }
-            if (half) __syncthreads();                          // the previous pass has been read
+            if (half) epi_sync();                               // the previous pass has been read
             if (wm >= wm_of_pass && wm < wm_of_pass + WR) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
@@ -380,7 +489,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                         }
                     }
             }
-            __syncthreads();
+            epi_sync();
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int row = r0 + j * RPP, m = cur_m0 + half * HM + row;
@@ -399,15 +508,54 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
                     // (supernet_transformer.py:14-16, :276-277).  gelu'(h) = Phi(h) + h phi(h) reuses Phi and the
                     // exponential: it is written INSTEAD of h (the backward needs nothing else of h).
                     u32x4v pb, gb;
+                    uint32_t hbv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hbv[e] = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
+                    bool direct = true;
+                    if constexpr (TAB) {
+                        // packed 16-bit index arithmetic on the two halves of a bf16 pair; table entry = gelu' << 16 | gelu
+                        const unsigned char* tabb = reinterpret_cast<const unsigned char*>(smem + NST * STAGE * 2);
+                        uint32_t big = 0;
+                        uint32_t tl[4], th[4], d2v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t abs2 = hbv[e] & 0x7FFF7FFFu;
+                            const nt_s16x2 d2 = __builtin_bit_cast(nt_s16x2, abs2) - nt_s16x2{(short)GELU_TAB_LO, (short)GELU_TAB_LO};
+                            const nt_s16x2 e2 = __builtin_elementwise_max(d2, nt_s16x2{0, 0});     // |h| < 2^-12 -> the 2^-12 entry (gelu' = 1/2 there too)
+                            const uint32_t e2u = __builtin_bit_cast(uint32_t, e2);
+                            big |= e2u;
+                            const uint32_t idx2 = ((hbv[e] >> 4) & 0x08000800u) | e2u;              // sign -> bit 11
+                            const uint32_t a2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(nt_u16x2, idx2) << nt_u16x2{2, 2});
+                            tl[e] = *reinterpret_cast<const uint32_t*>(tabb + (a2 & 0xFFFFu));
+                            th[e] = *reinterpret_cast<const uint32_t*>(tabb + (a2 >> 16));
+                            d2v[e] = __builtin_bit_cast(uint32_t, d2);
+                        }
+                        // |h| >= 16, inf, nan anywhere in the wave's chunks: the direct evaluation below (wave-uniform branch)
+                        direct = __builtin_amdgcn_ballot_w64((big & 0x78007800u) != 0) != 0;
+                        if (!direct) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t gt = __builtin_amdgcn_perm(th[e], tl[e], 0x05040100u);      // gelu:  low halves
+                                pb[e] = __builtin_amdgcn_perm(th[e], tl[e], 0x07060302u);                  // gelu': high halves
+                                // |h| < 2^-12: gelu(h) = h / 2 (exponent - 1; zero stays zero: saturating subtraction)
+                                const uint32_t tiny = __builtin_bit_cast(uint32_t, __builtin_bit_cast(nt_s16x2, d2v[e]) >> nt_s16x2{15, 15});
+                                const nt_u16x2 habs = __builtin_elementwise_sub_sat(__builtin_bit_cast(nt_u16x2, hbv[e] & 0x7FFF7FFFu), nt_u16x2{0x80, 0x80});
+                                const uint32_t half2 = (hbv[e] & 0x80008000u) | __builtin_bit_cast(uint32_t, habs);
+                                gb[e] = (half2 & tiny) | (gt & ~tiny);
+                            }
+                        }
+                    }
+                    if (direct) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t hb = f2bf_pair(v[2 * e] + bv[2 * e], v[2 * e + 1] + bv[2 * e + 1]);
+                        const uint32_t hb = hbv[e];
                         const float h0 = __uint_as_float(hb << 16), h1 = __uint_as_float(hb & 0xFFFF0000u);
                         float c0, e0, c1, e1;
                         phi_parts(h0, c0, e0);
                         phi_parts(h1, c1, e1);
                         gb[e] = f2bf_pair(h0 * c0, h1 * c1);
                         pb[e] = f2bf_pair(fmaf(h0 * 0.3989422804014327f, e0, c0), fmaf(h1 * 0.3989422804014327f, e1, c1));
+                    }
                     }
                     if (n + 8 > p.nvalid) {                     // padded columns: exact zeros (their gradients vanish)
 #pragma unroll
@@ -433,13 +581,13 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
             }
             if constexpr (EPI == EPI_MUL_COLSUM) {
                 if (((half + 1) * HM) % SLAB == 0) {            // a 128-row slab is complete: its column sums leave
-                    __syncthreads();                            // the fp32 pass has been consumed
+                    epi_sync();                                 // the fp32 pass has been consumed
                     float* red = ctile;                         // [RPP][BN]
                     if (epi_thread) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { red[r0 * BN + cc * 8 + e] = cs[e]; cs[e] = 0.f; }
                     }
-                    __syncthreads();
+                    epi_sync();
                     const int slab = (cur_m0 + (half + 1) * HM) / SLAB - 1;
                     if (slab * SLAB < p.M) {
                         for (int c = tid; c < BN; c += NT) {
@@ -456,6 +604,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt
         }
         GPROF(3);
         if (!has_next) break;
+        if constexpr (OPT1) {
+            // every wave issued all its row stores iff the tile was full (no row past M, no column chunk past N)
+            epi_pending = cur_m0 + BM <= p.M && cur_n0 + BN <= p.N;
+            epi_two = EPI == EPI_BIAS_GELU && p.out != nullptr;
+        }
         // (the first top_of_step of the next tile starts with a barrier: nobody loads into stage 1 — this
         //  epilogue's LDS — before every thread is past its reads)
     }

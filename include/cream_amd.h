@@ -395,6 +395,16 @@ int cream_gemm_nt256(int on);
  * (csrc/gemm_mfma.hip: launch_nt_half).  1 = on, 0 = off, < 0 queries; returns the previous value; initial: CREAM_GEMM_NTHALF. */
 int cream_gemm_nthalf(int on);
 int cream_gemm_nt8(int mode);
+/* Round 6: the two-stage NT kernels with their tile epilogue taken off the memory counters (csrc/gemm_mfma.hpp, "OPT"):
+ * bit 0 = LDS-DMA as asm, LDS-only epilogue barriers, side inputs (bias, the x gelu' factor rows) requested under the first
+ * K-step, counted vmcnt for the first K-step behind an epilogue; bit 1 = gelu(h) / gelu'(h) of cream_linear_gelu_fwd from a
+ * 16 KB LDS table over the bf16 values of h (filled by the same function the direct path evaluates).  mode 0 / 1 / 3
+ * (default 3), < 0 queries; returns the previous value; initial: CREAM_GEMM_NTOPT.  Results are bit-identical in every mode
+ * (tests/test_block_gpu.py::test_nt_epilogue_variants_are_bit_identical; the table exhaustively over all bf16 h, with the one
+ * exception |h| < 2^-125, where gelu(h) differs by less than 1.2e-38). */
+int cream_gemm_ntopt(int mode);
+/* The second half of a two-workgroups-per-CU NT grid starts n x 64 clocks late (A/B switch; default 0); < 0 queries. */
+int cream_gemm_stagger(int n);
 int cream_linear_fwd(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,
                      int64_t ldw, void* stream);
 int cream_linear_fwd_seg(void* out, const void* x, const void* w, const void* bias, int M, int N, int K,

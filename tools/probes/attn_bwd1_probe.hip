@@ -7,6 +7,7 @@
 // the sub-phases of step 3
 #include "../../cream_amd/csrc/attn_rpe2d.hip"
 namespace cream { thread_local hipEvent_t tl_stop_event = nullptr; thread_local hipEvent_t tl_start_event = nullptr; }   // (block_seq.cpp defines them in the library)
+namespace cream { int cu_count() { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 * 8; } }   // (gemm_mfma.hip in the library)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -28,6 +29,7 @@ static void cmp_bf16(Cmp& c, const uint16_t* a, const uint16_t* b, size_t n) {
     }
 }
 
+static int TM = 1;          // one-pass kernel under test: 1 = bwd1 (7 waves), 2 = bwd2 (12 waves, roles on separate waves); BWD_MODE in the environment
 static int run_case(int B, int H, int rounds, float qscale) {
     const int N = 197, gh = 14, gw = 14, mr = 14, NP = 224;
     const int64_t sn = 3 * H * 64, sb = (int64_t)N * sn, sh = 64;
@@ -62,7 +64,7 @@ static int run_case(int B, int H, int rounds, float qscale) {
     };
     rc = bwd(0, g0, tab0); hipDeviceSynchronize();
     if (rc || hipGetLastError() != hipSuccess) { printf("bwd two-launch rc=%d\n", rc); return 1; }
-    rc = bwd(1, g1, tab1);
+    rc = bwd(TM, g1, tab1);
     hipError_t e = hipDeviceSynchronize();
     if (rc || e != hipSuccess) { printf("bwd one-pass rc=%d hip=%s\n", rc, hipGetErrorString(e)); return 1; }
     std::vector<uint16_t> h0(nqkv), h1(nqkv);
@@ -96,7 +98,7 @@ static int run_case(int B, int H, int rounds, float qscale) {
     {
         uint16_t* g2; float* tab2;
         hipMalloc(&g2, nqkv * 2); hipMalloc(&tab2, (size_t)parts * 32768);
-        bwd(1, g2, tab2); hipDeviceSynchronize();
+        bwd(TM, g2, tab2); hipDeviceSynchronize();
         std::vector<uint16_t> h2(nqkv);
         hipMemcpy(h2.data(), g2, nqkv * 2, hipMemcpyDeviceToHost);
         size_t diff = 0;
@@ -144,22 +146,39 @@ static int run_case(int B, int H, int rounds, float qscale) {
         hipFree(dprof);
     }
 #endif
+    if (TM == 2) {          // bwd2 against bwd1: the same bits are expected (same contraction orders, same partial layout)
+        uint16_t* g2; float* tab2;
+        hipMalloc(&g2, nqkv * 2); hipMalloc(&tab2, (size_t)parts * 32768);
+        hipMemset(g2, 0xFF, nqkv * 2);
+        bwd(1, g2, tab2); hipDeviceSynchronize();
+        std::vector<uint16_t> h2(nqkv);
+        hipMemcpy(h2.data(), g2, nqkv * 2, hipMemcpyDeviceToHost);
+        size_t diff = 0;
+        for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n)
+            diff += memcmp(h2.data() + (size_t)b * sb + (size_t)n * sn, h1.data() + (size_t)b * sb + (size_t)n * sn, (size_t)sn * 2) != 0;
+        std::vector<float> t1((size_t)parts * 8192), t2((size_t)parts * 8192);
+        hipMemcpy(t1.data(), tab1, t1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(t2.data(), tab2, t2.size() * 4, hipMemcpyDeviceToHost);
+        const int tdiff = memcmp(t1.data(), t2.data(), t1.size() * 4) != 0;
+        printf("  B=%d H=%d bwd2 vs bwd1: %zu rows differ, table partials %s\n", B, H, diff, tdiff ? "DIFFER" : "identical");
+        if (diff || tdiff) fail = 1;
+        hipFree(g2); hipFree(tab2);
+    }
     if (rounds > 0) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        std::vector<float> t[3];
+        std::vector<float> t[4];
         for (int it = 0; it < rounds; ++it)
-            for (int mode = 0; mode < 3; ++mode) {
+            for (int mode = 0; mode < 4; ++mode) {
                 hipEventRecord(e0);
-                if (mode < 2) bwd(mode, mode ? g1 : g0, mode ? tab1 : tab0);
+                if (mode < 3) bwd(mode, mode ? g1 : g0, mode ? tab1 : tab0);
                 else cream_attn_rpe2d_fwd(dout, dlse, dsp, dqkv, dqkv + H * 64, dqkv + 2 * H * 64, sb, sn, sh, dt, dt + 1920, dt + 3840,
                                           dt + 5760, 64, B, H, N, gh, gw, mr, 0.125f, CREAM_BF16, nullptr);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (it >= 2) t[mode].push_back(ms * 1e3f);
             }
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             std::sort(t[mode].begin(), t[mode].end());
-            printf("  B=%d H=%d %-22s median %.1f us  min %.1f us\n", B, H, mode == 0 ? "bwd two-launch" : mode == 1 ? "bwd one-pass(+images)" : "fwd14",
+            printf("  B=%d H=%d %-22s median %.1f us  min %.1f us\n", B, H, mode == 0 ? "bwd two-launch" : mode == 1 ? "bwd1 one-pass(+images)" : mode == 2 ? "bwd2 one-pass(+images)" : "fwd14",
                    t[mode][t[mode].size() / 2], t[mode][0]);
         }
     }
@@ -172,6 +191,8 @@ static int run_case(int B, int H, int rounds, float qscale) {
 int main(int argc, char** argv) {
     srand(7);
     int fail = 0;
+    if (getenv("BWD_MODE")) TM = atoi(getenv("BWD_MODE"));
+    printf("one-pass mode under test: %d\n", TM);
     fail |= run_case(2, 3, 0, 1.0f);          // fewer items than CUs
     fail |= run_case(3, 5, 0, 2.0f);          // sharper softmax
     fail |= run_case(128, 6, 12, 1.0f);       // the bench shape (3 items per workgroup)

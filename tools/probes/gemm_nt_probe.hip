@@ -74,7 +74,24 @@ __global__ void check_colsum(float* maxerr, NtParams p, int bm) {
 }
 
 
-struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); int nt8 = 0; };
+// position-weighted 64-bit digest of a buffer (bit-identity of two variants' outputs = equal digests)
+__global__ void digest_kernel(unsigned long long* d, const uint16_t* x, size_t n) {
+    unsigned long long acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)x[i] * (2 * i + 1) + ((unsigned long long)x[i] << 40);
+    atomicAdd(d, acc);
+}
+static unsigned long long digest(const void* x, size_t n16) {
+    static unsigned long long* d = nullptr;
+    if (!d) CK(hipMalloc(&d, 8));
+    CK(hipMemset(d, 0, 8));
+    digest_kernel<<<1024, 256>>>(d, (const uint16_t*)x, n16);
+    unsigned long long h; CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    return h;
+}
+
+struct Variant { const char* name; int bm, bn, nt, epi; void (*kern)(const NtParams); int nt8 = 0; int opt = 0; };
+#define VO(BM, BN, WM, WN, NST, EPI, OCC, OPT) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " OPT" #OPT " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC, OPT>, 0, OPT}
 #define V8(EPI) {"nt8 256x256 phase-interleaved " #EPI, 256, 256, 512, EPI, gemm_nt8_kernel<EPI>, 1}
 #define V(BM, BN, WM, WN, NST, EPI, OCC) {#BM "x" #BN " w" #WM "x" #WN " st" #NST " occ" #OCC " " #EPI, BM, BN, WM * WN * 64, EPI, gemm_nt_kernel<BM, BN, WM, WN, NST, EPI, OCC>}
 static const Variant VARIANTS[] = {
@@ -93,6 +110,10 @@ static const Variant VARIANTS[] = {
     V(256, 256, 2, 4, 2, EPI_STORE, 1), V(128, 64, 2, 2, 2, EPI_STORE, 3),
     // round 5: counted-vmcnt, phase-interleaved loop (gemm_nt8.hpp)
     V8(EPI_BIAS), V8(EPI_STORE), V8(EPI_BIAS_GELU), V8(EPI_MUL_COLSUM),
+    // round 6 (last session): the epilogue off the memory counters (OPT 1) and gelu / gelu' from the LDS table (OPT 3)
+    VO(128, 128, 2, 2, 2, EPI_BIAS, 2, 1), VO(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2, 1), VO(128, 128, 2, 2, 2, EPI_BIAS_GELU, 2, 3),
+    VO(128, 128, 2, 2, 2, EPI_MUL_COLSUM, 2, 1), VO(128, 64, 2, 2, 2, EPI_STORE, 3, 1), VO(128, 64, 2, 2, 2, EPI_BIAS, 3, 1),
+    VO(256, 192, 4, 2, 2, EPI_BIAS, 1, 1), VO(256, 192, 4, 2, 2, EPI_STORE, 1, 1), VO(256, 256, 2, 4, 2, EPI_STORE, 1, 1), VO(256, 256, 2, 4, 2, EPI_BIAS, 1, 1),
 };
 static int occ_of(const Variant& v) { return (v.bm + v.bn) >= 384 ? 1 : (v.bm + v.bn) >= 256 ? 2 : 3; }
 static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
@@ -104,7 +125,8 @@ static void launch(const Variant& v, const NtParams& p, hipStream_t st = 0) {
         return;
     }
     const int slots = occ_of(v) * 256;
-    const int lds = nt_lds_bytes(v.bm, v.bn, 2) > 65536 ? nt_lds_bytes(v.bm, v.bn, 2) : 0;
+    const int want = nt_lds_bytes(v.bm, v.bn, 2) + (((v.opt & 2) && v.epi == EPI_BIAS_GELU) ? GELU_TAB_BYTES : 0);
+    const int lds = want > 65536 ? want : 0;
     if (lds) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(v.kern, dim3(persist && tiles > slots ? slots : tiles), dim3(v.nt), lds, st, p);
 }
@@ -450,6 +472,7 @@ int main(int argc, char** argv)
         p.A = dx; p.lda = s.K; p.B = dw; p.ldb = s.ldb;
         p.nseg = s.nseg >= s.N ? s.N : s.nseg; p.nseg_stride = nseg_stride; p.kseg = s.kseg >= s.K ? s.K : s.kseg; p.kseg_stride = kseg_stride;
         p.M = s.M; p.N = s.N; p.K = s.K; p.nvalid = s.N; p.out = dout; p.out2 = dout2; p.ldo = s.N; p.bias = db; p.aux = dh; p.ldaux = s.N; p.colsum = dcs;
+        p.stagger = getenv("GEMM_STAGGER") ? atoi(getenv("GEMM_STAGGER")) : 0;
         ref_nt<<<(unsigned)((no + 255) / 256), 256>>>(dref, p);
         CK(hipDeviceSynchronize());
         // the library on the same problem (plain layouts only): col-major C(N x M) = W('t', lda = ldb) . x('n', ldb = K) + bias
@@ -509,6 +532,8 @@ int main(int argc, char** argv)
             }
             float hm[4];
             CK(hipMemcpy(hm, dmax, 16, hipMemcpyDeviceToHost));
+            const unsigned long long dg1 = digest(dout, no), dg2 = v.epi == EPI_BIAS_GELU ? digest(dout2, no) : 0,
+                                     dg3 = v.epi == EPI_MUL_COLSUM ? digest(dcs, (size_t)((s.M + 127) / 128) * s.N * 2) : 0;
             auto rotated = [&](int i) {
                 NtParams q = p;
                 q.A = rx[i % R]; q.out = ro[i % R]; q.out2 = ro2[i % R]; q.aux = rh[i % R];
@@ -521,8 +546,8 @@ int main(int argc, char** argv)
             hipEventSynchronize(e1);
             const double us = ms(e0, e1) / 20 * 1e3;
             const bool bad = hm[0] > 0.02f || hm[1] > 0.02f || hm[2] > 1e-3f;
-            printf("    %-34s %7.1f us %6.0f TF/s  %5.2fx lib   err out %.2e gelu %.2e colsum %.2e %s\n", v.name, us, fl / us / 1e6,
-                   lib_us > 0 ? lib_us / us : 0.0, hm[0], hm[1], hm[2], bad ? " <-- WRONG" : "");
+            printf("    %-40s %7.1f us %6.0f TF/s  %5.2fx lib   err out %.2e gelu %.2e colsum %.2e  digest %016llx %016llx %016llx%s\n", v.name, us, fl / us / 1e6,
+                   lib_us > 0 ? lib_us / us : 0.0, hm[0], hm[1], hm[2], dg1, dg2, dg3, bad ? " <-- WRONG" : "");
             if (getenv("GEMM_PHASES")) phase_profile(v, p);
         }
         for (int r = 1; r < R; ++r) { hipFree(rx[r]); hipFree(ro[r]); hipFree(ro2[r]); hipFree(rh[r]); hipFree(rl[r]); }
