@@ -1460,6 +1460,7 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
     BwdArgs aa = a;
     aa.nitems = B * a.H;
     aa.stagger = 0;                                  // (de-phasing the workgroups' first items was measured: no gain, profiles/r04_attn_bwd1.md)
+    if (bwd_onepass_mode() == 2) { static const int stg = getenv("CREAM_ATTN_BWD_STAGGER") ? atoi(getenv("CREAM_ATTN_BWD_STAGGER")) : 0; aa.stagger = stg; }   // (< 0: items in (b, h) order)
     const short* img = reinterpret_cast<const short*>(a.timg);
     if (!img) {                                      // no images from the caller: built into the side buffer, one more launch
         short* own = reinterpret_cast<short*>(a.dlt);

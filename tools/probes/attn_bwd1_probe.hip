@@ -112,7 +112,34 @@ static int run_case(int B, int H, int rounds, float qscale) {
         hipFree(g2); hipFree(tab2);
     }
 #ifdef ATTN_PROFILE
-    if (rounds > 0) {
+    if (rounds > 0 && TM == 2) {
+        long long* dprof;
+        const int grid = parts;
+        hipMalloc(&dprof, (size_t)grid * 12 * 12 * 8);
+        hipMemset(dprof, 0, (size_t)grid * 12 * 12 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &dprof, sizeof(dprof));
+        bwd(2, g1, tab1); hipDeviceSynchronize();
+        std::vector<long long> hp((size_t)grid * 12 * 12);
+        hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost);
+        long long* nul = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &nul, sizeof(nul));
+        const char* pn[7] = {"wait for K, V, Q, dO", "prologue (delta, lookups, shifts)", "7 steps", "K / V requests, wait [C]", "shifts, dq product, dQ rows, dL'", "wait [D]", "wait [E] (key-table jobs)"};
+        const char* cn[7] = {"wait for K, V, Q, dO", "value-table job", "7 steps (consume + barriers)", "K / V requests, last consume, [C]", "dK / dV rows", "wait [D]", "key-table job + [E]"};
+        for (int role = 0; role < 2; ++role) {
+            std::vector<double> sum(7, 0.0); double tot = 0; int cnt = 0;
+            for (int blk = 0; blk < grid; ++blk) for (int w = role ? 7 : 0; w < (role ? 12 : 7); ++w) {
+                long long* d = &hp[((size_t)blk * 12 + w) * 12];
+                if (d[7] <= d[0]) continue;
+                for (int i = 0; i < 7; ++i) sum[i] += (double)(d[i + 1] - d[i]);
+                tot += (double)(d[7] - d[0]); ++cnt;
+            }
+            printf("  bwd2 %s, cycles per item and wave (second item of each workgroup, %d waves):\n", role ? "CONSUMERS" : "PRODUCERS", cnt);
+            for (int i = 0; i < 7; ++i) printf("    %-36s %9.0f\n", role ? cn[i] : pn[i], sum[i] / std::max(cnt, 1));
+            printf("    %-36s %9.0f\n", "total", tot / std::max(cnt, 1));
+        }
+        hipFree(dprof);
+    }
+    if (rounds > 0 && TM != 2) {
         long long* dprof;
         const int grid = parts;
         hipMalloc(&dprof, (size_t)grid * 8 * 20 * 8);
@@ -158,9 +185,11 @@ static int run_case(int B, int H, int rounds, float qscale) {
             diff += memcmp(h2.data() + (size_t)b * sb + (size_t)n * sn, h1.data() + (size_t)b * sb + (size_t)n * sn, (size_t)sn * 2) != 0;
         std::vector<float> t1((size_t)parts * 8192), t2((size_t)parts * 8192);
         hipMemcpy(t1.data(), tab1, t1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(t2.data(), tab2, t2.size() * 4, hipMemcpyDeviceToHost);
-        const int tdiff = memcmp(t1.data(), t2.data(), t1.size() * 4) != 0;
-        printf("  B=%d H=%d bwd2 vs bwd1: %zu rows differ, table partials %s\n", B, H, diff, tdiff ? "DIFFER" : "identical");
-        if (diff || tdiff) fail = 1;
+        // (bwd2 adds a workgroup's items in one fp32 chain, bwd1 per item + additions: the partials agree within fp32 rounding)
+        double tmd = 0, tmr = 0;
+        for (size_t i = 0; i < t1.size(); ++i) { tmd = std::max(tmd, (double)std::fabs(t1[i] - t2[i])); tmr = std::max(tmr, (double)std::fabs(t2[i])); }
+        printf("  B=%d H=%d bwd2 vs bwd1: %zu rows differ, table partials max|diff| %.3e (max|ref| %.3e)\n", B, H, diff, tmd, tmr);
+        if (diff || !(tmd <= 2e-6 * tmr + 1e-7)) fail = 1;
         hipFree(g2); hipFree(tab2);
     }
     if (rounds > 0) {
