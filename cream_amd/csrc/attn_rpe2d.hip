@@ -1440,14 +1440,17 @@ int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
-// 1: the one-pass backward (attn_rpe2d_bwd1.hpp) for the AutoFormer geometry in bf16; 0: the two-launch backward.
+// The backward of the AutoFormer geometry in bf16: 0 = the two-launch backward (what every other geometry and fp32 run);
+// 1 = the one-pass kernel with both roles on every wave (attn_rpe2d_bwd1.hpp, 7 waves); 2 = the one-pass kernel with the roles
+// on separate waves and the table gradients in registers (attn_rpe2d_bwd2.hpp, 12 waves) — the DEFAULT: 91.6 against 102.6 us
+// alone at B = 128, H = 6, same-call step A/B x3 8.475 -> 8.321 ms (profiles/r06_attn_bwd2.md).
 // CREAM_ATTN_BWD1 in the environment sets the initial value; cream_attn_rpe2d_bwd_mode() switches it (A/B runs).
 std::atomic<int> g_bwd_onepass{-1};
 int bwd_onepass_mode() {
     int m = g_bwd_onepass.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("CREAM_ATTN_BWD1");
-        m = e ? atoi(e) : 1;                     // 1: bwd1 (7 waves, both roles per wave); 2: bwd2 (12 waves, the roles on separate waves)
+        m = e ? atoi(e) : 2;
         g_bwd_onepass.store(m, std::memory_order_relaxed);
     }
     return m;

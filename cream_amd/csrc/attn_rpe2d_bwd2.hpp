@@ -26,7 +26,7 @@
 //   * the four VALUE-table jobs (X = dO, R = the forward's bucket sums S') are spread over the step loop — the two
 //     MFMAs of query tile s in step s, the S' fragments of tile s + 1 requested a step ahead: 28 KB per item drawn from
 //     HBM while nothing else is (the first build ran them at the top of the item: another burst beside K, V, Q, dO);
-//   * dK / dV rows (consumers, staged through the dO region — dead behind [C]) leave beside the producers'
+//   * dK / dV rows (consumers, staged through the V region — dead since step 6) leave beside the producers'
 //     slot -> bucket shifts, dq product and dQ rows;
 //   * the four KEY-table jobs (X = Q, R = dL') run behind [D] on three consumers.
 //     consumer   key-side jobs q = 2 j + t     value-table jobs   key-table jobs
@@ -274,11 +274,9 @@ __device__ __forceinline__ void producer_items(const BwdArgs& a, const short* im
             lds_barrier();                           // [B] the tiles of step s are in place
         }
         V4_MARK();                                   // 3: steps done
-        // K and V are dead: the next item's start travelling now (28 pieces each over all 12 waves)
-        if (more && !BWD2_EXP_NOLOAD) {
-            mat_dma12(In.kpg, a.sn, lds0 + OFF_K, wave, lane);
-            mat_dma12(In.vpg, a.sn, lds0 + OFF_V, wave, lane);
-        }
+        // K and V are dead.  Every region of the next item is requested as soon as its last reader is through: K now, dO behind
+        // [C] (the consumers stage their rows through the V region), V behind [D], Q behind [E]
+        if (more && !BWD2_EXP_NOLOAD) mat_dma12(In.kpg, a.sn, lds0 + OFF_K, wave, lane);
         if (more) {                                  // (ob, lse_r are dead since the prologue)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ob[ks] = *reinterpret_cast<const bf16x8*>(In.outp + (int64_t)qcl * orow + ks * 16 + g * 8);
@@ -292,6 +290,7 @@ __device__ __forceinline__ void producer_items(const BwdArgs& a, const short* im
             for (int dt = 0; dt < 2; ++dt) ktf[ks][dt] = *reinterpret_cast<const bf16x8*>(img + IMG_KT + (c32 + 32 * dt) * 64 + g * 32 + ks * 8);
         lds_barrier();                               // [C] the consumers are through with the last tiles: the slots are free
         V4_MARK();                                   // 4: behind [C]
+        if (more && !BWD2_EXP_NOLOAD) v2::mat_dma(In.dop, orow, lds0 + OFF_D, wave, lane);         // (7 waves x 4 pieces)
         const int64_t goff = (int64_t)b * a.dsb + (int64_t)(wave * 32) * a.dsn + (int64_t)h * a.dsh;
         {
             bf16x8 bk[4];
@@ -313,17 +312,15 @@ __device__ __forceinline__ void producer_items(const BwdArgs& a, const short* im
         V4_MARK();                                   // 5: epilogue done
         lds_barrier();                               // [D] all dL' tiles are in place
         V4_MARK();                                   // 6: behind [D]
+        if (more && !BWD2_EXP_NOLOAD) mat_dma12(In.vpg, a.sn, lds0 + OFF_V, wave, lane);
         lds_barrier();                               // [E] the key-table jobs are done with Q and the slots
         V4_MARK();                                   // 7: behind [E]
 #ifdef ATTN_PROFILE
         if (item == (int)(blockIdx.x + gridDim.x)) V4_FLUSH();                  // the SECOND item: one with a predecessor and a successor
 #endif
         if (!more) break;
-        // Q and dO of the next item (their last readers are behind [E])
-        if (!BWD2_EXP_NOLOAD) {
-            mat_dma12(In.qp, a.sn, lds0 + OFF_Q, wave, lane);
-            mat_dma12(In.dop, orow, lds0 + OFF_D, wave, lane);
-        }
+        // Q of the next item (its last readers are behind [E])
+        if (!BWD2_EXP_NOLOAD) mat_dma12(In.qp, a.sn, lds0 + OFF_Q, wave, lane);
         item = next;
         I = In;
     }
@@ -410,14 +407,11 @@ __device__ __forceinline__ void consumer_items(const BwdArgs& a, unsigned char* 
             lds_barrier();                           // [B]
         }
         V4_MARK();                                   // 3: steps done
-        if (more && !BWD2_EXP_NOLOAD) {
-            mat_dma12(In.kpg, a.sn, lds0 + OFF_K, wave, lane);
-            mat_dma12(In.vpg, a.sn, lds0 + OFF_V, wave, lane);
-        }
+        if (more && !BWD2_EXP_NOLOAD) mat_dma12(In.kpg, a.sn, lds0 + OFF_K, wave, lane);
         consume(NT - 1);
-        lds_barrier();                               // [C] dO is dead (its last readers: the consume above, the value-table MFMAs of step 6)
+        lds_barrier();                               // [C] (V is dead since step 6: its region stages the rows)
         V4_MARK();                                   // 4: behind [C]
-        unsigned char* stage = smem + OFF_D + c * 4096;
+        unsigned char* stage = smem + OFF_V + c * 4096;
 #pragma unroll
         for (int jb = 0; jb < KJ; ++jb) {
             const int q = c + NCONS * jb;
@@ -429,6 +423,7 @@ __device__ __forceinline__ void consumer_items(const BwdArgs& a, unsigned char* 
         V4_MARK();                                   // 5: rows out
         lds_barrier();                               // [D]
         V4_MARK();                                   // 6: behind [D]
+        if (more && !BWD2_EXP_NOLOAD) mat_dma12(In.vpg, a.sn, lds0 + OFF_V, wave, lane);
         if (more) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -459,10 +454,7 @@ __device__ __forceinline__ void consumer_items(const BwdArgs& a, unsigned char* 
         if (item == (int)(blockIdx.x + gridDim.x)) V4_FLUSH();
 #endif
         if (!more) break;
-        if (!BWD2_EXP_NOLOAD) {
-            mat_dma12(In.qp, a.sn, lds0 + OFF_Q, wave, lane);
-            mat_dma12(In.dop, orow, lds0 + OFF_D, wave, lane);
-        }
+        if (!BWD2_EXP_NOLOAD) mat_dma12(In.qp, a.sn, lds0 + OFF_Q, wave, lane);
         item = next;
         I = In;
     }

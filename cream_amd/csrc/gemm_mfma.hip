@@ -111,7 +111,8 @@ template <int EPI>
 int launch_nt256(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256, BN = 256;
-    auto kern = (ntopt_mode() & 1) ? gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
+    // (bit 2: the macro tiles too — cold probe: 256 x 192 +-1 %, 256 x 256 +12 % SLOWER on fc2 E448: not in the default)
+    auto kern = (ntopt_mode() & 4) ? gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, 2, 4, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
     if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
@@ -180,7 +181,7 @@ template <int EPI, int BN, int WM, int WN>
 int launch_nt_half(const NtParams& p, hipStream_t st)
 {
     constexpr int BM = 256;
-    auto kern = (ntopt_mode() & 1) ? gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1>;
+    auto kern = (ntopt_mode() & 4) ? gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1, 1> : gemm_nt_kernel<BM, BN, WM, WN, 2, EPI, 1>;
     constexpr int lds = nt_lds_bytes(BM, BN, 2);
     if (!cream::raise_dynamic_lds(kern, lds)) return CREAM_ERR_LAUNCH;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = num_cus() / 8 * 8;
@@ -292,7 +293,7 @@ int cream_gemm_nthalf(int on)
 int cream_gemm_ntopt(int mode)
 {
     const int prev = ntopt_mode();
-    if (mode >= 0) g_ntopt.store(mode & 3, std::memory_order_relaxed);
+    if (mode >= 0) g_ntopt.store(mode & 7, std::memory_order_relaxed);
     return prev;
 }
 

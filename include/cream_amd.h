@@ -89,11 +89,14 @@ int cream_attn_rpe2d_padded_len(int N);
 int cream_attn_rpe2d_dtab_parts(int B, int H);
 
 /* Which backward runs for the AutoFormer geometry (N = 197, 14 x 14 grid, max_relative_position 14) in bf16:
- * 1 = the one-pass kernel (csrc/attn_rpe2d_bwd1.hpp: K, V, Q, dO of one (b, h) whole in LDS, P / dS exchanged between
- * the query-tile and key-tile owners through LDS; the side buffers dlt / qe / de / delta are not used as such —
- * the first 32 KB of dlt carry the bf16 operand images of the tables), 0 = the two-launch backward.  onepass < 0
- * only queries.  Returns the previous setting; the initial one comes from CREAM_ATTN_BWD1 in the environment (default 1).
- * (What autograd derives for multihead_super.py:135-154 either way; a switch for same-box A/B measurements.) */
+ * 0 = the two-launch backward; 1 = the one-pass kernel (csrc/attn_rpe2d_bwd1.hpp: K, V, Q, dO of one (b, h) whole in LDS, P / dS
+ * exchanged between the query-tile and key-tile owners through LDS; the side buffers dlt / qe / de / delta are not used as
+ * such — the first 32 KB of dlt carry the bf16 operand images of the tables); 2 = the same pass with the two roles on separate
+ * waves (csrc/attn_rpe2d_bwd2.hpp: 7 query-tile owners + 5 waves sharing the 14 key-side jobs, the table gradients accumulated in
+ * registers over all items of a workgroup and written once) — the DEFAULT.  dq / dk / dv of modes 1 and 2 are bit-identical; the
+ * per-workgroup table-gradient partials of mode 2 are the sums mode 0 forms (one fp32 chain per workgroup).  onepass < 0 only
+ * queries.  Returns the previous setting; the initial one comes from CREAM_ATTN_BWD1 in the environment (default 2).
+ * (What autograd derives for multihead_super.py:135-154 in every mode; a switch for same-box A/B measurements.) */
 int cream_attn_rpe2d_bwd_mode(int onepass);
 
 /* The attention core of AttentionSuper.forward between the qkv and proj GEMMs

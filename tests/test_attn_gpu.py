@@ -195,3 +195,29 @@ def test_kernel_variants_of_the_benchmark_geometry_agree(B, H):
         assert torch.isfinite(a).all()
         # dqkv (bf16): at most one ulp (2^-8) on the largest elements; the four table gradients (fp32 sums): 2e-3
         assert _rel(a, b) < (8e-3 if i == 0 else 2e-3), (i, _rel(a, b))
+
+
+@pytest.mark.parametrize("B,H", [(2, 3), (50, 6), (128, 5), (128, 7)])
+def test_role_split_backward_equals_the_one_pass_kernel(B, H):
+    """csrc/attn_rpe2d_bwd2.hpp (cream_attn_rpe2d_bwd_mode(2), round 6): the one-pass backward with the query-tile owners and
+    the key-tile jobs on separate waves (12 waves of <= 168 registers instead of 7 of 238), the table gradients kept in registers
+    across a workgroup's items.  dq / dk / dv keep bwd1's contraction order: BIT-IDENTICAL; the table gradients are the same
+    products added in one fp32 chain per workgroup instead of per-item chains (= the two-launch kernels' order): 1e-5; a rerun
+    reproduces every bit (multihead_super.py:133-160)."""
+    from cream_amd import _lib
+    lib = _lib.load()
+    qkv, tabs, go = _inputs(B, H, 14, 14, seed=3 * B + H)
+    res = {}
+    prev_b = lib.cream_attn_rpe2d_bwd_mode(-1)
+    try:
+        for bm in (1, 2, 2):
+            lib.cream_attn_rpe2d_bwd_mode(bm)
+            res.setdefault(bm, []).append(_fused(qkv, tabs, go, 14, torch.bfloat16))
+    finally:
+        lib.cream_attn_rpe2d_bwd_mode(prev_b)
+    (_, g1), (_, g2), (_, g2b) = res[1][0], res[2][0], res[2][1]
+    for a, b in zip(g2, g2b):
+        assert torch.equal(a, b)
+    assert torch.isfinite(g2[0]).all() and torch.equal(g2[0], g1[0])
+    for i in range(1, len(g1)):
+        assert torch.isfinite(g2[i]).all() and _rel(g2[i], g1[i]) < 1e-5, (i, _rel(g2[i], g1[i]))

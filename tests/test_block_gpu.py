@@ -945,3 +945,97 @@ def test_256x192_nt_tile_matches_fp32_and_the_other_tiles(M, N, K, ldw):
     assert _rel(dx.float(), dy.float() @ W.t()) < 1e-2
     for a, b in zip(new, ref):                                             # same contraction order per element, one rounding
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K,ldw", [(25216, 1344, 384, 448), (25216, 960, 320, 448), (1000 + 24, 704, 200, 208), (197 * 3, 1792, 448, 448)])
+def test_nt_epilogue_variants_are_bit_identical(M, N, K, ldw):
+    """csrc/gemm_mfma.hpp "OPT" (cream_gemm_ntopt, round 6): the 128-wide two-stage NT kernels with the tile epilogue off the memory
+    counters (asm LDS-DMA, LDS-only barriers, side inputs under the first K-step, counted vmcnt behind an epilogue: bit 0) and
+    gelu / gelu' from the 16 KB LDS table (bit 1) — against the kernels without them, bit for bit, on the fc1 + GELU epilogue
+    (gelu and gelu'), the x gelu' epilogue with its column sums and the bias epilogue (Linear_super.py:71-81,
+    supernet_transformer.py:275-285): full tiles, row / column edges, a K tail, biases that push h out of the table's range."""
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K_
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(31)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    wsup = (torch.randn(N + 64, ldw, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N + 64, device=DEV, generator=g)
+    bias[5], bias[6], bias[7], bias[N - 1] = 40.0, -40.0, 0.0, 17.0            # |h| >= 16: the direct evaluation of the wave's chunk
+    bias = bias.bfloat16()
+    x[3].zero_()                                                               # h = bias exactly in one row
+    dy = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    fac = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    wt = (torch.randn(N + 64, ldw, device=DEV, generator=g) * 0.05).bfloat16()    # (in = N rows, out = K) transposed copy for the dgrad
+
+    def run():
+        gp, ge = K_.linear_gelu_fwd(x, wsup, bias, N, K)
+        _, ge_only = K_.linear_gelu_fwd(x, wsup, bias, N, K, want_grad=False)
+        out = K_.linear_fwd(x, wsup, bias, N, K)
+        dh, parts = K_.linear_dgrad_mul(dy, wt, fac, K, N)                       # dh (M, N) = (dy (M, K) . W) * fac
+        return gp, ge, ge_only, out, dh, parts
+
+    was = lib.cream_gemm_ntopt(-1)
+    try:
+        lib.cream_gemm_ntopt(0)
+        ref = run()
+        res = {}
+        for mode in (1, 3, 3):
+            lib.cream_gemm_ntopt(mode)
+            res.setdefault(mode, []).append(run())
+    finally:
+        lib.cream_gemm_ntopt(was)
+    for mode in (1, 3):
+        for a, b in zip(res[mode][0], ref):
+            assert torch.equal(a, b), mode
+    for a, b in zip(res[3][1], ref):
+        assert torch.equal(a, b)
+    assert torch.equal(ref[1], ref[2])
+    h = (x.float() @ wsup[:N, :K].float().t() + bias[:N].float())
+    assert _rel(ref[1].float(), torch.nn.functional.gelu(h)) < 1e-2
+
+
+def test_gelu_table_epilogue_over_every_bf16_value():
+    """The table path of the fc1 + GELU epilogue (csrc/gemm_mfma.hpp, OPT & 2) against the direct evaluation over EVERY finite bf16
+    value of h — x rows are unit vectors, so h = a weight entry exactly — plus inf / nan / denormals through the bias:
+    bit-identical gelu(h) and gelu'(h), except |h| < 2^-125 (gelu = h / 2 as an exponent decrement: differs by < 1.2e-38)."""
+    from cream_amd import _lib
+    from cream_amd.autoformer import block as K_
+    lib = _lib.load()
+    pats = torch.arange(65536, dtype=torch.int32, device=DEV)
+    finite = pats[((pats >> 7) & 0xFF) != 0xFF]                                 # 65,280 patterns
+    N, K, M = finite.numel() // 8, 8, 256
+    w = finite.to(torch.int16).view(torch.bfloat16).view(N, K).contiguous()
+    x = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    x[torch.arange(M, device=DEV), torch.arange(M, device=DEV) % 8] = 1.0
+    bias0 = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
+    spec = torch.tensor([0x7F80, 0xFF80, 0x7FC0, 0x0001, 0x8001, 0x007F, 0x0080, 0x00FF, 0x0100, 0x8100, 0x3980, 0xB980, 0x397F, 0x417F, 0x4180, 0xC180],
+                        dtype=torch.int32, device=DEV).to(torch.int16).view(torch.bfloat16)
+    N2 = 640
+    bias2 = spec.repeat(N2 // spec.numel())
+    w2 = torch.zeros(N2, K, device=DEV, dtype=torch.bfloat16)
+
+    def run():
+        return K_.linear_gelu_fwd(x, w, bias0, N, K) + K_.linear_gelu_fwd(x, w2, bias2, N2, K)
+
+    was = lib.cream_gemm_ntopt(-1)
+    try:
+        lib.cream_gemm_ntopt(0)
+        ref = run()
+        lib.cream_gemm_ntopt(3)
+        new = run()
+    finally:
+        lib.cream_gemm_ntopt(was)
+    for i, (a, b) in enumerate(zip(new, ref)):
+        ai, bi = a.view(torch.int16), b.view(torch.int16)
+        same = (ai == bi) | (a.isnan() & b.isnan())
+        if same.all():
+            continue
+        # the documented exception: |h| < 2^-125 (bit patterns 0x0001 .. 0x00FF): both results below 1.2e-38
+        bad = ~same
+        assert (a[bad].float().abs() < 1.2e-38).all() and (b[bad].float().abs() < 1.2e-38).all(), (i, int(bad.sum()))
+    # (every finite pattern really went through: row m of the first product is the weight column m % 8 — within the fast erf's error)
+    want = torch.nn.functional.gelu(w.float())
+    got = ref[1][:8].float().t()
+    ok = torch.isfinite(want)
+    assert ((got - want)[ok].abs() <= 1e-2 * want[ok].abs() + 1e-6).all()
