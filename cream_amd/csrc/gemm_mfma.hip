@@ -409,7 +409,10 @@ int tn8_splits(int M, int N, int K)
     // workgroups per launch: HALF the CUs.  In the step the weight gradients share the chip with the main chain and every slice is
     // another partial tile through HBM (same-call A/B, profiles/r05_tn8_step_ab.txt: 256 / 192 / 128 workgroups -> 9.62 / 9.48 /
     // 9.41 ms per step; another box: 128 / 96 / 64 -> 9.69 / 9.77 / 10.1)
-    const int slots = num_cus() / 2 / 8 * 8;
+    // CREAM_WGRAD_CUS in the environment (read once per process: the backward workspace layout depends on it) overrides the share
+    static const int share = getenv("CREAM_WGRAD_CUS") ? atoi(getenv("CREAM_WGRAD_CUS")) : 0;
+    int slots = num_cus() / 2 / 8 * 8;
+    if (share >= 8) slots = (share < num_cus() ? share : num_cus()) / 8 * 8;
     int s = slots / T;
     if (s > steps) s = steps;
     return s < 1 ? 1 : s;
