@@ -218,7 +218,12 @@ int launch_nt(const NtParams& p, hipStream_t st)
         //  9.50 / 9.51 ms per step — the step does not follow the probe there)
         if ((m256 == 1 && p.N >= 960) || (m256 == 2 && p.K >= 1152) || (m256 == 3 && p.K >= 960)) return launch_nt256<EPI>(p, st);
     }
-    const int opt = ntopt_mode();
+    // bit 0 serves the FORWARD epilogues (bias, bias + GELU); the backward's (plain store, x gelu') only with bit 3: in the two-stream
+    // backward a shorter main chain buys 0.4 % of the step and stretches the in-step durations of both streams' kernels by a fifth
+    // (profiles/r06k_step_ab_kernel_timing.txt) — kept as a switch
+    const int mode_ = ntopt_mode();
+    const bool bwd_epi = EPI == EPI_MUL_COLSUM || EPI == EPI_STORE;
+    const int opt = (bwd_epi && !(mode_ & 8)) ? 0 : mode_;
     if (p.N >= 640) {
         constexpr int BM = 128, BN = 128, OCC = 2;
         const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), slots = OCC * num_cus() / 8 * 8;
@@ -293,7 +298,7 @@ int cream_gemm_nthalf(int on)
 int cream_gemm_ntopt(int mode)
 {
     const int prev = ntopt_mode();
-    if (mode >= 0) g_ntopt.store(mode & 7, std::memory_order_relaxed);
+    if (mode >= 0) g_ntopt.store(mode & 15, std::memory_order_relaxed);
     return prev;
 }
 

@@ -400,9 +400,10 @@ int cream_gemm_nthalf(int on);
 int cream_gemm_nt8(int mode);
 /* Round 6: the two-stage NT kernels with their tile epilogue taken off the memory counters (csrc/gemm_mfma.hpp, "OPT"):
  * bit 0 = LDS-DMA as asm, LDS-only epilogue barriers, side inputs (bias, the x gelu' factor rows) requested under the first
- * K-step, counted vmcnt for the first K-step behind an epilogue; bit 1 = gelu(h) / gelu'(h) of cream_linear_gelu_fwd from a
- * 16 KB LDS table over the bf16 values of h (filled by the same function the direct path evaluates).  mode 0 / 1 / 3
- * (default 3), < 0 queries; returns the previous value; initial: CREAM_GEMM_NTOPT.  Results are bit-identical in every mode
+ * K-step, counted vmcnt for the first K-step behind an epilogue — on the 128-wide tiles of the forward products (bias, bias +
+ * GELU); bit 3 (8) = also on the backward's (plain store, x gelu'); bit 2 (4) = also on the 256-wide macro tiles; bit 1 = gelu(h) /
+ * gelu'(h) of cream_linear_gelu_fwd from a 16 KB LDS table over the bf16 values of h (filled by the same function the direct
+ * path evaluates).  Default 3, < 0 queries; returns the previous value; initial: CREAM_GEMM_NTOPT.  Results are bit-identical in every mode
  * (tests/test_block_gpu.py::test_nt_epilogue_variants_are_bit_identical; the table exhaustively over all bf16 h, with the one
  * exception |h| < 2^-125, where gelu(h) differs by less than 1.2e-38). */
 int cream_gemm_ntopt(int mode);
