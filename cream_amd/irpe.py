@@ -219,6 +219,40 @@ class iRPE_Cross(nn.Module):
     def forward(self, x, height=None, width=None):
         return self.rp_rows(x, height=height, width=width) + self.rp_cols(x, height=height, width=width)
 
+    # -- one-table view for the fused kernels (csrc/irpe_attn.hip) --------------------------------------------
+    # rows + cols is ONE lookup per (i, j) into a table over the (row bucket, column bucket) PAIRS that occur:
+    #   x W_r[:, b_r(i,j)] + x W_c[:, b_c(i,j)] = x (W_r[:, b_r] + W_c[:, b_c])        (same for bias / value tables)
+    # With the zoo's ratio (1.9, skip 1) the pairs are the product method's 50 buckets (7 x 7 + the class-token one).
+    mode = property(lambda self: self.rp_rows.mode)
+    transposed = property(lambda self: self.rp_rows.transposed)
+    method = METHOD.CROSS
+
+    @torch.no_grad()
+    def merged_ids_for(self, L, device, height=None, width=None):
+        """-> (int32 (L, L) ids of the occurring (row, col) bucket pairs, long (nb,) row bucket of each pair,
+        long (nb,) column bucket of each pair, nb); cached per (L, device, grid)."""
+        key = (L, str(device), height, width)
+        cache = self.__dict__.setdefault("_merged", {})
+        hit = cache.get(key)
+        if hit is None:
+            br = self.rp_rows.bucket_ids_for(L, device, height, width).long()
+            bc = self.rp_cols.bucket_ids_for(L, device, height, width).long()
+            pairs, inv = torch.unique(br * self.rp_cols.num_buckets + bc, return_inverse=True)
+            hit = (inv.to(torch.int32).contiguous(), pairs // self.rp_cols.num_buckets,
+                   pairs % self.rp_cols.num_buckets, int(pairs.numel()))
+            cache[key] = hit
+        return hit
+
+    def merged_table(self, L, device, height=None, width=None):
+        """The pair table as a differentiable function of the two parameters: (H', nb) bias, (H', d, nb) transposed
+        contextual, (H', nb, d) value side.  fp32, contiguous."""
+        _, ir, ic, _ = self.merged_ids_for(L, device, height, width)
+        if self.mode == 'bias':
+            r, c, dim = self.rp_rows.lookup_table_bias, self.rp_cols.lookup_table_bias, 1
+        else:
+            r, c, dim = self.rp_rows.lookup_table_weight, self.rp_cols.lookup_table_weight, 2 if self.transposed else 1
+        return (r.index_select(dim, ir) + c.index_select(dim, ic)).contiguous()
+
 
 def get_single_rpe_config(ratio=1.9, method=METHOD.PRODUCT, mode='contextual', shared_head=True, skip=0):
     """irpe.py:770-819: alpha = ratio, beta = 2 ratio, gamma = 8 ratio; +1 bucket if skip > 0."""

@@ -8,8 +8,8 @@ and returns (B, L, H*64) ready for the proj linear.
 
 `usable(...)` says whether a given RPEAttention configuration is covered: bf16 operands (autocast),
 head_dim 64, each rpe either absent or an iRPE with at most 64 buckets (product: 50, euclidean /
-quant: <= 64) — contextual, or bias mode on q / k (the lookups are then the bias table itself,
-irpe.py:622-624) — no attention dropout in training.  Everything else (cross method, fp32) takes
+quant: <= 64; cross: rows + cols as ONE table over the occurring bucket pairs, 50 in the zoo — iRPE_Cross.merged_table) —
+contextual, or bias mode on q / k (the lookups are then the bias table itself, irpe.py:622-624).  Everything else (fp32) takes
 the composed path of cream_amd.rpe_attention on the HIP rpe_index operator.
 """
 import ctypes
@@ -52,6 +52,12 @@ def _term(rpe, L, device):
     """-> (table parameter, head stride, query-major ids, key-major ids, nb, bias mode) of one rpe module."""
     if rpe is None:
         return None
+    from .irpe import iRPE_Cross
+    if type(rpe) is iRPE_Cross:          # rows + cols = one lookup over the occurring bucket pairs (irpe.py:758-760)
+        ids, _, _, nb = rpe.merged_ids_for(L, device)
+        asis, tr = bucket_bytes(ids)
+        w = rpe.merged_table(L, device)  # differentiable: the table gradient reaches both parameters through it
+        return w, (0 if w.shape[0] == 1 else w[0].numel()), asis, tr, nb, rpe.mode == "bias"
     ids = rpe.bucket_ids_for(L, device)
     asis, tr = bucket_bytes(ids)
     bias = rpe.mode == "bias"
@@ -69,17 +75,24 @@ def usable(qkv_dtype, device, head_dim, L, rpes, attn_drop_active=False, dropout
         return False
     if device.type != "cuda" or qkv_dtype != torch.bfloat16 or head_dim != 64 or L > 2048:
         return False
-    from .irpe import iRPE
+    from .irpe import iRPE, iRPE_Cross
     nbs = set()
     for r in rpes:
         if r is None:
             continue
-        if type(r) is not iRPE or r.mode not in ("contextual", "bias") or r.num_buckets > 64:
+        if type(r) is iRPE_Cross:
+            parts, nb = (r.rp_rows, r.rp_cols), r.merged_ids_for(L, device)[3]
+        else:
+            parts, nb = (r,), r.num_buckets
+        for m in parts:
+            if type(m) is not iRPE or m.mode not in ("contextual", "bias"):
+                return False
+            w = m.lookup_table_bias if m.mode == "bias" else m.lookup_table_weight
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                return False
+        if nb > 64:
             return False
-        w = r.lookup_table_bias if r.mode == "bias" else r.lookup_table_weight
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            return False
-        nbs.add(r.num_buckets)
+        nbs.add(nb)
     return len(nbs) <= 1
 
 

@@ -345,3 +345,36 @@ def test_dropout_keep_mask_restatement_is_deterministic_and_unbiased():
     assert 0.47 < agree < 0.53
     assert 0.47 < ((h1[0, 0] >> 31) == (h1[0, 1] >> 31)).mean() < 0.53
     assert irpe_fused.dropout_threshold(0.5) == 2 ** 31 and irpe_fused.dropout_threshold(1e-12) == 1
+
+
+@pytest.mark.parametrize("mode,rpe_on,L", [("ctx", "kv", 197), ("bias", "k", 196), ("ctx", "q", 50)])
+def test_cross_one_table_view_equals_rows_plus_cols(mode, rpe_on, L):
+    """iRPE_Cross.merged_table / merged_ids_for (the operand the fused kernels take for the cross method): one lookup over
+    the occurring (row bucket, col bucket) pairs is rows + cols of irpe.py:758-760, values and parameter gradients."""
+    torch.manual_seed(3)
+    cfg = I.get_rpe_config(ratio=1.9, method="cross", mode=mode, shared_head=False, skip=0 if L == 196 else 1, rpe_on=rpe_on)
+    for m in I.build_rpe(cfg, head_dim=16, num_heads=2):
+        if m is None:
+            continue
+        params = [p for p in m.parameters()]
+        with torch.no_grad():
+            for p in params:
+                p.normal_()
+        ids, ir, ic, nb = m.merged_ids_for(L, "cpu")
+        assert ids.dtype == torch.int32 and ids.shape == (L, L) and int(ids.max()) == nb - 1 and nb <= 64
+        table = m.merged_table(L, "cpu")
+        x = torch.randn(2, 2, L, 16 if m.transposed else L)
+        if not m.transposed:
+            x = x.softmax(-1)
+        want = m(x)
+        if mode == "bias":
+            got = table[:, ids.flatten().long()].view(1, 2, L, L)
+        elif m.transposed:
+            got = (x @ table.unsqueeze(0)).gather(-1, ids.long().expand(2, 2, L, L))
+        else:
+            sums = torch.zeros(2, 2, L, nb).scatter_add_(-1, ids.long().expand(2, 2, L, L), x)
+            got = sums @ table.unsqueeze(0)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
+        g = torch.randn_like(want)
+        for a, b in zip(torch.autograd.grad(got, params, g), torch.autograd.grad(want, params, g)):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)

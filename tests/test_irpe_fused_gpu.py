@@ -38,23 +38,28 @@ def _restatement(qkv, scale, mods, round_lookups=True, keep=None, ids=None):
     def bias_of(m):                                                            # (1, H', L, L), irpe.py:622-624
         return m.lookup_table_bias.float()[:, ids_of(m).flatten()].view(1, -1, L, L)
 
-    if rk is not None and rk.mode == "bias":
-        a = a + bias_of(rk)
-    elif rk is not None:
-        lk = rnd(qs @ w_of(rk))                                                # the autocast matmul's output dtype
-        a = a + lk.gather(-1, ids_of(rk).expand(*lk.shape[:2], L, L))
-    if rq is not None and rq.mode == "bias":
-        a = a + bias_of(rq).transpose(2, 3)
-    elif rq is not None:
-        lq = rnd((k * scale) @ w_of(rq))
-        a = a + lq.gather(-1, ids_of(rq).expand(*lq.shape[:2], L, L)).transpose(2, 3)
+    def parts(m):                                   # iRPE_Cross = rows + cols, two plain iRPE modules (irpe.py:758-760)
+        return [] if m is None else ([m.rp_rows, m.rp_cols] if hasattr(m, "rp_rows") else [m])
+
+    for m in parts(rk):
+        if m.mode == "bias":
+            a = a + bias_of(m)
+        else:
+            lk = rnd(qs @ w_of(m))                                             # the autocast matmul's output dtype
+            a = a + lk.gather(-1, ids_of(m).expand(*lk.shape[:2], L, L))
+    for m in parts(rq):
+        if m.mode == "bias":
+            a = a + bias_of(m).transpose(2, 3)
+        else:
+            lq = rnd((k * scale) @ w_of(m))
+            a = a + lq.gather(-1, ids_of(m).expand(*lq.shape[:2], L, L)).transpose(2, 3)
     p = a.softmax(-1)
     if keep is not None:                                                       # attn_drop (:86): mask / (1 - rate), given
         p = p * keep
     out = p @ v
-    if rv is not None:
-        sv = torch.zeros(*p.shape[:3], rv.num_buckets, device=p.device).scatter_add_(-1, ids_of(rv).expand_as(p), p)
-        out = out + sv @ w_of(rv)
+    for m in parts(rv):
+        sv = torch.zeros(*p.shape[:3], m.num_buckets, device=p.device).scatter_add_(-1, ids_of(m).expand_as(p), p)
+        out = out + sv @ w_of(m)
     return out.transpose(1, 2).reshape(q.shape[0], L, -1)
 
 
@@ -112,6 +117,65 @@ def test_fused_irpe_attention_matches_restatement(case):
     bound = 1.3e-2 if method == "product" else 5e-2
     for k, v in errs.items():
         assert v < bound, (k, v, errs)
+
+
+@pytest.mark.parametrize("case", [("k", True, 197, "ctx"), ("qkv", False, 197, "ctx"), ("qkv", True, 577, "ctx"), ("k", False, 196, "ctx"),
+                                  ("qk", False, 197, "bias")], ids=lambda c: "-".join(str(x) for x in c))
+def test_fused_cross_method_matches_rows_plus_cols(case):
+    """iRPE_Cross (irpe.py:696-767: a rows iRPE + a cols iRPE, two gathers summed) on the fused kernels as ONE table over the
+    occurring (row bucket, col bucket) pairs; the restatement evaluates the two modules separately, as the reference does, and
+    the gradients are those of the four (six) parameters themselves."""
+    from cream_amd import irpe as I, irpe_fused
+    rpe_on, shared, L, mode = case
+    B, H = 2, 3
+    torch.manual_seed(5)
+    cfg = I.get_rpe_config(ratio=1.9, method="cross", mode=mode, shared_head=shared, skip=0 if L == 196 else 1, rpe_on=rpe_on)
+    mods = list(I.build_rpe(cfg, head_dim=64, num_heads=H))
+    params = []
+    for m in mods:
+        if m is not None:
+            assert type(m) is I.iRPE_Cross
+            m.to(DEV)
+            for part in (m.rp_rows, m.rp_cols):
+                with torch.no_grad():
+                    _table(part).copy_(0.3 * torch.randn_like(_table(part)))
+                params.append(_table(part).requires_grad_())
+    qkv = (0.8 * torch.randn(B, L, 3, H, 64, device=DEV)).to(torch.bfloat16).requires_grad_()
+    gy = torch.randn(B, L, H * 64, device=DEV).to(torch.bfloat16)
+    assert irpe_fused.usable(qkv.dtype, qkv.device, 64, L, mods, False)
+    y = irpe_fused.attention(qkv, 0.125, *mods)
+    got = torch.autograd.grad(y, [qkv] + params, gy)
+    ref = _restatement(qkv, 0.125, mods)
+    want = torch.autograd.grad(ref, [qkv] + params, gy.float())
+    errs = dict(y=max_rel(y.float(), ref))
+    for name, a, b in zip(["dq", "dk", "dv"], got[0].float().unbind(2), want[0].float().unbind(2)):
+        errs[name] = max_rel(a, b)
+    for i, (a, b) in enumerate(zip(got[1:], want[1:])):
+        assert a.shape == b.shape
+        errs[f"dW{i}"] = max_rel(a.float(), b.float())
+    print(f"[fused irpe cross {rpe_on} {mode} shared={shared} L={L}]", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(torch.isfinite(t).all() for t in got)
+    # rows / cols tables have 8 buckets each; a row (col) bucket gradient sums the near-cancelling dS of a whole stripe of keys
+    # (the euclidean / quant bound of the test above)
+    for k, v in errs.items():
+        assert v < 5e-2, (k, v, errs)
+
+
+def test_cross_module_takes_the_fused_path_under_autocast():
+    from cream_amd import irpe as I, timing
+    from cream_amd.rpe_attention import RPEAttention
+    cfg = I.get_rpe_config(ratio=1.9, method="cross", mode="ctx", shared_head=True, skip=1, rpe_on="qkv")
+    att = RPEAttention(192, num_heads=3, qkv_bias=True, rpe_config=cfg).to(DEV)
+    x = torch.randn(2, 197, 192, device=DEV, requires_grad=True)
+    timing.reset()
+    timing.enable(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = att(x)
+    y.float().sum().backward()
+    timing.enable(False)
+    names = set(timing.summary())
+    assert {"irpe_attn_fwd", "irpe_attn_bwd"} <= names and not {"rpe_index_fwd", "rpe_index_bwd"} & names, names
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in att.parameters())
 
 
 def test_module_takes_the_fused_path_under_autocast():
