@@ -18,11 +18,12 @@
 // attn_common.hpp, so a lane holds 16 partners of ONE own token: the bias gather is 16 LDS reads from
 // lookup rows lk[token][bucket] (bf16 like the reference's autocast matmul result; pitch 33 words: the
 // bucket of a pair is data, so the reads are a random bank pattern whatever the pitch — an odd one
-// keeps rows from aliasing), the bucket ids come as bytes, four consecutive partners per 32-bit LDS
-// read, from a (128 x 32) id tile that the workgroup stages with coalesced 16-byte loads next to the
-// operand tiles.  The bucket tables are converted once per (table, device) to padded uint8 matrices
-// in BOTH orientations (query-major for the kernels whose lanes own queries, key-major for the dK/dV
-// kernel), 370 KB at L=577: L2 resident.  Scatter-adds (value-side bucket sums, bucket gradients) are
+// keeps rows from aliasing), the bucket ids come as bytes: the 16 ids of a lane and tile are ONE 16-byte
+// load from a byte matrix into registers (round 6; rounds 2-5 staged (128 x 32)-byte id tiles in LDS:
+// 9 KB per table, and with them the kv / qkv kernels did not fit twice on a CU).  The bucket tables are
+// converted once per (table, device) to padded uint8 matrices in BOTH orientations (query-major for the
+// kernels whose lanes own queries, key-major for the dK/dV kernel), every 32-byte group in lane order
+// (bucket_bytes_kernel), 370 KB at L=577: L2 resident.  Scatter-adds (value-side bucket sums, bucket gradients) are
 // LDS float atomics into rows owned by the wave.
 //
 // Forward softmax is two-pass (max first, then exp / sums / P.V): the bucket sums cannot be rescaled
@@ -54,9 +55,16 @@ using F = TT::frag;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KP = 72;      // pitch (bf16) of row-major [32][64] tiles and of the [64][64] tables
 constexpr int VTP = 36;     // pitch (bf16) of transposed [64][32] tiles read with load_perm
-constexpr int LKP = 65;     // pitch (fp32) of scatter-add rows (LDS float atomics)
-constexpr int LBP = 66;     // pitch (bf16) of lookup rows: 33 words
-constexpr int IDP = 36;     // pitch (bytes) of an id tile row: 32 partners + 4
+// Pitches of the per-token rows in LDS: fp32 scatter-add rows (bucket sums / bucket gradients) and bf16 lookup rows, both an odd
+// number of words.  SM: tables of at most 51 buckets (every configuration of the zoo: product 50, cross 50, euclidean / quant fewer)
+// take rows of 51 floats / 27 words instead of 65 / 33 — with the id tiles gone (ids_load) that is what lets the kernels with rpe on
+// q, k and v stay twice on a CU (160 KB): forward 86 -> 74 KB, dK/dV launch 90 -> 77 KB.  Columns past the pitch do not exist: every
+// 64-wide access of a row is guarded by its column (compile-time for most, the lane group g for the rest).
+template <bool SM> struct Pitch {
+    static constexpr int LK = SM ? 51 : 65;     // fp32 scatter-add rows
+    static constexpr int LB = SM ? 54 : 66;     // bf16 lookup rows: 27 / 33 words
+};
+constexpr int SM_MAX_NB = 51;
 constexpr int QW = 4;       // waves (32-token tiles) per workgroup
 
 struct Args {
@@ -153,28 +161,23 @@ __device__ __forceinline__ void rows_store_T(short* dst, const u32x4v& x, int pi
     for (int e = 0; e < 8; ++e) dst[(cc * 8 + e) * pitch + row] = u.e[e];
 }
 // lookup rows (bf16 [32][64] contiguous in global) -> [32][LBP]
-__device__ __forceinline__ void lrows_store(short* dst, const u32x4v& x) {
+template <int LBP> __device__ __forceinline__ void lrows_store(short* dst, const u32x4v& x) {
     const int row = threadIdx.x >> 3, cc = threadIdx.x & 7;
     uint32_t* d = reinterpret_cast<uint32_t*>(dst + row * LBP + cc * 8);
-    d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
-}
-// id tile: 128 own rows x 32 partners; thread -> (row tid >> 1, half tid & 1)
-__device__ __forceinline__ u32x4v ids_load(const uint8_t* tab, int NP, int row0, int t) {
-    const int row = min(row0 + (int)(threadIdx.x >> 1), NP - 1);
-    return *reinterpret_cast<const u32x4v*>(tab + (int64_t)row * NP + t * 32 + (threadIdx.x & 1) * 16);
-}
-__device__ __forceinline__ void ids_store(unsigned char* tile, const u32x4v& x) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(tile + (threadIdx.x >> 1) * IDP + (threadIdx.x & 1) * 16);
-    d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
-}
-// the 16 bucket ids of this lane's (own row, partners acc_row(r, g)) in a staged id tile
-__device__ __forceinline__ void lane_ids(uint32_t (&w)[4], const unsigned char* tile, int row, int g) {
-    const unsigned char* p = tile + row * IDP + 4 * g;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) w[rr] = *reinterpret_cast<const uint32_t*>(p + 8 * rr);
+    for (int i = 0; i < 4; ++i)
+        if (LBP >= 64 || cc * 8 + 2 * i + 1 < LBP) d[i] = x[i];
 }
-// the staged bytes hold 2 * bucket id: the byte offset of the bucket in a bf16 lookup row
-__device__ __forceinline__ int off2_of(const uint32_t (&w)[4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+// The 16 bucket ids of this lane's (own row, partners acc_row(r, g), r = 0..15) of streamed tile t: ONE 16-byte load from the
+// byte matrix straight into registers.  bucket_bytes_kernel stores every 32-byte group of a row in that order (lane group g = 0
+// first), so the two lanes of an own row read the two halves of one 32-byte piece and a wave reads 32 such pieces — the access
+// pattern the staged id tiles had (round 2-5: a (128 x 32)-byte tile per table, double-buffered in LDS, 27 KB with rpe on q, k
+// and v), without the LDS tile, its store and its four reads per lane.
+__device__ __forceinline__ u32x4v ids_load(const uint8_t* tab, int NP, int row, int t, int g) {
+    return *reinterpret_cast<const u32x4v*>(tab + (int64_t)min(row, NP - 1) * NP + t * 32 + g * 16);
+}
+// the bytes hold 2 * bucket id: the byte offset of the bucket in a bf16 lookup row
+__device__ __forceinline__ int off2_of(const u32x4v& w, int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
 // acc += (bf16 at byte offset off2 of row): one v_dot2c_f32_bf16 with (x, 0) . (1, 1) instead of shift + add
 typedef __bf16 hwbf16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float add_bf16_at(float acc, const short* row, int off2) {
@@ -188,7 +191,7 @@ __device__ __forceinline__ float add_bf16_at(float acc, const short* row, int of
 // the second half adds onto the first half's sums — and each half goes 8 pairs at a time: 8 reads,
 // duplicates inside the group resolved in registers (the latest earlier match carries the running sum,
 // and the last write to an address is the complete one), 8 writes.
-__device__ __forceinline__ void scatter_add16(float* row, const uint32_t (&w)[4], const f32x16& val, int g) {
+__device__ __forceinline__ void scatter_add16(float* row, const u32x4v& w, const f32x16& val, int g) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (g == half) {
@@ -230,7 +233,7 @@ template <typename Body> __device__ __forceinline__ void stream(int n, Body&& bo
 }
 
 // lookups^T (64 buckets x 32 own rows) = tab(64 buckets x 64 d) . X^T  ->  scr[row][bucket] (bf16) * mul
-__device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, const F (&xb)[4], float mul, int lane) {
+template <int LBP> __device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, const F (&xb)[4], float mul, int lane) {
     const int c32 = lane & 31, g = lane >> 5;
     f32x16 a0 = {}, a1 = {};
 #pragma unroll
@@ -242,15 +245,16 @@ __device__ __forceinline__ void lookups_to_lds(short* scr, const short* tab, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         row[acc_row(r, g)] = f2bf(a0[r] * mul);
-        row[32 + acc_row(r, g)] = f2bf(a1[r] * mul);
+        if (LBP >= 64 || 32 + acc_row(r, g) < LBP) row[32 + acc_row(r, g)] = f2bf(a1[r] * mul);
     }
 }
 // bias mode: the lookups do not depend on the token — every row of a [32][LBP] block is the head's bias table
-__device__ __forceinline__ void bias_rows_to_lds(short* scr, const float* bias, int nb, int lane) {
+template <int LBP> __device__ __forceinline__ void bias_rows_to_lds(short* scr, const float* bias, int nb, int lane) {
     const int c32 = lane & 31, g = lane >> 5;
     short* row = scr + c32 * LBP + g * 32;
 #pragma unroll 8
-    for (int e = 0; e < 32; ++e) row[e] = f2bf(g * 32 + e < nb ? bias[g * 32 + e] : 0.f);
+    for (int e = 0; e < 32; ++e)
+        if (LBP >= 64 || g * 32 + e < LBP) row[e] = f2bf(g * 32 + e < nb ? bias[g * 32 + e] : 0.f);
 }
 
 // this lane's half of a bf16 lookup row (buckets ks*16 + g*8 .. +7, ks = 0..3) -> global row of 64
@@ -262,10 +266,10 @@ __device__ __forceinline__ void lrow_to_global(short* dst, const short* row, int
     }
 }
 // fragment of 8 consecutive values (buckets ks*16 + g*8 ..) of an fp32 scatter-add row, times mul
-__device__ __forceinline__ F srow_frag(const float* row, int ks, int g, float mul) {
+template <int LKP> __device__ __forceinline__ F srow_frag(const float* row, int ks, int g, float mul) {
     f32x8v x;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = row[ks * 16 + g * 8 + e] * mul;
+    for (int e = 0; e < 8; ++e) x[e] = (LKP >= 64 || ks * 16 + g * 8 + e < LKP) ? row[ks * 16 + g * 8 + e] * mul : 0.f;
     return __builtin_bit_cast(F, __builtin_convertvector(x, hwbf16x8));
 }
 __device__ __forceinline__ void store_row64(short* op, const f32x16 (&o)[2], int g, float mul) {
@@ -301,16 +305,14 @@ __device__ __forceinline__ F load_perm_tr(const short* rows, int dt, int s2, int
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <bool HQ, bool HK, bool HV> struct LdsF {
+template <bool HQ, bool HK, bool HV, bool SM> struct LdsF {
+    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     static constexpr int kbuf = 0;                                   // 2 x [32][KP] bf16
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP] bf16 (read transposed: load_perm_tr)
-    static constexpr int idk = vbuf + 2 * 32 * KP * 2;               // 2 x [128][IDP] bytes
-    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
-    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
-    static constexpr int wkT = idq + (HQ ? 2 * 128 * IDP : 0);       // [64 buckets][KP] bf16
-    static constexpr int wqT = wkT + (HK ? 64 * KP * 2 : 0);
-    static constexpr int wvT = wqT + (HQ ? 64 * KP * 2 : 0);         // [64 d][KP] bf16 (columns = buckets)
-    static constexpr int lk = wvT + (HV ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
+    static constexpr int wkT = 0;                                    // [64 buckets][KP] bf16: prologue only, over the tile area
+    static constexpr int wvT = 0;                                    // [64 d][KP] bf16 (columns = buckets): epilogue only, over the tile area
+    static constexpr int wqT = vbuf + 2 * 32 * KP * 2;               // [64 buckets][KP] bf16: every key tile (lq_tile)
+    static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
     static constexpr int sv = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LKP] fp32
     static constexpr int lq = sv + (HV ? QW * 32 * LKP * 4 : 0);     // 2 x [32 keys][LBP] bf16
     static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
@@ -319,31 +321,27 @@ template <bool HQ, bool HK, bool HV> struct LdsF {
 // S^T tile (rows = streamed tokens, column = own token) with the relative position terms:
 //   own_row[id_own]             lookups indexed by the lane's own token        (ids in own_ids)
 //   side[partner][id_side]      lookups indexed by the streamed token          (ids in side_ids)
-template <bool OWN, bool SIDE>
-__device__ __forceinline__ f32x16 score_tile(const short* rows, const F (&own)[4], const unsigned char* own_ids,
-                                             const unsigned char* side_ids, const short* own_row, const short* side,
-                                             int trow, int lane) {
+template <bool OWN, bool SIDE, int LBP>
+__device__ __forceinline__ f32x16 score_tile(const short* rows, const F (&own)[4], const u32x4v& own_ids,
+                                             const u32x4v& side_ids, const short* own_row, const short* side, int lane) {
     const int c32 = lane & 31, g = lane >> 5;
     f32x16 s = {};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) s = TT::mma(TT::load(rows + c32 * KP + ks * 16 + g * 8), own[ks], s);
     if constexpr (OWN) {
-        uint32_t w[4];
-        lane_ids(w, own_ids, trow, g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], own_row, off2_of(w, r));
+        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], own_row, off2_of(own_ids, r));
     }
     if constexpr (SIDE) {
-        uint32_t w[4];
-        lane_ids(w, side_ids, trow, g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], side + acc_row(r, g) * LBP, off2_of(w, r));
+        for (int r = 0; r < 16; ++r) s[r] = add_bf16_at(s[r], side + acc_row(r, g) * LBP, off2_of(side_ids, r));
     }
     return s;
 }
 
 // rpe_q lookups of a staged key tile, shared by the four waves: waves 0 and 1 each compute one half of
 // the buckets.  Ends with a workgroup barrier.
+template <int LBP>
 __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const short* kb, float scale, int wave, int lane, bool ctx) {
     if (!ctx) return;                                  // bias mode: both tile buffers were filled once, nothing changes per tile
     if (wave < 2) {
@@ -355,14 +353,16 @@ __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const shor
                           acc);
         short* row = dst + c32 * LBP + 32 * wave;                     // lane = key, rows = buckets
 #pragma unroll
-        for (int r = 0; r < 16; ++r) row[acc_row(r, g)] = f2bf(acc[r] * scale);   // (k * scale) Wq (:82)
+        for (int r = 0; r < 16; ++r)
+            if (LBP >= 64 || 32 * wave + acc_row(r, g) < LBP) row[acc_row(r, g)] = f2bf(acc[r] * scale);   // (k * scale) Wq (:82)
     }
     __syncthreads();
 }
 
-template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
-__global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
-    using L = LdsF<HQ, HK, HV>;
+template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
+    using L = LdsF<HQ, HK, HV, SM>;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -395,35 +395,31 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
     load_frags(qs, qp + (int64_t)min(qi, a.L - 1) * a.sn, g);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qs[ks] = scaled(qs[ks], a.scale);          // q * scale in q's dtype (:73)
-    u32x4v sk, sv4 = {}, sik = {}, siv = {}, siq = {};
+    u32x4v sk, sv4 = {}, sik = {}, siv = {}, siq = {};       // s*: the NEXT tile (in flight), c*: the current tile's ids
+    u32x4v cik = {}, civ = {}, ciq = {};
     sk = rows_load(kp, a.sn, 0, a.L, false);
     sv4 = rows_load(vp, a.sn, 0, a.L, true);
-    if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, 0);
-    if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, 0);
-    if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, 0);
+    if constexpr (HK) cik = ids_load(a.idk, a.NP, qi, 0, g);
+    if constexpr (HQ) ciq = ids_load(a.idq, a.NP, qi, 0, g);
+    if constexpr (HV) civ = ids_load(a.idv, a.NP, qi, 0, g);
     if constexpr (HK) { if (a.wk) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }
     if constexpr (HQ) {
         if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
-        else if (wave < 2) bias_rows_to_lds(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);   // both tile buffers
+        else if (wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);   // both tile buffers
     }
-    if constexpr (HV) {
-        stage_table_T(wvT, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);            // Wv (nb x 64): dst[d][u]
-        for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f;
+    if constexpr (HV) { for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f; }
+    if constexpr (HK) {
+        __syncthreads();                               // the rpe_k table lies over the tile area: use it before the first tiles land
+        if (active) {
+            if (a.wk) lookups_to_lds<LBP>(lkw, wkT, qs, 1.f, lane);
+            else bias_rows_to_lds<LBP>(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
+        }
+        __syncthreads();
     }
     rows_store(kbuf, sk);
     rows_store(vbuf, sv4);
-    if constexpr (HK) ids_store(smem + L::idk, sik);
-    if constexpr (HQ) ids_store(smem + L::idq, siq);
-    if constexpr (HV) ids_store(smem + L::idv, siv);
     __syncthreads();
-    if constexpr (HK) {
-        if (active) {
-            if (a.wk) lookups_to_lds(lkw, wkT, qs, 1.f, lane);
-            else bias_rows_to_lds(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
-        }
-        wave_lds_fence();
-    }
-    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
+    if constexpr (HQ) lq_tile<LBP>(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     f32x16 o[2] = {f32x16{}, f32x16{}};
     float l4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -442,13 +438,12 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
             if (more) {
                 sk = rows_load(kp, a.sn, (t + 1) * 32, a.L, false);
                 sv4 = rows_load(vp, a.sn, (t + 1) * 32, a.L, true);
-                if constexpr (HK) sik = ids_load(a.idk, a.NP, q0, t + 1);
-                if constexpr (HQ) siq = ids_load(a.idq, a.NP, q0, t + 1);
-                if constexpr (HV) siv = ids_load(a.idv, a.NP, q0, t + 1);
+                if constexpr (HK) sik = ids_load(a.idk, a.NP, qi, t + 1, g);
+                if constexpr (HQ) siq = ids_load(a.idq, a.NP, qi, t + 1, g);
+                if constexpr (HV) siv = ids_load(a.idv, a.NP, qi, t + 1, g);
             }
             if (active) {
-                f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
-                                              smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+                f32x16 s = score_tile<HK, HQ, LBP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LBP, lane);
                 if (t == NT - 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -475,7 +470,8 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                     if constexpr (HV) {
                         float* row = svw + c32 * LKP + 32 * g;       // this lane's half of the row's 64 bucket sums
 #pragma unroll
-                        for (int i = 0; i < 32; ++i) row[i] *= alpha;        // (row pitch 65 floats: scalar accesses, conflict-free)
+                        for (int i = 0; i < 32; ++i)
+                            if (LKP >= 64 || 32 * g + i < LKP) row[i] *= alpha;   // (odd row pitch: scalar accesses, conflict-free)
                         wave_lds_fence();
                     }
                 }
@@ -501,23 +497,24 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                     o[0] = TT::mma(load_perm_tr(vb, 0, s2, lane), pb, o[0]);
                     o[1] = TT::mma(load_perm_tr(vb, 1, s2, lane), pb, o[1]);
                 }
-                if constexpr (HV) {
-                    uint32_t w[4];
-                    lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
-                    scatter_add16(svw + c32 * LKP, w, s, g);
-                }
+                if constexpr (HV) scatter_add16(svw + c32 * LKP, civ, s, g);
             }
             if (more) {
                 rows_store(kbuf + nxt * 32 * KP, sk);
                 rows_store(vbuf + nxt * 32 * KP, sv4);
-                if constexpr (HK) ids_store(smem + L::idk + nxt * 128 * IDP, sik);
-                if constexpr (HQ) ids_store(smem + L::idq + nxt * 128 * IDP, siq);
-                if constexpr (HV) ids_store(smem + L::idv + nxt * 128 * IDP, siv);
+                if constexpr (HK) cik = sik;
+                if constexpr (HQ) ciq = siq;
+                if constexpr (HV) civ = siv;
                 __syncthreads();
-                if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
+                if constexpr (HQ) lq_tile<LBP>(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
             }
         }
         l4[0] = lrun;                                  // (this lane's half; the halves are added below)
+    }
+    if constexpr (HV) {
+        __syncthreads();                               // every wave is done with the tile area: the value table goes over it
+        stage_table_T(wvT, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);            // Wv (nb x 64): dst[d][u]
+        __syncthreads();
     }
     if (!active) return;
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
@@ -529,12 +526,11 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; }
     if constexpr (HV) {
-        wave_lds_fence();
         const float* row = svw + c32 * LKP;
         short* svg = a.sv + ((int64_t)bh * a.NP + qi) * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const F sb = srow_frag(row, ks, g, inv_l);
+            const F sb = srow_frag<LKP>(row, ks, g, inv_l);
             *reinterpret_cast<F*>(svg + ks * 16 + g * 8) = sb;
             o[0] = TT::mma(TT::load(wvT + c32 * KP + ks * 16 + g * 8), sb, o[0]);
             o[1] = TT::mma(TT::load(wvT + (c32 + 32) * KP + ks * 16 + g * 8), sb, o[1]);
@@ -546,14 +542,12 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
 // ---------------------------------------------------------------------------------------------------
 // backward A: lanes own queries — delta, dq, dLK; LK / G rows for launch B
 // ---------------------------------------------------------------------------------------------------
-template <bool HQ, bool HK, bool HV> struct LdsA {
+template <bool HQ, bool HK, bool HV, bool SM> struct LdsA {
+    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     static constexpr int kbuf = 0;                                   // 2 x [32][KP]   K rows
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP]   V rows
     static constexpr int stage_end = vbuf + 2 * 32 * KP * 2;         // (two tables are staged over this area outside the loop)
-    static constexpr int idk = stage_end;
-    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
-    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
-    static constexpr int wqT = idq + (HQ ? 2 * 128 * IDP : 0);
+    static constexpr int wqT = stage_end;
     static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
     static constexpr int gl = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LBP] bf16
     static constexpr int dlk = gl + (HV ? QW * 32 * LBP * 2 : 0);    // QW x [32][LKP] fp32
@@ -561,9 +555,10 @@ template <bool HQ, bool HK, bool HV> struct LdsA {
     static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
 };
 
-template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
-__global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
-    using L = LdsA<HQ, HK, HV>;
+template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
+    using L = LdsA<HQ, HK, HV, SM>;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -623,46 +618,48 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     if constexpr (HV) stage_table_R(tab1, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);       // [bucket][d]
     if constexpr (HQ) {
         if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
-        else if (wave < 2) bias_rows_to_lds(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+        else if (wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
     }
     if constexpr (HK) { for (int i = lane; i < 32 * LKP; i += 64) dlkw[i] = 0.f; }
     __syncthreads();
     if (active) {
         if constexpr (HK) {
-            if (a.wk) lookups_to_lds(lkw, tab0, qs, 1.f, lane);
-            else bias_rows_to_lds(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
+            if (a.wk) lookups_to_lds<LBP>(lkw, tab0, qs, 1.f, lane);
+            else bias_rows_to_lds<LBP>(lkw, a.bk + (int64_t)h * a.bk_hs, a.nb, lane);
             wave_lds_fence();
             lrow_to_global(a.lkg + ((int64_t)bh * a.NP + qi) * 64, lkw + c32 * LBP, g);
         }
         if constexpr (HV) {
-            lookups_to_lds(glw, tab1, dob, 1.f, lane);
+            lookups_to_lds<LBP>(glw, tab1, dob, 1.f, lane);
             wave_lds_fence();
             lrow_to_global(a.gg + ((int64_t)bh * a.NP + qi) * 64, glw + c32 * LBP, g);
         }
     }
     __syncthreads();                                   // tables consumed: the tile area is free
+    static_assert(PF == 1, "the ids of the tile being processed live in one register set (cik / ciq / civ)");
     struct Stage { u32x4v k, v, ik, iv, iq; } st[PF];
+    u32x4v cik = {}, ciq = {}, civ = {};               // the current tile's ids of this lane (ids_load)
     auto issue = [&](Stage& r, int t) {
         r.k = rows_load(kp, a.sn, t * 32, a.L, false);
         r.v = rows_load(vp, a.sn, t * 32, a.L, true);
-        if constexpr (HK) r.ik = ids_load(a.idk, a.NP, q0, t);
-        if constexpr (HQ) r.iq = ids_load(a.idq, a.NP, q0, t);
-        if constexpr (HV) r.iv = ids_load(a.idv, a.NP, q0, t);
+        if constexpr (HK) r.ik = ids_load(a.idk, a.NP, qi, t, g);
+        if constexpr (HQ) r.iq = ids_load(a.idq, a.NP, qi, t, g);
+        if constexpr (HV) r.iv = ids_load(a.idv, a.NP, qi, t, g);
     };
     auto commit = [&](const Stage& r, int t) {
         const int buf = t & 1;
         rows_store(kbuf + buf * 32 * KP, r.k);
         rows_store(vbuf + buf * 32 * KP, r.v);
-        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
-        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, r.iq);
-        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, r.iv);
+        if constexpr (HK) cik = r.ik;
+        if constexpr (HQ) ciq = r.iq;
+        if constexpr (HV) civ = r.iv;
     };
 #pragma unroll
     for (int t = 0; t < PF; ++t)
         if (t < NT) issue(st[t], t);
     commit(st[0], 0);
     __syncthreads();
-    if constexpr (HQ) lq_tile(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
+    if constexpr (HQ) lq_tile<LBP>(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     // ---- key tiles ----------------------------------------------------------------------------------
     f32x16 dq[2] = {f32x16{}, f32x16{}};
@@ -671,18 +668,15 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         const int cur = t & 1, nxt = cur ^ 1;
         if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
-            f32x16 s = score_tile<HK, HQ>(kbuf + cur * 32 * KP, qs, smem + L::idk + cur * 128 * IDP,
-                                          smem + L::idq + cur * 128 * IDP, lkw + c32 * LBP, lqs + cur * 32 * LBP, qrow, lane);
+            f32x16 s = score_tile<HK, HQ, LBP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LBP, lane);
             f32x16 dp = {};
             const short* vb = vbuf + cur * 32 * KP;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = TT::mma(TT::load(vb + c32 * KP + ks * 16 + g * 8), dob[ks], dp);
             if constexpr (HV) {
-                uint32_t w[4];
-                lane_ids(w, smem + L::idv + cur * 128 * IDP, qrow, g);
                 const short* row = glw + c32 * LBP;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], row, off2_of(w, r));
+                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], row, off2_of(civ, r));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -693,11 +687,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
                 if constexpr (DROP) dpr = drop_keep(drop_key(a.drop_seed, bh), qi, key, a.drop_thr) ? dpr * a.drop_scale : 0.f;
                 s[r] = p * (dpr - delta);
             }
-            if constexpr (HK) {
-                uint32_t w[4];
-                lane_ids(w, smem + L::idk + cur * 128 * IDP, qrow, g);
-                scatter_add16(dlkw + c32 * LKP, w, s, g);
-            }
+            if constexpr (HK) scatter_add16(dlkw + c32 * LKP, cik, s, g);
             const short* kb = kbuf + cur * 32 * KP;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -709,7 +699,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         if (t + 1 < NT) {
             commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
-            if constexpr (HQ) lq_tile(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
+            if constexpr (HQ) lq_tile<LBP>(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
         }
     });
 
@@ -726,7 +716,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
             short* dst = a.dlk + ((int64_t)bh * a.NP + qi) * 64;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const F db = srow_frag(row, ks, g, 1.f);
+                const F db = srow_frag<LKP>(row, ks, g, 1.f);
                 *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = db;
                 if (ctx) {
                     dq[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dq[0]);
@@ -741,14 +731,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
 // ---------------------------------------------------------------------------------------------------
 // backward B: lanes own keys — dk, dv, dLQ
 // ---------------------------------------------------------------------------------------------------
-template <bool HQ, bool HK, bool HV> struct LdsB {
+template <bool HQ, bool HK, bool HV, bool SM> struct LdsB {
+    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     static constexpr int qbuf = 0;                                   // 2 x [32][KP]   (s q) rows
     static constexpr int dobuf = qbuf + 2 * 32 * KP * 2;             // 2 x [32][KP]   dO rows
     static constexpr int stage_end = dobuf + 2 * 32 * KP * 2;
-    static constexpr int idk = stage_end;                            // key-major id tiles
-    static constexpr int idv = idk + (HK ? 2 * 128 * IDP : 0);
-    static constexpr int idq = idv + (HV ? 2 * 128 * IDP : 0);
-    static constexpr int lkt = idq + (HQ ? 2 * 128 * IDP : 0);       // 2 x [32 queries][LBP]  rpe_k lookups of the query tile
+    static constexpr int lkt = stage_end;                            // 2 x [32 queries][LBP]  rpe_k lookups of the query tile
     static constexpr int gt = lkt + (HK ? 2 * 32 * LBP * 2 : 0);     // 2 x [32 queries][LBP]  value-side lookups of dO
     static constexpr int lqk = gt + (HV ? 2 * 32 * LBP * 2 : 0);     // QW x [32 keys][LBP]    rpe_q lookups (own keys)
     static constexpr int dlq = lqk + (HQ ? QW * 32 * LBP * 2 : 0);   // QW x [32 keys][LKP] fp32
@@ -756,9 +744,10 @@ template <bool HQ, bool HK, bool HV> struct LdsB {
     static constexpr int fixed = stats;
 };
 
-template <bool HQ, bool HK, bool HV, bool DROP = false>      // DROP: attention dropout (its own instantiations: the
-__global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs)
-    using L = LdsB<HQ, HK, HV>;
+template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
+__global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
+    using L = LdsB<HQ, HK, HV, SM>;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, KB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -807,33 +796,34 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {  
                 F ksf[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) ksf[ks] = scaled(kf[ks], a.scale);
-                lookups_to_lds(lqw, tab0, ksf, 1.f, lane);               // (k * scale) Wq (:82)
+                lookups_to_lds<LBP>(lqw, tab0, ksf, 1.f, lane);               // (k * scale) Wq (:82)
             } else {
-                bias_rows_to_lds(lqw, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+                bias_rows_to_lds<LBP>(lqw, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
             }
             wave_lds_fence();
         }
     }
     __syncthreads();
     struct Stage { u32x4v q, dout, lk, gl, ik, iv, iq; } st[PF];
+    u32x4v cik = {}, ciq = {}, civ = {};               // the current tile's (key-major) ids of this lane
     auto issue = [&](Stage& r, int t) {
         r.q = scaled_raw(rows_load(qp, a.sn, t * 32, a.L, false), a.scale);
         r.dout = rows_load(dop, orow, t * 32, a.L, true);
         if constexpr (HK) r.lk = rows_load(lkg, 64, t * 32, a.NP, false);
         if constexpr (HV) r.gl = rows_load(gg, 64, t * 32, a.NP, false);
-        if constexpr (HK) r.ik = ids_load(a.idk_t, a.NP, k0, t);
-        if constexpr (HQ) r.iq = ids_load(a.idq_t, a.NP, k0, t);
-        if constexpr (HV) r.iv = ids_load(a.idv_t, a.NP, k0, t);
+        if constexpr (HK) r.ik = ids_load(a.idk_t, a.NP, kj, t, g);
+        if constexpr (HQ) r.iq = ids_load(a.idq_t, a.NP, kj, t, g);
+        if constexpr (HV) r.iv = ids_load(a.idv_t, a.NP, kj, t, g);
     };
     auto commit = [&](const Stage& r, int t) {
         const int buf = t & 1;
         rows_store(qbuf + buf * 32 * KP, r.q);
         rows_store(dobuf + buf * 32 * KP, r.dout);
-        if constexpr (HK) lrows_store(lkt + buf * 32 * LBP, r.lk);
-        if constexpr (HV) lrows_store(gt + buf * 32 * LBP, r.gl);
-        if constexpr (HK) ids_store(smem + L::idk + buf * 128 * IDP, r.ik);
-        if constexpr (HQ) ids_store(smem + L::idq + buf * 128 * IDP, r.iq);
-        if constexpr (HV) ids_store(smem + L::idv + buf * 128 * IDP, r.iv);
+        if constexpr (HK) lrows_store<LBP>(lkt + buf * 32 * LBP, r.lk);
+        if constexpr (HV) lrows_store<LBP>(gt + buf * 32 * LBP, r.gl);
+        if constexpr (HK) cik = r.ik;
+        if constexpr (HQ) ciq = r.iq;
+        if constexpr (HV) civ = r.iv;
     };
 #pragma unroll
     for (int t = 0; t < PF; ++t)
@@ -849,18 +839,15 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {  
         if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
             // rows = queries of the tile, column = own key: own lookups = rpe_q, side lookups = rpe_k
-            f32x16 s = score_tile<HQ, HK>(qbuf + cur * 32 * KP, kf, smem + L::idq + cur * 128 * IDP,
-                                          smem + L::idk + cur * 128 * IDP, lqw + c32 * LBP, lkt + cur * 32 * LBP, krow, lane);
+            f32x16 s = score_tile<HQ, HK, LBP>(qbuf + cur * 32 * KP, kf, ciq, cik, lqw + c32 * LBP, lkt + cur * 32 * LBP, lane);
             f32x16 dp = {};
             const short* db = dobuf + cur * 32 * KP;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = TT::mma(TT::load(db + c32 * KP + ks * 16 + g * 8), vf[ks], dp);
             if constexpr (HV) {
-                uint32_t w[4];
-                lane_ids(w, smem + L::idv + cur * 128 * IDP, krow, g);
                 const short* side = gt + cur * 32 * LBP;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], side + acc_row(r, g) * LBP, off2_of(w, r));
+                for (int r = 0; r < 16; ++r) dp[r] = add_bf16_at(dp[r], side + acc_row(r, g) * LBP, off2_of(civ, r));
             }
             f32x16 ds;
 #pragma unroll
@@ -882,11 +869,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {  
                     ds[r] = p * (dpr - dl[e]);
                 }
             }
-            if constexpr (HQ) {
-                uint32_t w[4];
-                lane_ids(w, smem + L::idq + cur * 128 * IDP, krow, g);
-                scatter_add16(dlqw + c32 * LKP, w, ds, g);
-            }
+            if constexpr (HQ) scatter_add16(dlqw + c32 * LKP, ciq, ds, g);
             const short* qb = qbuf + cur * 32 * KP;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -917,9 +900,9 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {  
             short* dst = a.dlq + ((int64_t)bh * a.NP + kj) * 64;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = srow_frag(row, ks, g, 1.f);
+                *reinterpret_cast<F*>(dst + ks * 16 + g * 8) = srow_frag<LKP>(row, ks, g, 1.f);
                 if (ctx) {
-                    const F db = srow_frag(row, ks, g, a.scale);
+                    const F db = srow_frag<LKP>(row, ks, g, a.scale);
                     dk[0] = TT::mma(TT::load(tab0 + c32 * KP + ks * 16 + g * 8), db, dk[0]);
                     dk[1] = TT::mma(TT::load(tab0 + (c32 + 32) * KP + ks * 16 + g * 8), db, dk[1]);
                 }
@@ -980,14 +963,16 @@ __global__ __launch_bounds__(256) void irpe_table_grad_kernel(const TgArgs a) {
     for (int r = 0; r < 16; ++r) o[(ta * 32 + acc_row(r, g)) * 64 + tc * 32 + c32] = acc[r] * a.mul;
 }
 
-// int32 (Lq x Lk) bucket ids -> zero-padded uint8 (NP x NP) holding 2 * id, optionally transposed
+// int32 (Lq x Lk) bucket ids -> zero-padded uint8 (NP x NP) holding 2 * id, optionally transposed; every 32-byte group of a row
+// (one streamed tile) in the order the lanes of the kernels take it (ids_load): byte 16 g + r = partner acc_row(r, g) of the tile
 __global__ void bucket_bytes_kernel(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose) {
-    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= NP) return;
+    const int i = blockIdx.y, pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= NP) return;
+    const int j = (pos & ~31) + acc_row(pos & 15, (pos >> 4) & 1);
     int v = 0;
     if (!transpose) { if (i < Lq && j < Lk) v = ids[(int64_t)i * Lk + j]; }
     else            { if (j < Lq && i < Lk) v = ids[(int64_t)j * Lk + i]; }
-    dst[(int64_t)i * NP + j] = (uint8_t)(2 * v);      // byte offset of the bucket in a bf16 lookup row
+    dst[(int64_t)i * NP + pos] = (uint8_t)(2 * v);    // byte offset of the bucket in a bf16 lookup row
 }
 
 template <typename K>
@@ -1000,20 +985,24 @@ int launch(K kern, const Args& a, size_t lds, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
+template <bool HQ, bool HK, bool HV, bool DROP, bool SM> int launch_fwd2(const Args& a, hipStream_t st) {
+    return launch(irpe_attn_fwd_kernel<HQ, HK, HV, DROP, SM>, a, LdsF<HQ, HK, HV, SM>::total, st);
+}
+template <bool HQ, bool HK, bool HV, bool DROP, bool SM> int launch_bwd2(const Args& a, hipStream_t st) {
+    const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV, DROP, SM>, a, LdsA<HQ, HK, HV, SM>::total, st);
+    if (rc) return rc;
+    return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV, DROP, SM>, a, LdsB<HQ, HK, HV, SM>::fixed + (size_t)a.NP * 8, st);
+}
+// the narrow row pitches only where a table is present (without one there are no per-token rows)
 template <bool HQ, bool HK, bool HV> int launch_fwd(const Args& a, hipStream_t st) {
-    if (a.drop_thr) return launch(irpe_attn_fwd_kernel<HQ, HK, HV, true>, a, LdsF<HQ, HK, HV>::total, st);
-    return launch(irpe_attn_fwd_kernel<HQ, HK, HV>, a, LdsF<HQ, HK, HV>::total, st);
+    constexpr bool ANY = HQ || HK || HV;
+    if (ANY && a.nb <= SM_MAX_NB) return a.drop_thr ? launch_fwd2<HQ, HK, HV, true, ANY>(a, st) : launch_fwd2<HQ, HK, HV, false, ANY>(a, st);
+    return a.drop_thr ? launch_fwd2<HQ, HK, HV, true, false>(a, st) : launch_fwd2<HQ, HK, HV, false, false>(a, st);
 }
 template <bool HQ, bool HK, bool HV> int launch_bwd(const Args& a, hipStream_t st) {
-    const size_t ldsb = LdsB<HQ, HK, HV>::fixed + (size_t)a.NP * 8;
-    if (a.drop_thr) {
-        const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV, true>, a, LdsA<HQ, HK, HV>::total, st);
-        if (rc) return rc;
-        return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV, true>, a, ldsb, st);
-    }
-    const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV>, a, LdsA<HQ, HK, HV>::total, st);
-    if (rc) return rc;
-    return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV>, a, ldsb, st);
+    constexpr bool ANY = HQ || HK || HV;
+    if (ANY && a.nb <= SM_MAX_NB) return a.drop_thr ? launch_bwd2<HQ, HK, HV, true, ANY>(a, st) : launch_bwd2<HQ, HK, HV, false, ANY>(a, st);
+    return a.drop_thr ? launch_bwd2<HQ, HK, HV, true, false>(a, st) : launch_bwd2<HQ, HK, HV, false, false>(a, st);
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

@@ -68,7 +68,10 @@ CASES = [("k", True, 50, "product"), ("k", False, 197, "product"), ("q", True, 5
          ("k", True, 577, "product"), ("qkv", True, 577, "product"), ("", True, 50, "product"),
          ("qkv", True, 197, "euc"), ("qkv", False, 197, "quant"), ("k", True, 196, "euc"),      # 196: skip = 0 (no class token)
          ("k", True, 197, "product", "bias"), ("qk", False, 197, "product", "bias"), ("q", False, 50, "quant", "bias"),
-         ("qkv", False, 577, "product", "bias")]                                                # bias q / k + contextual v
+         ("qkv", False, 577, "product", "bias"),                                                # bias q / k + contextual v
+         # more than 51 buckets: the kernels' wide row pitches (csrc/irpe_attn.hip `Pitch`; everything above takes the narrow ones)
+         ("qkv", True, 197, "euc", "ctx", 15.5), ("kv", False, 577, "quant", "ctx", 14.0), ("qk", False, 197, "euc", "bias", 13.0),
+         ("qkv", True, 196, "euc", "ctx", 12.8)]                                                # 51 buckets: the narrow pitches' limit
 
 
 def _table(m):
@@ -84,7 +87,7 @@ def test_fused_irpe_attention_matches_restatement(case):
     torch.manual_seed(11)
     mods = [None, None, None]
     if rpe_on:
-        kw = dict(ratio=1.9, method=method, shared_head=shared, skip=0 if L == 196 else 1)
+        kw = dict(ratio=case[5] if len(case) > 5 else 1.9, method=method, shared_head=shared, skip=0 if L == 196 else 1)
         cfg = I.get_rpe_config(mode=mode, rpe_on=rpe_on.replace("v", "") if mode == "bias" else rpe_on, **kw)
         if mode == "bias" and "v" in rpe_on:          # bias mode does not exist on the value side (irpe.py:468-470)
             cfg.rpe_v = I.get_rpe_config(mode="ctx", rpe_on="v", **kw).rpe_v
