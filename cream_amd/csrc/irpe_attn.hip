@@ -547,8 +547,7 @@ template <bool HQ, bool HK, bool HV, bool SM> struct LdsA {
     static constexpr int kbuf = 0;                                   // 2 x [32][KP]   K rows
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP]   V rows
     static constexpr int stage_end = vbuf + 2 * 32 * KP * 2;         // (two tables are staged over this area outside the loop)
-    static constexpr int wqT = stage_end;
-    static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
+    static constexpr int lk = stage_end;                             // QW x [32][LBP] bf16
     static constexpr int gl = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LBP] bf16
     static constexpr int dlk = gl + (HV ? QW * 32 * LBP * 2 : 0);    // QW x [32][LKP] fp32
     static constexpr int lq = dlk + (HK ? QW * 32 * LKP * 4 : 0);    // 2 x [32][LBP] bf16
@@ -584,7 +583,6 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     short* vbuf = reinterpret_cast<short*>(smem + L::vbuf);
     short* tab0 = reinterpret_cast<short*>(smem);                    // tables staged over the tile area
     short* tab1 = tab0 + 64 * KP;
-    short* wqT = reinterpret_cast<short*>(smem + L::wqT);
     short* lkw = reinterpret_cast<short*>(smem + L::lk) + wave * 32 * LBP;
     short* glw = reinterpret_cast<short*>(smem + L::gl) + wave * 32 * LBP;
     float* dlkw = reinterpret_cast<float*>(smem + L::dlk) + wave * 32 * LKP;
@@ -616,9 +614,14 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
 
     if constexpr (HK) { if (a.wk) stage_table_T(tab0, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }      // [bucket][d]
     if constexpr (HV) stage_table_R(tab1, a.wv + (int64_t)h * a.wv_hs, a.nb, 64);       // [bucket][d]
+    // rpe_q lookups of the streamed keys: contextual — rows of (k * scale) Wq written by lq_rows_kernel (launched in front of
+    // this kernel) into the dlq buffer, which launch B overwrites with the bucket gradients only at its end; staged per key tile
+    // like K and V (rounds 2-5 recomputed them per tile from a resident Wq^T: 9 KB of LDS, two MFMA chains and a second
+    // workgroup barrier per tile).  Bias mode: the head's table in both tile buffers, once.
+    const short* lqg = HQ ? a.dlq + (int64_t)bh * a.NP * 64 : nullptr;
+    const bool lq_rows = HQ && a.wq != nullptr;
     if constexpr (HQ) {
-        if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
-        else if (wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+        if (!a.wq && wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
     }
     if constexpr (HK) { for (int i = lane; i < 32 * LKP; i += 64) dlkw[i] = 0.f; }
     __syncthreads();
@@ -637,11 +640,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     }
     __syncthreads();                                   // tables consumed: the tile area is free
     static_assert(PF == 1, "the ids of the tile being processed live in one register set (cik / ciq / civ)");
-    struct Stage { u32x4v k, v, ik, iv, iq; } st[PF];
+    struct Stage { u32x4v k, v, lq, ik, iv, iq; } st[PF];
     u32x4v cik = {}, ciq = {}, civ = {};               // the current tile's ids of this lane (ids_load)
     auto issue = [&](Stage& r, int t) {
         r.k = rows_load(kp, a.sn, t * 32, a.L, false);
         r.v = rows_load(vp, a.sn, t * 32, a.L, true);
+        if constexpr (HQ) { if (lq_rows) r.lq = rows_load(lqg, 64, t * 32, a.NP, false); }
         if constexpr (HK) r.ik = ids_load(a.idk, a.NP, qi, t, g);
         if constexpr (HQ) r.iq = ids_load(a.idq, a.NP, qi, t, g);
         if constexpr (HV) r.iv = ids_load(a.idv, a.NP, qi, t, g);
@@ -650,6 +654,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         const int buf = t & 1;
         rows_store(kbuf + buf * 32 * KP, r.k);
         rows_store(vbuf + buf * 32 * KP, r.v);
+        if constexpr (HQ) { if (lq_rows) lrows_store<LBP>(lqs + buf * 32 * LBP, r.lq); }
         if constexpr (HK) cik = r.ik;
         if constexpr (HQ) ciq = r.iq;
         if constexpr (HV) civ = r.iv;
@@ -659,13 +664,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         if (t < NT) issue(st[t], t);
     commit(st[0], 0);
     __syncthreads();
-    if constexpr (HQ) lq_tile<LBP>(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     // ---- key tiles ----------------------------------------------------------------------------------
     f32x16 dq[2] = {f32x16{}, f32x16{}};
     stream(NT, [&](int t, auto slot) {
         constexpr int K = decltype(slot)::value;
-        const int cur = t & 1, nxt = cur ^ 1;
+        const int cur = t & 1;
         if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
             f32x16 s = score_tile<HK, HQ, LBP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LBP, lane);
@@ -699,7 +703,6 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         if (t + 1 < NT) {
             commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
-            if constexpr (HQ) lq_tile<LBP>(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
         }
     });
 
@@ -726,6 +729,28 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         }
     }
     if (qok) store_row64(a.dq + (int64_t)b * a.dsb + (int64_t)qi * a.dsn + (int64_t)h * a.dsh, dq, g, a.scale);
+}
+
+// rpe_q lookup rows of every key, (k * scale) Wq as bf16 (the values lq_tile puts in LDS in the forward: product first, scale
+// after, :82) -> dst (B, H, NP, 64).  Launched in front of backward A with dst = the dlq buffer.
+__global__ __launch_bounds__(256) void irpe_lq_rows_kernel(const Args a, short* dst) {
+    __shared__ __attribute__((aligned(16))) short tab[64 * KP];
+    __shared__ __attribute__((aligned(16))) short scr[QW * 32 * 66];
+    const int NT = a.NP >> 5, KB = (NT + QW - 1) / QW;
+    const int bh = blockIdx.x / KB, kblk = blockIdx.x - bh * KB;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 5, c32 = lane & 31;
+    const int kj = kblk * 32 * QW + wave * 32 + c32;
+    stage_table_T(tab, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);      // [bucket][d]
+    __syncthreads();
+    if (kblk * QW + wave >= NT) return;
+    F kf[4];
+    load_frags(kf, a.k + (int64_t)b * a.sb + (int64_t)h * a.sh + (int64_t)min(kj, a.L - 1) * a.sn, g);
+    short* rows = scr + wave * 32 * 66;
+    lookups_to_lds<66>(rows, tab, kf, a.scale, lane);
+    wave_lds_fence();
+    lrow_to_global(dst + ((int64_t)bh * a.NP + kj) * 64, rows + c32 * 66, g);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -989,6 +1014,11 @@ template <bool HQ, bool HK, bool HV, bool DROP, bool SM> int launch_fwd2(const A
     return launch(irpe_attn_fwd_kernel<HQ, HK, HV, DROP, SM>, a, LdsF<HQ, HK, HV, SM>::total, st);
 }
 template <bool HQ, bool HK, bool HV, bool DROP, bool SM> int launch_bwd2(const Args& a, hipStream_t st) {
+    if (HQ && a.wq) {                                  // rpe_q lookup rows of the keys for launch A, in the buffer launch B fills last
+        const int NT = a.NP >> 5, KB = (NT + QW - 1) / QW;
+        hipLaunchKernelGGL(irpe_lq_rows_kernel, dim3(a.B * a.H * KB), dim3(256), 0, st, a, a.dlq);
+        if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    }
     const int rc = launch(irpe_attn_bwd_q_kernel<HQ, HK, HV, DROP, SM>, a, LdsA<HQ, HK, HV, SM>::total, st);
     if (rc) return rc;
     return launch(irpe_attn_bwd_kv_kernel<HQ, HK, HV, DROP, SM>, a, LdsB<HQ, HK, HV, SM>::fixed + (size_t)a.NP * 8, st);
