@@ -63,6 +63,11 @@ constexpr int VTP = 36;     // pitch (bf16) of transposed [64][32] tiles read wi
 template <bool SM> struct Pitch {
     static constexpr int LK = SM ? 51 : 65;     // fp32 scatter-add rows
     static constexpr int LB = SM ? 54 : 66;     // bf16 lookup rows: 27 / 33 words
+#ifdef IRPE_LQ_NARROW
+    static constexpr int LQ = LB;
+#else
+    static constexpr int LQ = 66;               // rpe_q lookup rows of the streamed key tile (forward, dQ launch): the narrow pitch costs the
+#endif                                          // side gathers 8 % (forward q 224 vs 207 us, q + k + v 620 vs 567) and 1.5 KB fits
 };
 constexpr int SM_MAX_NB = 51;
 constexpr int QW = 4;       // waves (32-token tiles) per workgroup
@@ -191,28 +196,33 @@ __device__ __forceinline__ float add_bf16_at(float acc, const short* row, int of
 // the second half adds onto the first half's sums — and each half goes 8 pairs at a time: 8 reads,
 // duplicates inside the group resolved in registers (the latest earlier match carries the running sum,
 // and the last write to an address is the complete one), 8 writes.
+#ifndef IRPE_SCATTER_GROUP
+#define IRPE_SCATTER_GROUP 4      // pairs per read-modify-write group.  Same-call A/B at config 4 (tools/probe_irpe_variants.sh, two workgroups per
+#endif                            // CU): 16 / 8 / 4 / 2 -> forward v 413 / 313 / 274 / 274 us, backward k 1,042 / 930 / 870 / 870: with a second wave on
+                                  // the SIMD the extra LDS round trips are hidden and the compare / select pairs (G (G - 1) / 2 per group) are not
 __device__ __forceinline__ void scatter_add16(float* row, const u32x4v& w, const f32x16& val, int g) {
+    constexpr int G = IRPE_SCATTER_GROUP;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (g == half) {
 #pragma unroll
-            for (int grp = 0; grp < 2; ++grp) {
-                int id[8];
-                float sum[8];
+            for (int grp = 0; grp < 16 / G; ++grp) {
+                int id[G];
+                float sum[G];
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    id[v] = off2_of(w, grp * 8 + v);
+                for (int v = 0; v < G; ++v) {
+                    id[v] = off2_of(w, grp * G + v);
                     sum[v] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + 2 * id[v]);
                 }
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
+                for (int v = 0; v < G; ++v) {
                     float base = sum[v];
 #pragma unroll
                     for (int u = 0; u < v; ++u) base = (id[u] == id[v]) ? sum[u] : base;
-                    sum[v] = base + val[grp * 8 + v];
+                    sum[v] = base + val[grp * G + v];
                 }
 #pragma unroll
-                for (int v = 0; v < 8; ++v) *reinterpret_cast<float*>(reinterpret_cast<char*>(row) + 2 * id[v]) = sum[v];
+                for (int v = 0; v < G; ++v) *reinterpret_cast<float*>(reinterpret_cast<char*>(row) + 2 * id[v]) = sum[v];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -315,7 +325,7 @@ template <bool HQ, bool HK, bool HV, bool SM> struct LdsF {
     static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
     static constexpr int sv = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LKP] fp32
     static constexpr int lq = sv + (HV ? QW * 32 * LKP * 4 : 0);     // 2 x [32 keys][LBP] bf16
-    static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
+    static constexpr int total = lq + (HQ ? 2 * 32 * Pitch<SM>::LQ * 2 : 0);
 };
 
 // S^T tile (rows = streamed tokens, column = own token) with the relative position terms:
@@ -362,7 +372,7 @@ __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const shor
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
 __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsF<HQ, HK, HV, SM>;
-    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
     if constexpr (HK) { if (a.wk) stage_table_T(wkT, a.wk + (int64_t)h * a.wk_hs, 64, a.nb); }
     if constexpr (HQ) {
         if (a.wq) stage_table_T(wqT, a.wq + (int64_t)h * a.wq_hs, 64, a.nb);
-        else if (wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);   // both tile buffers
+        else if (wave < 2) bias_rows_to_lds<LQP>(lqs + wave * 32 * LQP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);   // both tile buffers
     }
     if constexpr (HV) { for (int i = lane; i < 32 * LKP; i += 64) svw[i] = 0.f; }
     if constexpr (HK) {
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
     rows_store(kbuf, sk);
     rows_store(vbuf, sv4);
     __syncthreads();
-    if constexpr (HQ) lq_tile<LBP>(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
+    if constexpr (HQ) lq_tile<LQP>(lqs, wqT, kbuf, a.scale, wave, lane, a.wq != nullptr);
 
     f32x16 o[2] = {f32x16{}, f32x16{}};
     float l4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                 if constexpr (HV) siv = ids_load(a.idv, a.NP, qi, t + 1, g);
             }
             if (active) {
-                f32x16 s = score_tile<HK, HQ, LBP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LBP, lane);
+                f32x16 s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
                 if (t == NT - 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                 if constexpr (HQ) ciq = siq;
                 if constexpr (HV) civ = siv;
                 __syncthreads();
-                if constexpr (HQ) lq_tile<LBP>(lqs + nxt * 32 * LBP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
+                if constexpr (HQ) lq_tile<LQP>(lqs + nxt * 32 * LQP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
             }
         }
         l4[0] = lrun;                                  // (this lane's half; the halves are added below)
@@ -551,13 +561,13 @@ template <bool HQ, bool HK, bool HV, bool SM> struct LdsA {
     static constexpr int gl = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LBP] bf16
     static constexpr int dlk = gl + (HV ? QW * 32 * LBP * 2 : 0);    // QW x [32][LKP] fp32
     static constexpr int lq = dlk + (HK ? QW * 32 * LKP * 4 : 0);    // 2 x [32][LBP] bf16
-    static constexpr int total = lq + (HQ ? 2 * 32 * LBP * 2 : 0);
+    static constexpr int total = lq + (HQ ? 2 * 32 * Pitch<SM>::LQ * 2 : 0);
 };
 
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
 __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsA<HQ, HK, HV, SM>;
-    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     const short* lqg = HQ ? a.dlq + (int64_t)bh * a.NP * 64 : nullptr;
     const bool lq_rows = HQ && a.wq != nullptr;
     if constexpr (HQ) {
-        if (!a.wq && wave < 2) bias_rows_to_lds<LBP>(lqs + wave * 32 * LBP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
+        if (!a.wq && wave < 2) bias_rows_to_lds<LQP>(lqs + wave * 32 * LQP, a.bq + (int64_t)h * a.bq_hs, a.nb, lane);
     }
     if constexpr (HK) { for (int i = lane; i < 32 * LKP; i += 64) dlkw[i] = 0.f; }
     __syncthreads();
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         const int buf = t & 1;
         rows_store(kbuf + buf * 32 * KP, r.k);
         rows_store(vbuf + buf * 32 * KP, r.v);
-        if constexpr (HQ) { if (lq_rows) lrows_store<LBP>(lqs + buf * 32 * LBP, r.lq); }
+        if constexpr (HQ) { if (lq_rows) lrows_store<LQP>(lqs + buf * 32 * LQP, r.lq); }
         if constexpr (HK) cik = r.ik;
         if constexpr (HQ) ciq = r.iq;
         if constexpr (HV) civ = r.iv;
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         const int cur = t & 1;
         if (t + PF < NT) issue(st[K], t + PF);
         if (active) {
-            f32x16 s = score_tile<HK, HQ, LBP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LBP, lane);
+            f32x16 s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
             f32x16 dp = {};
             const short* vb = vbuf + cur * 32 * KP;
 #pragma unroll

@@ -6,7 +6,8 @@ from cream_amd import timing, irpe as I, irpe_fused
 
 dev = "cuda:0"
 B, L, H = 64, 577, 12
-for rpe_on in ("", "k", "q", "v", "qk", "kv", "qkv"):
+for rpe_on in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("", "k", "q", "v", "qk", "kv", "qkv")):   # "none" = no rpe
+    rpe_on = "" if rpe_on == "none" else rpe_on
     torch.manual_seed(0)
     mods = [None, None, None]
     if rpe_on:
