@@ -242,7 +242,9 @@ typedef struct cream_irpe_attn_desc {
     int64_t dsb, dsn, dsh;
     float* delta;                   /* (B, H, NP) scratch                                               */
     void *lkg, *gg;                 /* (B, H, NP, 64) bf16 scratch (needed with wk / wv)                 */
-    void *dlk, *dlq;                /* (B, H, NP, 64) bf16 out: bucket gradients of rpe_k / rpe_q lookups */
+    void *dlk, *dlq;                /* (B, H, NP, 64) bf16 out: bucket gradients of rpe_k / rpe_q lookups
+                                       (dlq also serves as scratch inside the call: the rpe_q lookup rows of the
+                                       keys live there between the pre-pass and the end of the second launch) */
     /* bias mode of rpe_q / rpe_k (irpe.py:622-624: lookup_table_bias (H', nb), no dependence on q / k): give the
      * table here INSTEAD of wq / wk; its gradient is the sum of the dlq / dlk rows over batch and tokens (caller) */
     const float *bq, *bk;
@@ -261,14 +263,19 @@ typedef struct cream_irpe_attn_desc {
 int cream_irpe_padded_len(int L);
 
 /* int32 (Lq, Lk) bucket ids (irpe.py:523-583) -> zero-padded uint8 (NP, NP) holding 2 * id (the byte
- * offset of the bucket in a bf16 lookup row; ids < 64); transpose != 0 writes dst[j][i] = 2 * ids[i][j].  Done once per (table, device) by the caller. */
+ * offset of the bucket in a bf16 lookup row; ids < 64); transpose != 0 converts the transposed table (dst row j
+ * = column j of ids).  Done once per (table, device) by the caller.  The matrix is an OPAQUE operand of the two
+ * calls below: inside every 32-byte group of a row (one streamed tile of 32 partners) the bytes are in the order
+ * the lanes of the kernels read them (byte 16 g + r = partner (r & 3) + 8 (r >> 2) + 4 g of the tile), so that a
+ * lane's 16 ids of a tile are one 16-byte load. */
 int cream_irpe_bucket_bytes(uint8_t* dst, const int32_t* ids, int Lq, int Lk, int NP, int transpose, void* stream);
 
 /* out, lse (and sv) from q, k, v.  One launch. */
 int cream_irpe_attn_fwd(const cream_irpe_attn_desc* d, void* stream);
 
 /* dq, dk, dv and the bucket-gradient rows dlk, dlq from dout (+ out, lse of the forward).  Two launches
- * (queries own lanes; keys own lanes); no global atomics. */
+ * (queries own lanes; keys own lanes) behind a small pre-pass when wq is given ((k * scale) Wq rows of all keys);
+ * no global atomics. */
 int cream_irpe_attn_bwd(const cream_irpe_attn_desc* d, void* stream);
 
 /* Per-(b,h) table gradient  out[b*H+h][a][c] = mul * sum_n X[b,n,h][a] * Y[b,n,h][c]  (64 x 64 fp32):
