@@ -70,6 +70,18 @@ template <bool SM> struct Pitch {
 #endif                                          // side gathers 8 % (forward q 224 vs 207 us, q + k + v 620 vs 567) and 1.5 KB fits
 };
 constexpr int SM_MAX_NB = 51;
+// ONE V tile buffer instead of two in the forward and the dQ launch (4.6 KB less LDS, paid with a second workgroup barrier per tile)
+// exactly where it buys a third workgroup on the CU — the register budgets of these kernels allow three waves per SIMD, not four.
+// Same-call A/B at config 4 (tools/probe_irpe_variants.sh, IRPE_V_DOUBLE = never): forward k + v 431 -> 338 us, backward with rpe
+// on k 881 -> 750 (dQ launch 58.4 -> 53.8 KB); everywhere else the extra barrier costs 3-16 % and buys nothing.
+constexpr int wgs_per_cu(int lds_bytes) { return 160 * 1024 / lds_bytes; }
+template <template <bool, bool, bool, bool, int> class T, bool HQ, bool HK, bool HV, bool SM> constexpr int pick_vbufs() {
+#ifdef IRPE_V_DOUBLE
+    return 2;
+#else
+    return (wgs_per_cu(T<HQ, HK, HV, SM, 1>::total) > wgs_per_cu(T<HQ, HK, HV, SM, 2>::total) && wgs_per_cu(T<HQ, HK, HV, SM, 1>::total) <= 3) ? 1 : 2;
+#endif
+}
 constexpr int QW = 4;       // waves (32-token tiles) per workgroup
 
 struct Args {
@@ -315,18 +327,19 @@ __device__ __forceinline__ F load_perm_tr(const short* rows, int dt, int s2, int
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <bool HQ, bool HK, bool HV, bool SM> struct LdsF {
-    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
+template <bool HQ, bool HK, bool HV, bool SM, int VB> struct LdsFv {
+    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, VBUFS = VB;
     static constexpr int kbuf = 0;                                   // 2 x [32][KP] bf16
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP] bf16 (read transposed: load_perm_tr)
     static constexpr int wkT = 0;                                    // [64 buckets][KP] bf16: prologue only, over the tile area
     static constexpr int wvT = 0;                                    // [64 d][KP] bf16 (columns = buckets): epilogue only, over the tile area
-    static constexpr int wqT = vbuf + 2 * 32 * KP * 2;               // [64 buckets][KP] bf16: every key tile (lq_tile)
+    static constexpr int wqT = vbuf + VBUFS * 32 * KP * 2;           // [64 buckets][KP] bf16: every key tile (lq_tile)
     static constexpr int lk = wqT + (HQ ? 64 * KP * 2 : 0);          // QW x [32][LBP] bf16
     static constexpr int sv = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LKP] fp32
     static constexpr int lq = sv + (HV ? QW * 32 * LKP * 4 : 0);     // 2 x [32 keys][LBP] bf16
     static constexpr int total = lq + (HQ ? 2 * 32 * Pitch<SM>::LQ * 2 : 0);
 };
+template <bool HQ, bool HK, bool HV, bool SM> using LdsF = LdsFv<HQ, HK, HV, SM, pick_vbufs<LdsFv, HQ, HK, HV, SM>()>;
 
 // S^T tile (rows = streamed tokens, column = own token) with the relative position terms:
 //   own_row[id_own]             lookups indexed by the lane's own token        (ids in own_ids)
@@ -372,7 +385,7 @@ __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const shor
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
 __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsF<HQ, HK, HV, SM>;
-    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ, VBUFS = L::VBUFS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -452,8 +465,9 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                 if constexpr (HQ) siq = ids_load(a.idq, a.NP, qi, t + 1, g);
                 if constexpr (HV) siv = ids_load(a.idv, a.NP, qi, t + 1, g);
             }
+            f32x16 s = {};
             if (active) {
-                f32x16 s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
+                s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
                 if (t == NT - 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -500,7 +514,10 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
                     for (int r = 0; r < 16; ++r)
                         s[r] = drop_keep(dkey, qi, t * 32 + acc_row(r, g), a.drop_thr) ? s[r] * a.drop_scale : 0.f;
                 }
-                const short* vb = vbuf + cur * 32 * KP;
+            }
+            if constexpr (VBUFS == 1) __syncthreads();     // the one V buffer was refilled behind the previous tile's barrier
+            if (active) {
+                const short* vb = vbuf + (VBUFS == 2 ? cur : 0) * 32 * KP;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const F pb = TT::from_acc(s, s2);
@@ -511,11 +528,12 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
             }
             if (more) {
                 rows_store(kbuf + nxt * 32 * KP, sk);
-                rows_store(vbuf + nxt * 32 * KP, sv4);
+                if constexpr (VBUFS == 2) rows_store(vbuf + nxt * 32 * KP, sv4);
                 if constexpr (HK) cik = sik;
                 if constexpr (HQ) ciq = siq;
                 if constexpr (HV) civ = siv;
                 __syncthreads();
+                if constexpr (VBUFS == 1) rows_store(vbuf, sv4);                // every wave is past this tile's value product
                 if constexpr (HQ) lq_tile<LQP>(lqs + nxt * 32 * LQP, wqT, kbuf + nxt * 32 * KP, a.scale, wave, lane, a.wq != nullptr);
             }
         }
@@ -552,22 +570,31 @@ __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {     
 // ---------------------------------------------------------------------------------------------------
 // backward A: lanes own queries — delta, dq, dLK; LK / G rows for launch B
 // ---------------------------------------------------------------------------------------------------
-template <bool HQ, bool HK, bool HV, bool SM> struct LdsA {
-    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;
+template <bool HQ, bool HK, bool HV, bool SM, int VB> struct LdsAv {
+    static constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, VBUFS = VB;
     static constexpr int kbuf = 0;                                   // 2 x [32][KP]   K rows
     static constexpr int vbuf = kbuf + 2 * 32 * KP * 2;              // 2 x [32][KP]   V rows
-    static constexpr int stage_end = vbuf + 2 * 32 * KP * 2;         // (two tables are staged over this area outside the loop)
+    static constexpr int tile_end = vbuf + VBUFS * 32 * KP * 2;
+    static constexpr int tables = (HV ? 2 : (HK ? 1 : 0)) * 64 * KP * 2;             // Wk^T (slot 0) / Wv (slot 1) are staged over the tile area outside the loop:
+    static constexpr int stage_end = tile_end > tables ? tile_end : tables;          // room for both even with ONE V buffer
     static constexpr int lk = stage_end;                             // QW x [32][LBP] bf16
     static constexpr int gl = lk + (HK ? QW * 32 * LBP * 2 : 0);     // QW x [32][LBP] bf16
     static constexpr int dlk = gl + (HV ? QW * 32 * LBP * 2 : 0);    // QW x [32][LKP] fp32
     static constexpr int lq = dlk + (HK ? QW * 32 * LKP * 4 : 0);    // 2 x [32][LBP] bf16
     static constexpr int total = lq + (HQ ? 2 * 32 * Pitch<SM>::LQ * 2 : 0);
 };
+template <bool HQ, bool HK, bool HV, bool SM> using LdsA = LdsAv<HQ, HK, HV, SM, pick_vbufs<LdsAv, HQ, HK, HV, SM>()>;
+#ifndef IRPE_V_DOUBLE
+static_assert(LdsF<false, true, true, true>::VBUFS == 1 && LdsA<false, true, false, true>::VBUFS == 1, "the two kernels the third workgroup is for");
+static_assert(LdsF<true, true, true, true>::VBUFS == 2 && LdsA<true, true, true, true>::VBUFS == 2 && LdsF<false, false, true, true>::VBUFS == 2 &&
+              LdsF<false, true, false, true>::VBUFS == 2 && LdsA<false, true, true, true>::VBUFS == 2, "no barrier where it buys no workgroup");
+static_assert(LdsF<true, true, true, true>::total <= 80 * 1024 && LdsA<true, true, true, true>::total <= 80 * 1024, "q + k + v: twice per CU");
+#endif
 
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
 __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsA<HQ, HK, HV, SM>;
-    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ;
+    constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ, VBUFS = L::VBUFS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = a.NP >> 5, QB = (NT + QW - 1) / QW;
     const int lb = xcd_order(blockIdx.x, gridDim.x);
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     auto commit = [&](const Stage& r, int t) {
         const int buf = t & 1;
         rows_store(kbuf + buf * 32 * KP, r.k);
-        rows_store(vbuf + buf * 32 * KP, r.v);
+        if constexpr (VBUFS == 2) rows_store(vbuf + buf * 32 * KP, r.v);
         if constexpr (HQ) { if (lq_rows) lrows_store<LQP>(lqs + buf * 32 * LQP, r.lq); }
         if constexpr (HK) cik = r.ik;
         if constexpr (HQ) ciq = r.iq;
@@ -673,6 +700,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
     for (int t = 0; t < PF; ++t)
         if (t < NT) issue(st[t], t);
     commit(st[0], 0);
+    if constexpr (VBUFS == 1) rows_store(vbuf, st[0].v);
     __syncthreads();
 
     // ---- key tiles ----------------------------------------------------------------------------------
@@ -681,10 +709,12 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         constexpr int K = decltype(slot)::value;
         const int cur = t & 1;
         if (t + PF < NT) issue(st[K], t + PF);
+        f32x16 s = {};
+        if (active) s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
+        if constexpr (VBUFS == 1) __syncthreads();     // the one V buffer was refilled behind the previous tile's barrier
         if (active) {
-            f32x16 s = score_tile<HK, HQ, LQP>(kbuf + cur * 32 * KP, qs, cik, ciq, lkw + c32 * LBP, lqs + cur * 32 * LQP, lane);
             f32x16 dp = {};
-            const short* vb = vbuf + cur * 32 * KP;
+            const short* vb = vbuf + (VBUFS == 2 ? cur : 0) * 32 * KP;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = TT::mma(TT::load(vb + c32 * KP + ks * 16 + g * 8), dob[ks], dp);
             if constexpr (HV) {
@@ -713,6 +743,7 @@ __global__ __launch_bounds__(256) void irpe_attn_bwd_q_kernel(const Args a) {   
         if (t + 1 < NT) {
             commit(st[(K + 1) % PF], t + 1);
             __syncthreads();
+            if constexpr (VBUFS == 1) rows_store(vbuf, st[(K + 1) % PF].v);    // every wave is past this tile's dP product
         }
     });
 
