@@ -383,6 +383,9 @@ __device__ __forceinline__ void lq_tile(short* dst, const short* wqT, const shor
 }
 
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
+// without any rpe term (TinyCLIP's towers): 108 VGPRs — held to 102 (96 used, 16 bytes of scratch) a fifth workgroup fits: 153 -> 144.5 us
+// at config 4's shape (same-call A/B, tools/probe_irpe_variants.sh)
+__attribute__((amdgpu_waves_per_eu((!HQ && !HK && !HV && !DROP) ? 5 : 2)))
 __global__ __launch_bounds__(256) void irpe_attn_fwd_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsF<HQ, HK, HV, SM>;
     constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK, LQP = Pitch<SM>::LQ, VBUFS = L::VBUFS;
@@ -811,6 +814,9 @@ template <bool HQ, bool HK, bool HV, bool SM> struct LdsB {
 };
 
 template <bool HQ, bool HK, bool HV, bool DROP = false, bool SM = false>      // DROP: attention dropout (its own instantiations: the
+// without any rpe term the launch is register-bound at two waves per SIMD (184 VGPRs, 18 KB of LDS): held to 170 registers (164 used, no
+// scratch) a third workgroup fits — 300 -> 265 us at config 4's shape; with rpe on k the same bound costs 52 bytes of scratch and 2 %
+__attribute__((amdgpu_waves_per_eu((!HQ && !HK && !HV && !DROP) ? 3 : 2)))
 __global__ __launch_bounds__(256) void irpe_attn_bwd_kv_kernel(const Args a) {       // hash temporaries cost 6-40 VGPRs); SM: Pitch
     using L = LdsB<HQ, HK, HV, SM>;
     constexpr int LBP = Pitch<SM>::LB, LKP = Pitch<SM>::LK;

@@ -1,7 +1,6 @@
 #!/bin/bash
-# one visit: rocprofv3 kernel stats of the TinyCLIP config-5 leg
-export TMPDIR=/tmp; REPO=$(pwd); OUT=$REPO/gpurun_out
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r06m_tc_prof -o tc -- python $REPO/tools/bench_tinyclip.py > $OUT/r06m_tc.json 2> $OUT/r06m_tc.err
-cd $REPO; cat $OUT/r06m_tc.json
-python tools/summarize_rocprof.py $(find $OUT/r06m_tc_prof -name '*kernel_stats.csv' | head -1) > $OUT/r06m_tinyclip_kernel_stats.md 2>&1; head -30 $OUT/r06m_tinyclip_kernel_stats.md | cut -c1-200
+# one visit: the attention-family parity tests, then the config-4 layer and the TinyCLIP leg
+timeout 1500 python -m pytest tests/test_irpe_fused_gpu.py tests/test_irpe_gpu.py tests/test_minivit.py tests/test_detr_attention.py tests/test_tinyclip_model.py tests/test_tinyclip_loss.py -m gpu -x -q 2>&1 | tail -4
+timeout 300 python tools/bench_irpe_attention.py 2>/dev/null | tee gpurun_out/r06o_irpe_attention.jsonl | cut -c1-330
+timeout 300 python tools/bench_tinyclip.py 2>/dev/null | tee gpurun_out/r06o_tinyclip.json
+bash tools/irpe_round.sh r06o notest | tail -24
