@@ -494,7 +494,13 @@ __global__ __launch_bounds__(64) void rpe_scatter_planes(
             for (int q = 0; q < LPR; ++q) {
                 Pack pk;
                 pk.vec = *reinterpret_cast<const u32x4*>(tile + lane * TP + q * V);
-                constexpr int G = V < 4 ? V : 4;       // keys per read-modify-write group
+#ifdef RPE_SCATTER_GROUP
+                constexpr int G = V < RPE_SCATTER_GROUP ? V : RPE_SCATTER_GROUP;       // probe (tools/probe_irpe_variants.sh)
+#else
+                // keys per read-modify-write group.  Same-call A/B at config 4 (round 6): 8 / 4 / 2 / 1 -> bf16 230 / 203 / 195 / 203 us,
+                // fp32 272 / 268 / 275 / 263 (noise): the kernel is not bound by this chain — two for 16-bit elements, four otherwise
+                constexpr int G = BYTES == 2 ? 2 : (V < 4 ? V : 4);
+#endif
 #pragma unroll
                 for (int g0 = 0; g0 < V; g0 += G) {
                     int u[G];
