@@ -39,8 +39,12 @@ class METHOD:
 
 class RPEConfig(dict):
     """Attribute-style dict (the reference uses easydict.EasyDict)."""
-    __getattr__ = dict.get
     __setattr__ = dict.__setitem__
+
+    def __getattr__(self, name):
+        if name.startswith("__"):          # copy / pickle probe special methods through getattr: they must see AttributeError
+            raise AttributeError(name)
+        return self.get(name)
 
 
 @torch.no_grad()

@@ -184,21 +184,105 @@ def _flops(B, H, L, n_terms, bwd):
     return (2.5 if bwd else 1.0) * 4.0 * B * H * L * L * 64 + (3 if bwd else 1) * n_terms * 2.0 * B * H * L * 64 * 64
 
 
+def fwd_core(qkv, scale, terms, drop_p=0.0, seed=0, causal=False):
+    """One forward launch: qkv (B, L, 3, H, 64) bf16 -> (out (B, L, H*64), lse (B, H, L) fp32, sv (B, H, NP, 64) or None).
+    `terms` = (_term(rpe_q), _term(rpe_k), _term(rpe_v)), each None when absent.  Outside autograd."""
+    B, L, _, H, D = qkv.shape
+    NP = padded_len(L)
+    out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    sv = torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=qkv.device) if terms[2] is not None else None
+    d = _desc(qkv, scale, terms, out, lse, sv)
+    d.dropout_p, d.dropout_seed = float(drop_p), int(seed)
+    d.causal = 1 if causal else 0
+    n_terms = sum(t is not None for t in terms)
+    with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, n_terms, False)):
+        rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cream_irpe_attn_fwd")
+    return out, lse, sv
+
+
+def bwd_core(dout, qkv, out, lse, sv, scale, terms, drop_p=0.0, seed=0, causal=False):
+    """The backward launches of fwd_core: -> (dqkv (B, L, 3, H, 64), [d table of rpe_q, rpe_k, rpe_v] — each None or a tensor of the
+    table's shape and dtype).  Outside autograd."""
+    tq, tk, tv = terms
+    if tv is None:
+        sv = None
+    B, L, _, H, D = qkv.shape
+    NP = padded_len(L)
+    dev = qkv.device
+    dout = dout.contiguous()
+    dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
+    d = _desc(qkv, scale, terms, out, lse, sv)
+    d.dropout_p, d.dropout_seed = float(drop_p), int(seed)
+    d.causal = 1 if causal else 0
+    d.dout = dout.data_ptr()
+    es = dqkv.element_size()
+    sb, sn, s3, sh, _ = dqkv.stride()
+    d.dq, d.dk, d.dv = dqkv.data_ptr(), dqkv.data_ptr() + s3 * es, dqkv.data_ptr() + 2 * s3 * es
+    d.dsb, d.dsn, d.dsh = sb, sn, sh
+    delta = torch.empty((B, H, NP), dtype=torch.float32, device=dev)
+    rows = lambda: torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=dev)      # noqa: E731
+    lkg = dlk = gg = dlq = None
+    d.delta = delta.data_ptr()
+    if tk is not None:
+        lkg, dlk = rows(), rows()
+        d.lkg, d.dlk = lkg.data_ptr(), dlk.data_ptr()
+    if tv is not None:
+        gg = rows()
+        d.gg = gg.data_ptr()
+    if tq is not None:
+        dlq = rows()
+        d.dlq = dlq.data_ptr()
+    lib = _lib.load()
+    n_terms = sum(t is not None for t in terms)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        with timing.region("irpe_attn_bwd", flops=_flops(B, H, L, n_terms, True)):
+            rc = lib.cream_irpe_attn_bwd(ctypes.byref(d), stream)
+        _lib.check(rc, "cream_irpe_attn_bwd")
+
+        def table_grad(x, xs, y, ys, mul):
+            part = torch.empty((B, H, 64, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.cream_irpe_table_grad(part.data_ptr(), x, xs[0], xs[1], xs[2], y, ys[0], ys[1], ys[2],
+                                                 B, H, L, mul, stream), "cream_irpe_table_grad")
+            return part.sum(0)                                   # (H, 64, 64)
+
+        qs = qkv.stride()
+        q_str, row_str = (qs[0], qs[1], qs[3]), (H * NP * 64, 64, NP * 64)
+        do_str = (L * H * 64, H * 64, 64)
+        es_q = qkv.element_size()
+        grads = [None, None, None]
+        if tq is not None and tq[5]:   # bias mode: d lookup_table_bias (H', nb) = the bucket gradient rows summed
+            grads[0] = dlq[:, :, :L].sum((0, 2), dtype=torch.float32)
+        elif tq is not None:    # d lookup_table_weight(rpe_q) (H', 64, nb) = (scale k)^T dlq
+            grads[0] = table_grad(qkv.data_ptr() + qs[2] * es_q, q_str, dlq.data_ptr(), row_str, scale)
+        if tk is not None and tk[5]:
+            grads[1] = dlk[:, :, :L].sum((0, 2), dtype=torch.float32)
+        elif tk is not None:    # (scale q)^T dlk
+            grads[1] = table_grad(qkv.data_ptr(), q_str, dlk.data_ptr(), row_str, scale)
+        if tv is not None:      # (H', nb, 64) = sv^T dout
+            grads[2] = table_grad(sv.data_ptr(), row_str, dout.data_ptr(), do_str, 1.0)
+    res = []
+    for gpart, t, transposed in zip(grads, terms, (True, True, False)):
+        if gpart is None:
+            res.append(None)
+            continue
+        w, nb = t[0], t[4]
+        if w.shape[0] == 1:
+            gpart = gpart.sum(0, keepdim=True)
+        if t[5]:
+            res.append(gpart[:, :nb].to(w.dtype).contiguous())
+            continue
+        res.append((gpart[:, :, :nb] if transposed else gpart[:, :nb, :]).to(w.dtype).contiguous())
+    return dqkv, res
+
+
 class _Fused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, scale, wq, wk, wv, terms, drop_p=0.0, seed=0):
-        B, L, _, H, D = qkv.shape
-        NP = padded_len(L)
-        out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-        sv = torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=qkv.device) if terms[2] is not None else None
-        d = _desc(qkv, scale, terms, out, lse, sv)
-        d.dropout_p, d.dropout_seed = float(drop_p), int(seed)
+        out, lse, sv = fwd_core(qkv, scale, terms, drop_p, seed)
         ctx.drop = (float(drop_p), int(seed))
-        n_terms = sum(t is not None for t in terms)
-        with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, n_terms, False)):
-            rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "cream_irpe_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, sv if sv is not None else lse)
         ctx.scale, ctx.terms = scale, terms
         return out
@@ -206,111 +290,22 @@ class _Fused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, sv = ctx.saved_tensors
-        terms, scale = ctx.terms, ctx.scale
-        tq, tk, tv = terms
-        if tv is None:
-            sv = None
-        B, L, _, H, D = qkv.shape
-        NP = padded_len(L)
-        dev = qkv.device
-        dout = dout.contiguous()
-        dqkv = torch.empty_like(qkv, memory_format=torch.contiguous_format)
-        d = _desc(qkv, scale, terms, out, lse, sv)
-        d.dropout_p, d.dropout_seed = ctx.drop
-        d.dout = dout.data_ptr()
-        es = dqkv.element_size()
-        sb, sn, s3, sh, _ = dqkv.stride()
-        d.dq, d.dk, d.dv = dqkv.data_ptr(), dqkv.data_ptr() + s3 * es, dqkv.data_ptr() + 2 * s3 * es
-        d.dsb, d.dsn, d.dsh = sb, sn, sh
-        delta = torch.empty((B, H, NP), dtype=torch.float32, device=dev)
-        rows = lambda: torch.empty((B, H, NP, 64), dtype=qkv.dtype, device=dev)      # noqa: E731
-        lkg = dlk = gg = dlq = None
-        d.delta = delta.data_ptr()
-        if tk is not None:
-            lkg, dlk = rows(), rows()
-            d.lkg, d.dlk = lkg.data_ptr(), dlk.data_ptr()
-        if tv is not None:
-            gg = rows()
-            d.gg = gg.data_ptr()
-        if tq is not None:
-            dlq = rows()
-            d.dlq = dlq.data_ptr()
-        lib = _lib.load()
-        n_terms = sum(t is not None for t in terms)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
-            with timing.region("irpe_attn_bwd", flops=_flops(B, H, L, n_terms, True)):
-                rc = lib.cream_irpe_attn_bwd(ctypes.byref(d), stream)
-            _lib.check(rc, "cream_irpe_attn_bwd")
-
-            def table_grad(x, xs, y, ys, mul):
-                part = torch.empty((B, H, 64, 64), dtype=torch.float32, device=dev)
-                _lib.check(lib.cream_irpe_table_grad(part.data_ptr(), x, xs[0], xs[1], xs[2], y, ys[0], ys[1], ys[2],
-                                                     B, H, L, mul, stream), "cream_irpe_table_grad")
-                return part.sum(0)                                   # (H, 64, 64)
-
-            qs = qkv.stride()
-            q_str, row_str = (qs[0], qs[1], qs[3]), (H * NP * 64, 64, NP * 64)
-            do_str = (L * H * 64, H * 64, 64)
-            es_q = qkv.element_size()
-            grads = [None, None, None]
-            if tq is not None and tq[5]:   # bias mode: d lookup_table_bias (H', nb) = the bucket gradient rows summed
-                grads[0] = dlq[:, :, :L].sum((0, 2), dtype=torch.float32)
-            elif tq is not None:    # d lookup_table_weight(rpe_q) (H', 64, nb) = (scale k)^T dlq
-                grads[0] = table_grad(qkv.data_ptr() + qs[2] * es_q, q_str, dlq.data_ptr(), row_str, scale)
-            if tk is not None and tk[5]:
-                grads[1] = dlk[:, :, :L].sum((0, 2), dtype=torch.float32)
-            elif tk is not None:    # (scale q)^T dlk
-                grads[1] = table_grad(qkv.data_ptr(), q_str, dlk.data_ptr(), row_str, scale)
-            if tv is not None:      # (H', nb, 64) = sv^T dout
-                grads[2] = table_grad(sv.data_ptr(), row_str, dout.data_ptr(), do_str, 1.0)
-        res = []
-        for gpart, t, transposed in zip(grads, terms, (True, True, False)):
-            if gpart is None:
-                res.append(None)
-                continue
-            w, nb = t[0], t[4]
-            if w.shape[0] == 1:
-                gpart = gpart.sum(0, keepdim=True)
-            if t[5]:
-                res.append(gpart[:, :nb].to(w.dtype).contiguous())
-                continue
-            res.append((gpart[:, :, :nb] if transposed else gpart[:, :nb, :]).to(w.dtype).contiguous())
+        dqkv, res = bwd_core(dout, qkv, out, lse, sv, ctx.scale, ctx.terms, *ctx.drop)
         return dqkv, None, res[0], res[1], res[2], None, None, None
+
+
+_NO_TERMS = (None, None, None)
 
 
 def plain_fwd(qkv, scale, causal=False):
     """Attention without any relative position term, forward only, outside autograd: qkv (B, L, 3, H, 64) bf16 ->
     (out (B, L, H*64) bf16, lse (B, H, L) fp32).  For callers that sequence their own backward (cream_amd.tinyclip.native)."""
-    B, L, _, H, D = qkv.shape
-    out = torch.empty((B, L, H * D), dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-    d = _desc(qkv, scale, (None, None, None), out, lse, None)
-    d.causal = 1 if causal else 0
-    with torch.cuda.device(qkv.device), timing.region("irpe_attn_fwd", flops=_flops(B, H, L, 0, False)):
-        rc = _lib.load().cream_irpe_attn_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "cream_irpe_attn_fwd")
-    return out, lse
+    return fwd_core(qkv, scale, _NO_TERMS, causal=causal)[:2]
 
 
 def plain_bwd(dout, qkv, out, lse, scale, causal=False):
     """Backward of plain_fwd: -> dqkv (B, L, 3, H, 64) bf16 (two launches)."""
-    B, L, _, H, D = qkv.shape
-    dqkv = torch.empty((B, L, 3, H, D), dtype=qkv.dtype, device=qkv.device)
-    d = _desc(qkv, scale, (None, None, None), out, lse, None)
-    d.causal = 1 if causal else 0
-    dout = dout.contiguous()
-    d.dout = dout.data_ptr()
-    es = dqkv.element_size()
-    sb, sn, s3, sh, _ = dqkv.stride()
-    d.dq, d.dk, d.dv = dqkv.data_ptr(), dqkv.data_ptr() + s3 * es, dqkv.data_ptr() + 2 * s3 * es
-    d.dsb, d.dsn, d.dsh = sb, sn, sh
-    delta = torch.empty((B, H, padded_len(L)), dtype=torch.float32, device=qkv.device)
-    d.delta = delta.data_ptr()
-    with torch.cuda.device(qkv.device), timing.region("irpe_attn_bwd", flops=_flops(B, H, L, 0, True)):
-        rc = _lib.load().cream_irpe_attn_bwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "cream_irpe_attn_bwd")
-    return dqkv
+    return bwd_core(dout, qkv, out, lse, None, scale, _NO_TERMS, causal=causal)[0]
 
 
 def attention(qkv, scale, rpe_q, rpe_k, rpe_v, dropout_p=0.0, seed=None):

@@ -168,8 +168,12 @@ class VisionTransformer(nn.Module):
         x = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1) + self.pos_embed
         x = self.pos_drop(x)
-        for blk in self.blocks:
-            x = blk(x)
+        from . import deit_native
+        if deit_native.supported(self.blocks, x):            # bf16 autocast: the whole run of blocks on the own kernels, one node
+            x = deit_native.run(self.blocks, x)
+        else:
+            for blk in self.blocks:
+                x = blk(x)
         return self.norm(x)[:, 0]
 
     def forward(self, x):
@@ -188,7 +192,7 @@ def deit_irpe(size='tiny', img_size=224, rpe_on='k', method='product', mode='ctx
     from functools import partial
     cfg = get_rpe_config(ratio=ratio, method=method, mode=mode, shared_head=shared_head, skip=1, rpe_on=rpe_on)
     return VisionTransformer(img_size=img_size, patch_size=16, mlp_ratio=4, qkv_bias=True,
-                             norm_layer=partial(nn.LayerNorm, eps=1e-6), rpe_config=cfg, **_DEIT[size], **kwargs)
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), rpe_config=cfg, **{**_DEIT[size], **kwargs})
 
 
 def deit_tiny_patch16_224_ctx_product_50_shared_k(**kwargs):

@@ -18,8 +18,8 @@ from cream_amd.rpe_attention import deit_irpe
 dev = torch.device("cuda")
 B = int(os.environ.get("DEIT_BATCH", "64"))
 for rpe_on in ("k", "qkv"):
-    for fused in ("1", "0"):
-        os.environ["CREAM_IRPE_FUSED"] = fused
+    for fused, native in (("1", "1"), ("1", "0"), ("0", "0")):
+        os.environ["CREAM_IRPE_FUSED"], os.environ["CREAM_DEIT_NATIVE"] = fused, native
         torch.manual_seed(0)
         model = deit_irpe("base", img_size=384, rpe_on=rpe_on).to(dev)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
@@ -44,6 +44,7 @@ for rpe_on in ("k", "qkv"):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         print(json.dumps({"workload": f"DeiT-base-384 + iRPE product-ctx rpe_on={rpe_on}, train step, bf16 autocast", "batch": B, "L": 577,
+                          "blocks": ("own kernels end to end (cream_amd/deit_native.py)" if native == "1" else "framework linears / LayerNorm / GELU"),
                           "attention": "fused (csrc/irpe_attn.hip)" if fused == "1" else "composed (rpe_index gather / scatter-add, (B,H,L,L) tensors)",
                           "ms_per_step": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1), "loss": round(float(loss), 4),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
@@ -51,3 +52,4 @@ for rpe_on in ("k", "qkv"):
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
 os.environ.pop("CREAM_IRPE_FUSED", None)
+os.environ.pop("CREAM_DEIT_NATIVE", None)
