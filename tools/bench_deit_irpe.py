@@ -17,8 +17,11 @@ from cream_amd.rpe_attention import deit_irpe
 
 dev = torch.device("cuda")
 B = int(os.environ.get("DEIT_BATCH", "64"))
+ONLY = os.environ.get("DEIT_ONLY")                 # e.g. "k1": rpe on k, own kernels only (profiling)
 for rpe_on in ("k", "qkv"):
     for fused, native in (("1", "1"), ("1", "0"), ("0", "0")):
+        if ONLY and (rpe_on, native) != (ONLY[:-1], ONLY[-1]):
+            continue
         os.environ["CREAM_IRPE_FUSED"], os.environ["CREAM_DEIT_NATIVE"] = fused, native
         torch.manual_seed(0)
         model = deit_irpe("base", img_size=384, rpe_on=rpe_on).to(dev)

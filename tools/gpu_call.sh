@@ -1,4 +1,5 @@
 #!/bin/bash
-# one visit: the native DeiT block stack — parity tests, TinyCLIP tests (same node), then config 4 as a whole model
-timeout 900 python -m pytest tests/test_deit_native_gpu.py tests/test_tinyclip_model.py tests/test_tinyclip_loss.py tests/test_irpe_gpu.py -m gpu -x -q -s 2>&1 | grep -E "deit native|passed|failed|Error|error|assert" | cut -c1-700 | tail -20
-
+# one visit: the whole GPU suite, smoke and the bench line at the final tree
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+CREAM_BENCH_EXTRA=gpurun_out/r06s_bench_extra.json timeout 600 python bench.py > gpurun_out/r06s_bench.json 2> gpurun_out/r06s_bench.err; cut -c1-400 gpurun_out/r06s_bench.json
