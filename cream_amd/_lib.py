@@ -131,7 +131,7 @@ class GradJob(ctypes.Structure):
     """struct cream_grad_job of include/cream_amd.h."""
     _fields_ = [("dst", _vp), ("src", _vp), ("ld", _i64), ("pstride", _i64),
                 ("nparts", _c.c_int32), ("rows", _c.c_int32), ("cols", _c.c_int32),
-                ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("reserved", _c.c_int32)]
+                ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("overwrite", _c.c_int32)]
 
 class SliceJob(ctypes.Structure):
     """struct cream_slice_job of include/cream_amd.h."""

@@ -380,11 +380,17 @@ class GradJobs:
         self.keep = []
 
     def add(self, param, src, nparts, pstride, rows, cols, interleave=0, src_offset=0, ld=None):
+        fresh = False
         if param.grad is None:
-            param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+            # a job that covers the whole parameter writes its gradient instead of adding to a zero fill (one launch less per
+            # parameter and step where the optimizer drops the gradients: TinyCLIP / DeiT towers); slices of a super-weight
+            # (AutoFormer) need the zeros around them
+            fresh = not interleave and ld is None and rows * cols == param.numel()
+            param.grad = (torch.empty_like if fresh else torch.zeros_like)(param, memory_format=torch.contiguous_format)
         g = param.grad
         assert g.is_contiguous() or g.dim() <= 2
         j = self.jobs[self.n]
+        j.overwrite = 1 if fresh else 0
         j.dst = g.data_ptr()
         j.src = src.data_ptr() + src_offset * src.element_size()
         j.ld = ld if ld is not None else (g.stride(0) if g.dim() == 2 else cols)

@@ -499,6 +499,7 @@ template <> struct PartChunk<4> {
         o += v;
         *reinterpret_cast<f32x4v*>(d) = o;
     }
+    __device__ __forceinline__ void store(float* d) const { *reinterpret_cast<f32x4v*>(d) = v; }
 };
 template <> struct PartChunk<8> {                                  // bf16 sources only
     f32x4v lo, hi;
@@ -520,6 +521,10 @@ template <> struct PartChunk<8> {                                  // bf16 sourc
         o1 += hi;
         *reinterpret_cast<f32x4v*>(d) = o0;
         *reinterpret_cast<f32x4v*>(d + 4) = o1;
+    }
+    __device__ __forceinline__ void store(float* d) const {
+        *reinterpret_cast<f32x4v*>(d) = lo;
+        *reinterpret_cast<f32x4v*>(d + 4) = hi;
     }
 };
 
@@ -568,7 +573,8 @@ __device__ __forceinline__ void grad_finalize_job(const cream_grad_job& jb, int 
         for (int l = 1; l < nl; ++l) s.add(red[l * CL + cl]);
         const int r = (int)(chunk / cpr), c = (int)(chunk - (int64_t)r * cpr) * W;
         const int rr = jb.interleave > 0 ? 3 * (r % jb.interleave) + r / jb.interleave : r;
-        s.add_into(jb.dst + (int64_t)rr * jb.ld + c);
+        if (jb.overwrite) s.store(jb.dst + (int64_t)rr * jb.ld + c);      // dst = the sum (a gradient that did not exist yet: no zero fill)
+        else s.add_into(jb.dst + (int64_t)rr * jb.ld + c);
     }
 }
 

@@ -406,7 +406,7 @@ int cream_block_bwd(const cream_block_desc* d, const cream_block_grads* G, const
     auto job = [&](float* dst, int64_t ld, const void* src, int nparts, int64_t pstride, int rows, int cols, int interleave,
                    int bf16) {
         J[n].dst = dst; J[n].src = src; J[n].ld = ld; J[n].pstride = pstride; J[n].nparts = nparts; J[n].rows = rows;
-        J[n].cols = cols; J[n].interleave = interleave; J[n].src_bf16 = bf16; J[n].reserved = 0;
+        J[n].cols = cols; J[n].interleave = interleave; J[n].src_bf16 = bf16; J[n].overwrite = 0;
         ++n;
     };
     job(G->w2, G->ld_w2, at<void>(ws, L.pw2), S2, (int64_t)E * F, E, F, 0, wb16);

@@ -489,7 +489,8 @@ typedef struct cream_grad_job {
     int32_t nparts, rows, cols;
     int32_t interleave;
     int32_t src_bf16;      /* partials are bf16 (1) or fp32 (0) */
-    int32_t reserved;
+    int32_t overwrite;     /* 0: dst += sum of the parts; 1: dst = sum (a gradient that did not exist yet: the caller allocates it
+                              uninitialised instead of zero-filling it; the job must cover all of dst) */
 } cream_grad_job;
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);

@@ -283,6 +283,23 @@ def test_grad_finalize_adds_partials_into_super_weight_slices():
     tab.grad.zero_()
     run()
     assert all(torch.equal(a, p.grad) for a, p in zip(first, (w, wq, bias, tab)))   # fixed summation tree
+    # overwrite mode (cream_grad_job.overwrite: a gradient that did not exist yet is allocated uninitialised and WRITTEN): whatever
+    # the destination held must not come through — bf16 (8-wide chunks) and fp32 (4-wide) partials
+    for parts, rows, cols in ((torch.randn(12, 64, 96, device=DEV, generator=g).bfloat16(), 64, 96), (torch.randn(200, 1, 76, device=DEV, generator=g), 1, 76)):
+        p = torch.nn.Parameter(torch.zeros(rows, cols, device=DEV).squeeze(0))
+        p.grad = torch.full_like(p, float("nan"))
+        jobs = K.GradJobs()
+        jobs.add(p, parts, parts.shape[0], rows * cols, rows, cols)
+        assert jobs.jobs[0].overwrite == 0                       # an existing gradient is accumulated into
+        jobs.jobs[0].overwrite = 1
+        jobs.launch()
+        assert torch.isfinite(p.grad).all() and _rel(p.grad, parts.float().sum(0).view_as(p)) < 1e-6
+        q = torch.nn.Parameter(torch.zeros_like(p))
+        jobs = K.GradJobs()
+        jobs.add(q, parts, parts.shape[0], rows * cols, rows, cols)
+        assert jobs.jobs[0].overwrite == 1                       # no gradient yet + the job covers the parameter
+        jobs.launch()
+        assert torch.equal(q.grad, p.grad)
 
 
 def _supernet(depth=2):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one visit: the whole GPU suite, smoke and the bench line at the final tree
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-CREAM_BENCH_EXTRA=gpurun_out/r06s_bench_extra.json timeout 600 python bench.py > gpurun_out/r06s_bench.json 2> gpurun_out/r06s_bench.err; cut -c1-400 gpurun_out/r06s_bench.json
+# one visit: gradient finalisation in overwrite mode — its test, the stacks that use it, the two model-level legs
+timeout 900 python -m pytest tests/test_block_gpu.py tests/test_deit_native_gpu.py tests/test_tinyclip_model.py tests/test_tinyclip_loss.py tests/test_autoformer_gpu.py -m gpu -x -q 2>&1 | tail -3
+DEIT_ONLY=k1 timeout 300 python tools/bench_deit_irpe.py 2>/dev/null | grep "^{" | cut -c1-330
+timeout 300 python tools/bench_tinyclip.py 2>/dev/null | cut -c1-300
