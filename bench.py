@@ -440,6 +440,40 @@ def irpe_config4_leg(iters=10):
     return dict(workload="RPEAttention layer fwd+bwd, DeiT-B-384 iRPE product-ctx, B=64 H=12 L=577, bf16 autocast", **out)
 
 
+def deit_config4_model_leg(iters=6, batch=64):
+    """BASELINE config 4 as a whole model: DeiT-base-384 + iRPE (product, contextual, rpe on k), batch 64, one training step
+    (forward + backward + AdamW) under bf16 autocast with the run of RPEBlocks as one node on the own kernels
+    (cream_amd/deit_native.py); tools/bench_deit_irpe.py measures the framework / composed variants beside it."""
+    from cream_amd.rpe_attention import deit_irpe
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = deit_irpe("base", img_size=384, rpe_on="k").to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    x = torch.randn(batch, 3, 384, 384, device=dev)
+    y = torch.randint(0, 1000, (batch,), device=dev)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    del model, opt, x, y
+    torch.cuda.empty_cache()
+    return dict(workload="DeiT-base-384 + iRPE product-ctx (rpe on k) train step, batch 64, L = 577, bf16 autocast, blocks on the own kernels",
+                ms_per_step=round(ms, 2), images_per_s=round(batch / ms * 1e3, 1))
+
+
 def tinyclip_config5_leg(batch=256, iters=10):
     """BASELINE config 5 on ONE device: the affinity-mimicking distillation step of TinyCLIP — student
     TinyCLIP-ViT-39M/16 + Text-19M, frozen teacher ViT-B/16, ClipSoftLoss, gradient clipping 5, AdamW — on synthetic
@@ -759,6 +793,10 @@ def main():
             try:
                 del trainer, model, opt, reducer, images, target
                 torch.cuda.empty_cache()
+                line["irpe_config4"]["model"] = deit_config4_model_leg()
+            except Exception as e:
+                sys.stderr.write(f"[bench] DeiT config-4 model leg failed: {e}\n")
+            try:
                 line["tinyclip_config5"] = tinyclip_config5_leg()
             except Exception as e:
                 sys.stderr.write(f"[bench] TinyCLIP config-5 leg failed: {e}\n")
