@@ -9,8 +9,8 @@ erf-GELU / GELU' epilogues on bf16 operand copies, split-K weight gradients on a
 says where an RPEBlock keeps its parameters (`BlockView`) and when the node applies.  The lookup tables of the rpe terms get their
 gradients from the attention backward (cream_irpe_table_grad) and are accumulated into `.grad` like every other parameter of the node.
 
-Applies to: CUDA tensors under bf16 autocast, heads of 64, exact-erf GELU, no stochastic depth / projection / MLP dropout active
-(attention dropout is fine: in-kernel), every rpe either absent or a plain iRPE the fused kernels take (<= 64 buckets, contextual or
+Applies to: CUDA tensors under bf16 autocast, heads of 64, exact-erf GELU, no projection / MLP dropout active (attention dropout is
+fine: in-kernel; stochastic depth too: per-sample factors of the two branches through the residual / LayerNorm kernels), every rpe either absent or a plain iRPE the fused kernels take (<= 64 buckets, contextual or
 bias mode; the cross method keeps the module path: its one-table view is differentiated by autograd), all parameters trainable (or
 no gradient wanted at all).  `CREAM_DEIT_NATIVE=0` keeps the module path.
 """
@@ -28,7 +28,8 @@ def view_of(blk):
     at, mlp = blk.attn, blk.mlp
     return native.BlockView(blk.norm1, blk.norm2, [(at.qkv.weight, at.qkv.bias), (at.proj.weight, at.proj.bias),
                                                    (mlp.fc1.weight, mlp.fc1.bias), (mlp.fc2.weight, mlp.fc2.bias)],
-                            at.num_heads, (at.rpe_q, at.rpe_k, at.rpe_v), float(at.attn_drop.p), float(at.scale))
+                            at.num_heads, (at.rpe_q, at.rpe_k, at.rpe_v), float(at.attn_drop.p), float(at.scale),
+                            float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0))
 
 
 def _inactive(mod, training):
@@ -49,7 +50,9 @@ def _block_supported(blk, L, dev):
     if not (isinstance(blk.norm1, nn.LayerNorm) and isinstance(blk.norm2, nn.LayerNorm) and blk.norm1.elementwise_affine):
         return False
     tr = blk.training
-    if not (_inactive(blk.drop_path, tr) and _inactive(at.proj_drop, tr) and _inactive(mlp.drop, tr)):
+    if not (_inactive(at.proj_drop, tr) and _inactive(mlp.drop, tr)):
+        return False
+    if not (isinstance(blk.drop_path, nn.Identity) or hasattr(blk.drop_path, "drop_prob")):     # DropPath: per-sample factors in the node
         return False
     rpes = (at.rpe_q, at.rpe_k, at.rpe_v)
     if any(r is not None and type(r) is not iRPE for r in rpes):

@@ -29,10 +29,11 @@ class BlockView:
     the two LayerNorms, the four (weight, bias) pairs in the order qkv ([q; k; v] rows), output projection, fc1, fc2, the number
     of heads (of 64), and — for DeiT with iRPE (cream_amd.deit_native) — the relative position modules of the attention and its
     dropout rate."""
-    __slots__ = ("ln1", "ln2", "pairs", "heads", "rpes", "drop_p", "scale")
+    __slots__ = ("ln1", "ln2", "pairs", "heads", "rpes", "drop_p", "scale", "drop_path")
 
-    def __init__(self, ln1, ln2, pairs, heads, rpes=(None, None, None), drop_p=0.0, scale=0.125):
+    def __init__(self, ln1, ln2, pairs, heads, rpes=(None, None, None), drop_p=0.0, scale=0.125, drop_path=0.0):
         self.ln1, self.ln2, self.pairs, self.heads, self.rpes, self.drop_p, self.scale = ln1, ln2, pairs, heads, rpes, drop_p, scale
+        self.drop_path = drop_path        # stochastic depth rate of the block's two branches (rpe_vision_transformer.py:115-116)
 
 
 def clip_view(blk):
@@ -124,8 +125,20 @@ def _attn_meta(view, L, dev, training):
     return terms, p, (irpe_fused._new_seed(dev) if p else 0)
 
 
-def _block_forward(view, ops, x, pend, B, L, keep, causal, meta):
-    """x (M, D) fp32 stream (or, with pend = previous branch output f, the stream before that add).  -> (x1, f, saved)"""
+def _path_scales(view, B, dev, training):
+    """Stochastic depth (timm's DropPath as the reference's blocks use it: x + drop_path(branch(x))): per-sample factors
+    mask_b / keep of the attention branch and of the MLP branch, drawn from the device generator in the module's order; None when
+    inactive.  The LayerNorm / residual kernels take them as `sample_scale` (the AutoFormer block's mechanism)."""
+    if not (training and view.drop_path):
+        return None, None
+    keep = 1.0 - float(view.drop_path)
+    draw = lambda: torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep     # noqa: E731
+    return draw(), draw()
+
+
+def _block_forward(view, ops, x, pend, pend_scale, B, L, keep, causal, meta, s_attn):
+    """x (M, D) fp32 stream (or, with pend = previous branch output f and its per-sample factors, the stream before that add).
+    -> (x1, f, saved)"""
     M, D = x.shape
     H = view.heads
     F_ = view.pairs[2][0].shape[0]
@@ -136,11 +149,11 @@ def _block_forward(view, ops, x, pend, B, L, keep, causal, meta):
         xin = x
         a, mean1, rstd1 = K.ln_fwd(x, ln1.weight, ln1.bias, ln1.eps)
     else:
-        xin, a, mean1, rstd1 = K.add_ln_fwd(x, pend, None, L, ln1.weight, ln1.bias, ln1.eps)
+        xin, a, mean1, rstd1 = K.add_ln_fwd(x, pend, pend_scale, L, ln1.weight, ln1.bias, ln1.eps)
     qkv = K.linear_fwd(a, wqkv, bqkv, 3 * D, D)
     o, lse, sv = irpe_fused.fwd_core(qkv.view(B, L, 3, H, 64), view.scale, terms, drop_p, seed, causal)
     p = K.linear_fwd(o.view(M, D), wo, bo, D, D)
-    x1, c, mean2, rstd2 = K.add_ln_fwd(xin, p, None, L, ln2.weight, ln2.bias, ln2.eps)
+    x1, c, mean2, rstd2 = K.add_ln_fwd(xin, p, s_attn, L, ln2.weight, ln2.bias, ln2.eps)
     gp, g = K.linear_gelu_fwd(c, w1, b1, F_, D, want_grad=keep)      # (the frozen teacher writes no gelu')
     f = K.linear_fwd(g, w2, b2, D, F_)
     saved = (xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g, sv if sv is not None else lse) if keep else None
@@ -151,7 +164,7 @@ def _add_grad(param, g):
     param.grad = g if param.grad is None else param.grad + g
 
 
-def _block_backward(blk, view, ops, saved, dx2, df, pb2, B, L, want_prev, causal, meta):
+def _block_backward(blk, view, ops, saved, dx2, df, pb2, B, L, want_prev, causal, meta, s_attn, s_prev):
     """dx2 (M, D) fp32 gradient of the block's output stream, df (M, D) bf16 = gradient of the c_proj output with its
     per-slab column sums pb2 = (tensor, nparts, pstride, offset).  -> (dx, df_prev, pb2_prev)"""
     xin, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, c, gp, g, sv = saved
@@ -171,7 +184,7 @@ def _block_backward(blk, view, ops, saved, dx2, df, pb2, B, L, want_prev, causal
     jobs.add(W1, pw1, pw1.shape[0], F_ * D, F_, D)
     jobs.add(B1, pb1, pb1.shape[0], F_, 1, F_)
     dc = K.linear_dgrad(dh, w1_t, F_, D)
-    dx1, dp, pl2 = K.ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight, dx2, None, L, True)
+    dx1, dp, pl2 = K.ln_bwd_raw(dc, x1, mean2, rstd2, ln2.weight, dx2, s_attn, L, True)
     P = pl2.shape[0]
     jobs.add(ln2.weight, pl2, P, 3 * D, 1, D)
     jobs.add(ln2.bias, pl2, P, 3 * D, 1, D, src_offset=D)
@@ -188,7 +201,7 @@ def _block_backward(blk, view, ops, saved, dx2, df, pb2, B, L, want_prev, causal
     jobs.add(Wqkv, pwq, pwq.shape[0], 3 * D * D, 3 * D, D)
     jobs.add(Bqkv, pbq, pbq.shape[0], 3 * D, 1, 3 * D)
     da = K.linear_dgrad(dqkv2d, wqkv_t, 3 * D, D)
-    dx, df_prev, pl1 = K.ln_bwd_raw(da, xin, mean1, rstd1, ln1.weight, dx1, None, L, want_prev)
+    dx, df_prev, pl1 = K.ln_bwd_raw(da, xin, mean1, rstd1, ln1.weight, dx1, s_prev, L, want_prev)
     jobs.add(ln1.weight, pl1, P, 3 * D, 1, D)
     jobs.add(ln1.bias, pl1, P, 3 * D, 1, D, src_offset=D)
     K.finalize_on_side_stream(jobs, blk, [df, g, pw2, pb2[0], dh, c, pw1, pb1, pl2, dp, o, pwp, dqkv, a, pwq, pbq, pl1])
@@ -206,17 +219,20 @@ class TowerStack(torch.autograd.Function):
         views = [view_of(blk) for blk in blks]
         keep = any(ctx.needs_input_grad)            # (False under no_grad: the frozen teacher saves nothing)
         cur = x.reshape(M, D).float().contiguous()
-        pend = None
-        saved, metas = [], []
+        pend = pend_scale = None
+        saved, metas, scales = [], [], []
         for blk, view in zip(blks, views):
             meta = _attn_meta(view, L, x.device, blk.training)
-            x1, f, sv = _block_forward(view, operands(blk, view), cur, pend, B, L, keep, causal, meta)
+            s_attn, s_mlp = _path_scales(view, B, x.device, blk.training)
+            x1, f, sv = _block_forward(view, operands(blk, view), cur, pend, pend_scale, B, L, keep, causal, meta, s_attn)
             if keep:
                 saved.extend(sv)
             metas.append(meta)
-            cur, pend = x1, f
-        out = K.residual_add(cur, pend, None, L * D)
+            scales.append((s_attn, s_mlp))
+            cur, pend, pend_scale = x1, f, s_mlp
+        out = K.residual_add(cur, pend, pend_scale, L * D)
         ctx.blks, ctx.views, ctx.metas, ctx.dims, ctx.nsaved = blks, views, metas, (B, L, D), (len(saved) // len(blks) if keep else 0)
+        ctx.scales = scales
         ctx.in_dtype, ctx.causal = x.dtype, causal
         if keep:
             ctx.save_for_backward(*saved)
@@ -228,13 +244,13 @@ class TowerStack(torch.autograd.Function):
         tens = ctx.saved_tensors
         M = B * L
         dx = dout.reshape(M, D).float().contiguous()
-        df, part = K.scale_cast_colsum(dx, None, L)
+        df, part = K.scale_cast_colsum(dx, ctx.scales[-1][1], L)
         pb2 = (part, part.shape[0], D, 0)
         for i in range(len(blks) - 1, -1, -1):
             blk = blks[i]
             view = ctx.views[i]
             dx, df, pb2 = _block_backward(blk, view, operands(blk, view), tens[i * ns:(i + 1) * ns], dx, df, pb2, B, L, i > 0, ctx.causal,
-                                          ctx.metas[i])
+                                          ctx.metas[i], ctx.scales[i][0], ctx.scales[i - 1][1] if i > 0 else None)
         K.join_side_stream(dx.device)
         return (dx.view(B, L, D).to(ctx.in_dtype), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 

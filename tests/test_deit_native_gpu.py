@@ -78,6 +78,61 @@ def test_native_block_stack_matches_fp32_blocks(rpe_on, mode, size, shared):
         assert a < max(3e-2, 2 * b), (n, a, b)
 
 
+def test_native_stack_with_stochastic_depth_matches_fp32_blocks_under_the_same_masks():
+    """DropPath (rpe_vision_transformer.py:115-116: x + drop_path(branch(x)); timm's per-sample mask / keep) inside the node: the
+    per-sample factors go through the residual / LayerNorm kernels.  Same factors in an fp32 evaluation of the blocks; a dropped
+    sample's branch must contribute neither to the output nor to any gradient."""
+    from cream_amd import deit_native
+    from cream_amd.rpe_attention import deit_irpe
+    from cream_amd.tinyclip import native
+    torch.manual_seed(11)
+    model = deit_irpe("tiny", rpe_on="k", depth=3, num_classes=10, drop_path_rate=0.3).to(DEV).train()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "lookup_table" in n:
+                p.normal_(0, 0.2)
+    B, L, D = 4, 197, model.embed_dim
+    x = torch.randn(B, L, D, device=DEV)
+    g = torch.randn(B, L, D, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    fixed = []
+    for blk in model.blocks:
+        keep = 1.0 - float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0)
+        fixed.append(tuple(torch.floor(keep + torch.rand(B, device=DEV, generator=gen)) / keep for _ in range(2)))
+    fixed[1] = (torch.tensor([0.0, 1 / 0.85, 0.0, 1 / 0.85], device=DEV), fixed[1][1])          # dropped samples for certain
+    ref_blocks = copy.deepcopy(model.blocks)
+    xr = x.clone().requires_grad_()
+    out = xr
+    for blk, (sa, sm) in zip(ref_blocks, fixed):
+        out = out + sa[:, None, None] * blk.attn(blk.norm1(out))
+        out = out + sm[:, None, None] * blk.mlp(blk.norm2(out))
+    out.backward(g)
+    it = iter(fixed)
+    orig = native._path_scales
+    native._path_scales = lambda view, B_, dev, training: next(it)
+    try:
+        nat_blocks = copy.deepcopy(model.blocks)
+        xn = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert deit_native.supported(nat_blocks, xn)
+            o = deit_native.run(nat_blocks, xn)
+        o.float().backward(g)
+    finally:
+        native._path_scales = orig
+    errs = {"out": _rel(o.float(), out), "dx": _rel(xn.grad, xr.grad)}
+    for (n, p), (_, q) in zip(nat_blocks.named_parameters(), ref_blocks.named_parameters()):
+        errs[n] = _rel(p.grad, q.grad)
+    print("[deit native drop_path]", {k: f"{v:.2e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:5]})
+    assert all(v < 3e-2 for v in errs.values()), errs
+    # the real draw: masks from the device generator, a different one per call
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = deit_native.run(model.blocks, x), deit_native.run(model.blocks, x)
+    assert not torch.equal(a, b)
+    model.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        assert torch.equal(deit_native.run(model.blocks, x), deit_native.run(model.blocks, x))
+
+
 def test_whole_model_takes_the_native_stack_under_autocast():
     """forward_features (rpe_vision_transformer.py:193-199) dispatches to the node; logits against the fp32 model, every gradient set."""
     from cream_amd import timing
@@ -103,13 +158,13 @@ def test_whole_model_takes_the_native_stack_under_autocast():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
-def test_native_stack_is_not_taken_when_a_block_has_stochastic_depth_or_frozen_parameters():
+def test_native_stack_is_not_taken_with_projection_dropout_frozen_parameters_or_the_cross_method():
     from cream_amd import deit_native
     from cream_amd.rpe_attention import deit_irpe
     x = torch.empty(2, 197, 192, device=DEV)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        m = deit_irpe("tiny", rpe_on="k", depth=2, drop_path_rate=0.1).to(DEV)
-        assert not deit_native.supported(m.blocks, x)            # training mode: DropPath is active
+        m = deit_irpe("tiny", rpe_on="k", depth=2, drop_path_rate=0.1, drop_rate=0.1).to(DEV)
+        assert not deit_native.supported(m.blocks, x)            # training mode: projection / MLP dropout is active
         m.eval()
         assert deit_native.supported(m.blocks, x)
         m = deit_irpe("tiny", rpe_on="k", depth=2).to(DEV)
