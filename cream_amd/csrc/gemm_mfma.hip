@@ -208,7 +208,11 @@ int launch_nt(const NtParams& p, hipStream_t st)
         const int npad = (p.N + 255) / 256 * 256;
         // mode 4: the forward products only (bias epilogue: no weight-gradient stream runs beside them), same padding bound
         if ((m8 == 1 || (m8 == 2 && (light || p.K >= 1024)) || (m8 == 3 && light && (npad - p.N) * 8 <= npad) ||
-             (m8 == 4 && EPI == EPI_BIAS && (npad - p.N) * 8 <= npad)) && nt8_fits(p))
+             (m8 == 4 && EPI == EPI_BIAS && (npad - p.N) * 8 <= npad) ||
+             // ... and every epilogue where BOTH the output and the contraction are at least 640 wide — no AutoFormer search space has
+             // such a product (one side is always the embedding width, <= 624); DeiT-base / CLIP ViT-B blocks (768 / 2304 / 3072) are
+             // nothing else: same-call A/B of the native DeiT-base-384 + iRPE step, mode 4 / 1: 36.7 / 35.4 ms (round 6)
+             (m8 == 4 && p.K >= 640 && p.N >= 640)) && nt8_fits(p))
             return launch_nt8<EPI>(p, st);
     }
     {

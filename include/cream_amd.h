@@ -395,7 +395,8 @@ int cream_gemm_nt256(int on);
  * stream continuous over output tiles, barrier-free per-wave epilogue).  0 = never (the kernels above), 1 = wherever its
  * limits allow (31-bit element offsets), 2 = plain and bias products everywhere, the GELU / x gelu' epilogues only on long
  * contractions (K >= 1024); 3 = plain and bias products whose 256-wide column tiles carry at most 1/8 padding; 4 = the forward
- * products (bias epilogue) under the same padding bound — the DEFAULT (no weight-gradient stream runs beside the forward).
+ * products (bias epilogue) under the same padding bound — the DEFAULT (no weight-gradient stream runs beside the forward) —
+ * plus every product whose output AND contraction are at least 640 wide (DeiT-base / CLIP ViT-B blocks; no AutoFormer shape).
  * mode < 0 only queries; returns the previous setting; the initial one comes from CREAM_GEMM_NT8 in the environment.
  * Forward, bias, bias + GELU results are identical to the other kernels'.  cream_linear_dgrad_mul: when this kernel serves it
  * (modes 1 and 2) dy . W is rounded to bf16 before the multiplication by gelu' (as the reference's two operators do); the

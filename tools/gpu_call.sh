@@ -1,2 +1,6 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_deit_native_gpu.py tests/test_tinyclip_model.py tests/test_tinyclip_loss.py -m gpu -x -q -s 2>&1 | grep -E "deit native|passed|failed|Error|error|assert" | cut -c1-500 | tail -14
+timeout 1200 python -m pytest tests/test_block_gpu.py tests/test_deit_native_gpu.py tests/test_tinyclip_model.py -m gpu -x -q 2>&1 | tail -3
+for E in "X=1" "CREAM_GEMM_NT8=1"; do for r in 1 2; do
+    echo "[$E] $(env $E DEIT_ONLY=k1 timeout 200 python tools/bench_deit_irpe.py 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss'])")"
+done; done
+timeout 300 python tools/bench_tinyclip.py 2>/dev/null | cut -c1-200
