@@ -66,12 +66,20 @@ def enable_irpe_fast_path(caller):
     fused kernels of csrc/irpe_attn.hip (`cream_irpe_attn_fwd / _bwd`) when the layer is covered — CUDA, bf16
     operands, head_dim 64, contextual rpe modules built from the drop-in `irpe` (<= 64 buckets) — and otherwise
     computes exactly what the reference's forward computes, on the drop-in `rpe_index` operator."""
-    from cream_amd.rpe_attention import RPEAttention as ours
+    from cream_amd.rpe_attention import RPEAttention as ours, VisionTransformer as ours_model
     cls = caller.RPEAttention
     if not getattr(cls, "_cream_fast_path", False):
         cls._cream_reference_forward = cls.forward
         cls.forward = ours.forward
         cls._cream_fast_path = True
+    # the model's block loop (rpe_vision_transformer.py:183-196): under bf16 autocast the whole run of RPEBlocks becomes one node on
+    # the own kernels (cream_amd/deit_native.py: same attribute names — norm1 / attn.qkv / attn.proj / norm2 / mlp.fc1 / mlp.fc2 /
+    # drop_path); everything that node does not cover runs the caller's own blocks one by one, as before
+    model = getattr(caller, "VisionTransformer", None)
+    if model is not None and not getattr(model, "_cream_fast_path", False):
+        model._cream_reference_forward_features = model.forward_features
+        model.forward_features = ours_model.forward_features
+        model._cream_fast_path = True
     return caller
 
 

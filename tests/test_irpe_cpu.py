@@ -241,6 +241,15 @@ def test_reference_rpe_attention_through_the_patched_caller():
         y = att(x)
         y.backward(gy)
         assert max_rel(y.detach(), fix["y"]) < 1e-5 and max_rel(x.grad, fix["dx"]) < 1e-5
+        # the model's block loop is patched as well (on the device under bf16 autocast: one node for all RPEBlocks,
+        # cream_amd/deit_native.py); where that node does not apply — here — it is the caller's own loop
+        assert caller.VisionTransformer._cream_fast_path
+        cfg_k = irpe.get_rpe_config(ratio=1.9, method="product", mode="ctx", shared_head=True, skip=1, rpe_on="k")
+        model = caller.VisionTransformer(img_size=64, patch_size=16, embed_dim=192, depth=2, num_heads=3, num_classes=10, qkv_bias=True,
+                                         rpe_config=cfg_k)
+        img = torch.randn(2, 3, 64, 64, generator=g)
+        with torch.no_grad():
+            assert torch.equal(model.forward_features(img), model._cream_reference_forward_features(img))
     finally:
         if refshim.IRPE in sys.path:
             sys.path.remove(refshim.IRPE)
