@@ -71,7 +71,8 @@ CASES = [("k", True, 50, "product"), ("k", False, 197, "product"), ("q", True, 5
          ("qkv", False, 577, "product", "bias"),                                                # bias q / k + contextual v
          # more than 51 buckets: the kernels' wide row pitches (csrc/irpe_attn.hip `Pitch`; everything above takes the narrow ones)
          ("qkv", True, 197, "euc", "ctx", 15.5), ("kv", False, 577, "quant", "ctx", 14.0), ("qk", False, 197, "euc", "bias", 13.0),
-         ("qkv", True, 196, "euc", "ctx", 12.8)]                                                # 51 buckets: the narrow pitches' limit
+         ("qkv", True, 196, "euc", "ctx", 12.8),                                                # 51 buckets: the narrow pitches' limit
+         ("qkv", True, 1025, "product"), ("kv", True, 2026, "euc", "ctx", 14.0)]                # long sequences (32 x 32 / 45 x 45 grids)
 
 
 def _table(m):

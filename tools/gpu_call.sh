@@ -1,6 +1,10 @@
 #!/bin/bash
-timeout 1200 python -m pytest tests/test_block_gpu.py tests/test_deit_native_gpu.py tests/test_tinyclip_model.py -m gpu -x -q 2>&1 | tail -3
-for E in "X=1" "CREAM_GEMM_NT8=1"; do for r in 1 2; do
-    echo "[$E] $(env $E DEIT_ONLY=k1 timeout 200 python tools/bench_deit_irpe.py 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss'])")"
-done; done
-timeout 300 python tools/bench_tinyclip.py 2>/dev/null | cut -c1-200
+# one visit: the fused iRPE attention at long sequences (L = 1025, 2026: beyond what the suite covers)
+cd tests && PYTHONPATH=.. timeout 600 python - <<'PY'
+import torch, test_irpe_fused_gpu as T
+for case in [("qkv", True, 1025, "product"), ("k", False, 1025, "product"), ("qkv", True, 2026, "product"), ("kv", True, 2026, "euc", "ctx", 14.0), ("qk", False, 1025, "quant", "bias")]:
+    try:
+        T.test_fused_irpe_attention_matches_restatement(case); print("ok", case)
+    except Exception as e:
+        print("FAIL", case, repr(e)[:300])
+PY
