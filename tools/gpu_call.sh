@@ -1,10 +1,5 @@
 #!/bin/bash
-# one visit: the fused iRPE attention at long sequences (L = 1025, 2026: beyond what the suite covers)
-cd tests && PYTHONPATH=.. timeout 600 python - <<'PY'
-import torch, test_irpe_fused_gpu as T
-for case in [("qkv", True, 1025, "product"), ("k", False, 1025, "product"), ("qkv", True, 2026, "product"), ("kv", True, 2026, "euc", "ctx", 14.0), ("qk", False, 1025, "quant", "bias")]:
-    try:
-        T.test_fused_irpe_attention_matches_restatement(case); print("ok", case)
-    except Exception as e:
-        print("FAIL", case, repr(e)[:300])
-PY
+# same-call A/B of the NT kernel policy on the TinyCLIP config-5 leg (student width 512, teacher 768)
+for E in "X=1" "CREAM_GEMM_NT8=1" "CREAM_GEMM_NT8=2" "CREAM_GEMM_NT256=1"; do for r in 1 2; do
+  echo "[$E] $(env $E timeout 300 python tools/bench_tinyclip.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss'])")"
+done; done
