@@ -24,7 +24,7 @@ for rpe_on in ("k", "qkv"):
             continue
         os.environ["CREAM_IRPE_FUSED"], os.environ["CREAM_DEIT_NATIVE"] = fused, native
         torch.manual_seed(0)
-        model = deit_irpe("base", img_size=384, rpe_on=rpe_on).to(dev)
+        model = deit_irpe("base", img_size=384, rpe_on=rpe_on, drop_path_rate=float(os.environ.get("DEIT_DROP_PATH", "0"))).to(dev)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
         x = torch.randn(B, 3, 384, 384, device=dev)
         y = torch.randint(0, 1000, (B,), device=dev)
@@ -49,7 +49,7 @@ for rpe_on in ("k", "qkv"):
         print(json.dumps({"workload": f"DeiT-base-384 + iRPE product-ctx rpe_on={rpe_on}, train step, bf16 autocast", "batch": B, "L": 577,
                           "blocks": ("own kernels end to end (cream_amd/deit_native.py)" if native == "1" else "framework linears / LayerNorm / GELU"),
                           "attention": "fused (csrc/irpe_attn.hip)" if fused == "1" else "composed (rpe_index gather / scatter-add, (B,H,L,L) tensors)",
-                          "ms_per_step": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1), "loss": round(float(loss), 4),
+                          "drop_path": float(os.environ.get("DEIT_DROP_PATH", "0")), "ms_per_step": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1), "loss": round(float(loss), 4),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
         del model, opt
         torch.cuda.empty_cache()

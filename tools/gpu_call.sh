@@ -1,5 +1,3 @@
 #!/bin/bash
-# same-call A/B of the NT kernel policy on the TinyCLIP config-5 leg (student width 512, teacher 768)
-for E in "X=1" "CREAM_GEMM_NT8=1" "CREAM_GEMM_NT8=2" "CREAM_GEMM_NT256=1"; do for r in 1 2; do
-  echo "[$E] $(env $E timeout 300 python tools/bench_tinyclip.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss'])")"
-done; done
+# config 4 as a whole model with DeiT's stochastic depth (drop_path 0.1): own kernels against framework blocks
+for N in k1 k0; do DEIT_DROP_PATH=0.1 DEIT_ONLY=$N timeout 300 python tools/bench_deit_irpe.py 2>/dev/null | grep "^{" | cut -c60-460; done | tee gpurun_out/r06w_deit_drop_path.txt
