@@ -32,7 +32,9 @@ Extra objects on the line:
                   the reference's own pure-PyTorch formulation (oracle/irpe_oracle.py: flat-index gather, irpe.py:646).
   tinyclip_config5 — BASELINE config 5's distillation step on one device (student ViT-39M/16 + Text-19M, teacher ViT-B/16);
   irpe_config4  — BASELINE config 4 on the device: one RPEAttention layer (DeiT-B-384 + iRPE, L = 577) fwd+bwd
-                  through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only).
+                  through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only); `model`: the whole
+                  DeiT-base-384 + iRPE training step at batch 64 with the run of RPEBlocks as one node on the own kernels
+                  (cream_amd/deit_native.py; tools/bench_deit_irpe.py measures the framework / composed variants beside it).
 `--subnet T|S` benchmarks ONE fixed published sub-network instead of random sampling (BASELINE
 config 2: AutoFormer-T subnet, bf16, batch 128).
 """
