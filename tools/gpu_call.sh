@@ -1,3 +1,5 @@
 #!/bin/bash
-# config 4 as a whole model with DeiT's stochastic depth (drop_path 0.1): own kernels against framework blocks
-for N in k1 k0; do DEIT_DROP_PATH=0.1 DEIT_ONLY=$N timeout 300 python tools/bench_deit_irpe.py 2>/dev/null | grep "^{" | cut -c60-460; done | tee gpurun_out/r06w_deit_drop_path.txt
+# one visit: the whole GPU suite, smoke and the bench line (the short form of tools/gpu_round.sh)
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+CREAM_BENCH_EXTRA=gpurun_out/call_bench_extra.json timeout 600 python bench.py > gpurun_out/call_bench.json 2> gpurun_out/call_bench.err; cut -c1-400 gpurun_out/call_bench.json
