@@ -63,6 +63,11 @@ SIGNATURES = {
     "cream_attn_rpe2d_bwd_img": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                       _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cream_attn_rpe2d_fwd_drop": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp,
+                                       _i, _i, _i, _i, _i, _i, _f, _f, _c.c_uint32, _i, _vp]),
+    "cream_attn_rpe2d_bwd_drop": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                       _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _c.c_uint32, _i, _vp]),
     "cream_attn_rpe2d_table_image_bytes": (_i64, []),
     "cream_attn_rpe2d_table_images": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cream_attn_rpe2d_fwd_mode": (_i, [_i]),

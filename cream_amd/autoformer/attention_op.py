@@ -112,7 +112,7 @@ def attention_rpe2d(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p=0.0, impl=
         from . import fused_attention
         qkv_f, tabs = _fused_operands(qkv, (tkv, tkh, tvv, tvh))
         if impl == 'fused' or fused_attention.supported(qkv_f, dropout_p, max_relative_position, tabs):
-            return fused_attention.attention_rpe2d_fused(qkv_f, *tabs, scale, max_relative_position)
+            return fused_attention.attention_rpe2d_fused(qkv_f, *tabs, scale, max_relative_position, dropout_p=dropout_p)
     elif impl == 'fused':
         raise RuntimeError("cream_amd: the fused attention kernels need device tensors")
     return _bucketed(qkv, tkv, tkh, tvv, tvh, iv, ih, scale, dropout_p)

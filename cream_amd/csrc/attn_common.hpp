@@ -330,4 +330,26 @@ __device__ __forceinline__ void slots_to_buckets14(float (&bk)[32], float* scr, 
     wave_lds_fence();                  // the row is reused by the caller
 }
 
+// ---- attention dropout: counter-based keep mask -----------------------------------------------------------------------
+// P[i,j] -> keep[i,j] P[i,j] / (1 - p) AFTER the softmax normalisation (multihead_super.py:145, rpe_vision_transformer.py:86
+// `attn = self.attn_drop(attn)`).  keep is a pure function of (seed, b * H + h, i, j) — a 32-bit avalanche mix (two
+// multiply-xorshift rounds) of a per-(b, h) key and the pair (query i, key j) — so that the backward launches regenerate it
+// instead of reading a mask from memory.  Shared by the AutoFormer kernels (attn_rpe2d.hip) and the iRPE kernels
+// (irpe_attn.hip); cream_amd/irpe_fused.py `dropout_keep_mask` restates it in numpy for the tests.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_key(uint32_t seed, int bh) { return mix32(seed ^ ((uint32_t)(bh + 1) * 0x9E3779B9u)); }
+__device__ __forceinline__ bool drop_keep(uint32_t key, int i, int j, uint32_t thr) {
+    return mix32(key ^ (((uint32_t)i << 16) | (uint32_t)j)) >= thr;
+}
+// keep iff hash >= thr = round(p 2^32) clamped to [1, 2^32 - 1]; 0 means "no dropout"
+inline uint32_t drop_threshold(float p) {
+    const double thr = (double)p * 4294967296.0;
+    return p > 0.f ? (uint32_t)(thr < 1.0 ? 1.0 : (thr > 4294967295.0 ? 4294967295.0 : thr)) : 0u;
+}
+
 }  // namespace cream

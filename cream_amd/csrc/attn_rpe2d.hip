@@ -70,6 +70,9 @@ struct FwdArgs {
     float scale;
     int nitems;                                      // B * H (forward: persistent workgroups walk them)
     const void* timg;                                // bf16 operand images of the four tables (cream_attn_rpe2d_table_images) or NULL
+    // attention dropout (multihead_super.py:145), DROP instantiations of the tile-streamed kernels only (attn_common.hpp: drop_keep)
+    uint32_t drop_thr = 0, drop_seed = 0;            // keep iff hash >= drop_thr; 0: no dropout
+    float drop_scale = 1.f;                          // 1 / (1 - p)
 };
 
 struct BwdArgs {
@@ -92,6 +95,8 @@ struct BwdArgs {
     int nitems;                                      // B * H (dQ kernel: persistent workgroups walk them)
     int stagger;                                     // one-pass kernel: start offset between the 8 phase groups (x 64 cycles)
     const void* timg;                                // bf16 operand images of the four tables or NULL (then built into dlt)
+    uint32_t drop_thr = 0, drop_seed = 0;            // as in FwdArgs: the two-launch backward regenerates the forward's mask
+    float drop_scale = 1.f;
 };
 
 // ---- pieces shared by forward and backward ---------------------------------------------
@@ -486,7 +491,7 @@ template <typename T> size_t fwd_lds_bytes(int NP, int waves, bool fast) {
 
 // FAST: the AutoFormer geometry (14 x 14 grid, max_relative_position 14, bf16): compile-time
 // shapes, window-read shifts and one-hot operands staged in LDS (see attn_common.hpp)
-template <typename T, int NT, bool FAST>
+template <typename T, int NT, bool FAST, bool DROP = false>
 __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(const FwdArgs a) {
     using TT = Tr<T>;
     using E = typename TT::elem;
@@ -653,6 +658,16 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     const float inv_l = 1.f / l;
     if (active && qok && g == 0)
         a.lse[((int64_t)b * a.H + h) * N + qi] = (msc + log2f(l)) * (1.f / LOG2E);
+    if constexpr (DROP) {                          // the normaliser above is the undropped sum; V product and slot sums take the dropped map
+        const uint32_t dkey = drop_key(a.drop_seed, item);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s[t][r] = drop_keep(dkey, qi, t * 32 + acc_row(r, g), a.drop_thr) ? s[t][r] * a.drop_scale : 0.f;
+            }
+    }
     PROF_MARK();
 
     // ---- [O | slot sums]^T = [V | one-hot]^T . P^T   (V^T streamed) -------------------------
@@ -890,11 +905,11 @@ int fwd_persistent_grid() { return cream::cu_count(); }
 
 bool fast_geometry(const RelGeom& G) { return G.n == 197 && G.gh == G14 && G.gw == G14 && G.mr == G14; }
 
-template <typename T, int NT, bool FAST = false>
+template <typename T, int NT, bool FAST = false, bool DROP = false>
 int launch_fwd_nt(const FwdArgs& a, int B, hipStream_t st) {
     const int waves = a.NP / 32 < 4 ? 4 : a.NP / 32;
     const size_t lds = fwd_lds_bytes<T>(a.NP, waves, FAST);
-    auto kern = attn_rpe2d_fwd_kernel<T, NT, FAST>;
+    auto kern = attn_rpe2d_fwd_kernel<T, NT, FAST, DROP>;
     if (!cream::raise_dynamic_lds(kern, (int)(160 * 1024))) return CREAM_ERR_LAUNCH;
     FwdArgs aa = a;
     aa.nitems = B * a.H;
@@ -942,6 +957,12 @@ int launch_fwd14(const FwdArgs& a, int B, hipStream_t st) {
 template <typename T>
 int launch_fwd(const FwdArgs& a, int B, hipStream_t st) {
     const int nt = a.NP / 32;
+    if (a.drop_thr) {        // attention dropout: the tile-streamed kernel for every geometry (the score row block is in registers when the mask applies)
+        if (nt <= 2) return launch_fwd_nt<T, 2, false, true>(a, B, st);
+        if (nt <= 4) return launch_fwd_nt<T, 4, false, true>(a, B, st);
+        if (nt <= 7) return launch_fwd_nt<T, 7, false, true>(a, B, st);
+        return launch_fwd_nt<T, 8, false, true>(a, B, st);
+    }
     if (nt <= 2) return launch_fwd_nt<T, 2>(a, B, st);
     if (nt <= 4) return launch_fwd_nt<T, 4>(a, B, st);
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
@@ -975,7 +996,7 @@ template <typename T> size_t bwd_q_lds_bytes(int NP, int waves, bool fast) {
            (size_t)NP * 4 + (size_t)waves * 32 * LP * 4 + (fast ? onehot_bytes(NP) : 0);
 }
 
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool DROP = false>
 __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) {
     using TT = Tr<T>;
     using E = typename TT::elem;
@@ -1125,6 +1146,8 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_q_kernel(const BwdArgs a) 
             for (int r = 0; r < 16; ++r) {
                 const bool ok = t * 32 + acc_row(r, g) < N;
                 const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m2)) : 0.f;
+                if constexpr (DROP)                   // dP = keep / (1 - p) o (dO Vx^T): the mask sits on dP, P stays undropped
+                    pacc[r] = drop_keep(drop_key(a.drop_seed, item), qi, t * 32 + acc_row(r, g), a.drop_thr) ? pacc[r] * a.drop_scale : 0.f;
                 sacc[r] = p * (pacc[r] - delta) * a.scale;
             }
             const E* ktb = ktbuf(cur);
@@ -1167,7 +1190,7 @@ template <typename T> __host__ __device__ constexpr size_t kv_set_bytes() {
 }
 template <typename T> size_t bwd_kv_lds_bytes(int NP) { return 2 * kv_set_bytes<T>() + (size_t)NP * 8; }
 
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a) {
     using TT = Tr<T>;
     using E = typename TT::elem;
@@ -1350,8 +1373,14 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * r4 + e;
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -l4[e]));
+                    if constexpr (DROP) {                                         // dV takes the dropped map, dS the mask on dP
+                        const bool keep = drop_keep(drop_key(a.drop_seed, item), t * 32 + 8 * r4 + 4 * g + e, kj, a.drop_thr);
+                        sacc[r] = keep ? p * a.drop_scale : 0.f;
+                        pacc[r] = p * __builtin_fmaf(keep ? pacc[r] * a.drop_scale : 0.f, a.scale, -d4[e]);
+                    } else {
                     sacc[r] = p;
                     pacc[r] = p * __builtin_fmaf(pacc[r], a.scale, -d4[e]);      // dlt_s holds scale * delta
+                    }
                 }
             }
             PROF_LOOP(t);
@@ -1422,10 +1451,10 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     }
 }
 
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool DROP = false>
 int launch_bwd_impl(const BwdArgs& a, int B, hipStream_t st) {
-    auto kq = attn_rpe2d_bwd_q_kernel<T, FAST>;
-    auto kkv = attn_rpe2d_bwd_kv_kernel<T>;
+    auto kq = attn_rpe2d_bwd_q_kernel<T, FAST, DROP>;
+    auto kkv = attn_rpe2d_bwd_kv_kernel<T, DROP>;
     if (!cream::raise_dynamic_lds(kq, 160 * 1024) || !cream::raise_dynamic_lds(kkv, 160 * 1024)) return CREAM_ERR_LAUNCH;
     BwdArgs aa = a;
     aa.nitems = B * a.H;
@@ -1483,6 +1512,7 @@ int launch_bwd1(const BwdArgs& a, int B, hipStream_t st) {
 
 template <typename T>
 int launch_bwd(const BwdArgs& a, int B, hipStream_t st) {
+    if (a.drop_thr) return launch_bwd_impl<T, false, true>(a, B, st);       // attention dropout: the two-launch backward regenerates the mask
     if constexpr (sizeof(typename Tr<T>::elem) == 2) {
         if (fast_geometry(a.G)) {
             if (bwd_onepass_mode() && (size_t)B * a.H * 64 * a.NP >= (size_t)v2::IMG_ELEMS) return launch_bwd1(a, B, st);
@@ -1549,7 +1579,17 @@ int cream_attn_rpe2d_fwd_img(void* out, float* lse, void* sp, const void* q, con
                              const float* tvv, const float* tvh, int ldt, const void* timg, int B, int H, int N, int gh, int gw,
                              int mr, float scale, int dtype, void* stream)
 {
+    return cream_attn_rpe2d_fwd_drop(out, lse, sp, q, k, v, sb, sn, sh, tkv, tkh, tvv, tvh, ldt, timg, B, H, N, gh, gw, mr, scale,
+                                     0.f, 0u, dtype, stream);
+}
+
+int cream_attn_rpe2d_fwd_drop(void* out, float* lse, void* sp, const void* q, const void* k, const void* v,
+                              int64_t sb, int64_t sn, int64_t sh, const float* tkv, const float* tkh,
+                              const float* tvv, const float* tvh, int ldt, const void* timg, int B, int H, int N, int gh, int gw,
+                              int mr, float scale, float dropout_p, uint32_t dropout_seed, int dtype, void* stream)
+{
     if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
+    if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CREAM_ERR_BAD_ARG;
     if (B == 0 || H == 0) return CREAM_OK;
     if (!out || !lse || !q || !k || !v || !tkv || !tkh || !tvv || !tvh) return CREAM_ERR_BAD_ARG;     // (sp == NULL: forward only)
     if (!geom_ok(N, gh, gw, mr, 2 * mr + 2)) return CREAM_ERR_TOO_LARGE;
@@ -1567,6 +1607,9 @@ int cream_attn_rpe2d_fwd_img(void* out, float* lse, void* sp, const void* q, con
     a.H = H; a.NP = cream_attn_rpe2d_padded_len(N);
     a.G = RelGeom{N, gh, gw, mr};
     a.scale = scale;
+    a.drop_thr = drop_threshold(dropout_p);
+    a.drop_seed = dropout_seed;
+    a.drop_scale = 1.f / (1.f - dropout_p);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case CREAM_BF16: return launch_fwd<hip_bfloat16>(a, B, st);
@@ -1593,7 +1636,20 @@ int cream_attn_rpe2d_bwd_img(void* dq, void* dk, void* dv, int64_t dsb, int64_t 
                              const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt, const void* timg,
                              int B, int H, int N, int gh, int gw, int mr, float scale, int dtype, void* stream)
 {
+    return cream_attn_rpe2d_bwd_drop(dq, dk, dv, dsb, dsn, dsh, dtab, dlt, qe, de, delta, dout, out, lse, sp, q, k, v, sb, sn, sh, tkv,
+                                     tkh, tvv, tvh, ldt, timg, B, H, N, gh, gw, mr, scale, 0.f, 0u, dtype, stream);
+}
+
+int cream_attn_rpe2d_bwd_drop(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh, float* dtab,
+                              void* dlt, void* qe, void* de, float* delta,
+                              const void* dout, const void* out, const float* lse, const void* sp,
+                              const void* q, const void* k, const void* v, int64_t sb, int64_t sn, int64_t sh,
+                              const float* tkv, const float* tkh, const float* tvv, const float* tvh, int ldt, const void* timg,
+                              int B, int H, int N, int gh, int gw, int mr, float scale, float dropout_p, uint32_t dropout_seed,
+                              int dtype, void* stream)
+{
     if (B < 0 || H < 0) return CREAM_ERR_BAD_ARG;
+    if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CREAM_ERR_BAD_ARG;
     if (B == 0 || H == 0) return CREAM_OK;
     if (!dq || !dk || !dv || !dtab || !dlt || !qe || !de || !delta || !dout || !out || !lse || !sp || !q || !k ||
         !v || !tkv || !tkh || !tvv || !tvh)
@@ -1618,6 +1674,9 @@ int cream_attn_rpe2d_bwd_img(void* dq, void* dk, void* dv, int64_t dsb, int64_t 
     a.H = H; a.NP = cream_attn_rpe2d_padded_len(N);
     a.G = RelGeom{N, gh, gw, mr};
     a.scale = scale;
+    a.drop_thr = drop_threshold(dropout_p);
+    a.drop_seed = dropout_seed;
+    a.drop_scale = 1.f / (1.f - dropout_p);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case CREAM_BF16: return launch_bwd<hip_bfloat16>(a, B, st);

@@ -114,18 +114,7 @@ struct Args {
     short *dlk, *dlq;                 // (B, H, NP, 64) bucket gradients (-> table gradients)
 };
 
-// counter-based keep mask: a 32-bit avalanche mix (two multiply-xorshift rounds) of a per-(b,h) key and the pair (i, j).
-// cream_amd/irpe_fused.py `dropout_keep_mask` restates it in numpy for the tests.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du;
-    x ^= x >> 15; x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ uint32_t drop_key(uint32_t seed, int bh) { return mix32(seed ^ ((uint32_t)(bh + 1) * 0x9E3779B9u)); }
-__device__ __forceinline__ bool drop_keep(uint32_t key, int i, int j, uint32_t thr) {
-    return mix32(key ^ (((uint32_t)i << 16) | (uint32_t)j)) >= thr;
-}
+// (keep mask: mix32 / drop_key / drop_keep in attn_common.hpp)
 
 // consecutive logical workgroups (the blocks of one (b,h), which share the streamed side) on one XCD
 __device__ __forceinline__ int xcd_order(int bid, int n) {
@@ -1116,8 +1105,7 @@ Args to_args(const cream_irpe_attn_desc* d) {
     a.idq = d->idq; a.idk = d->idk; a.idv = d->idv;
     a.idq_t = d->idq_t; a.idk_t = d->idk_t; a.idv_t = d->idv_t;
     a.B = d->B; a.H = d->H; a.L = d->L; a.NP = d->NP; a.nb = d->nb; a.scale = d->scale; a.causal = d->causal;
-    const double thr = (double)d->dropout_p * 4294967296.0;
-    a.drop_thr = d->dropout_p > 0.f ? (uint32_t)(thr < 1.0 ? 1.0 : (thr > 4294967295.0 ? 4294967295.0 : thr)) : 0u;
+    a.drop_thr = drop_threshold(d->dropout_p);
     a.drop_seed = d->dropout_seed;
     a.drop_scale = 1.f / (1.f - d->dropout_p);
     a.dout = (const short*)d->dout;

@@ -103,7 +103,7 @@ int cream_attn_rpe2d_bwd_mode(int onepass);
  * (AutoFormer/model/module/multihead_super.py:135-154) with the relative position
  * embeddings of RelativePosition2D_super.forward (multihead_super.py:40-66) folded in:
  *     A[i,j] = scale * ( q_i.k_j + q_i.(Tkv[iv[i,j]] + Tkh[ih[i,j]]) )
- *     P = softmax_j(A)          (attention dropout must be 0 — the supernet recipe's value)
+ *     P = softmax_j(A)          (attention dropout 0 — the supernet recipe's value; cream_attn_rpe2d_fwd_drop below takes p > 0)
  *     O_i = sum_j P[i,j] * ( v_j + Tvv[iv[i,j]] + Tvh[ih[i,j]] )
  * for every (b, h); head_dim is 64 (supernet_transformer.py:243).  iv/ih are the
  * reference's index matrices for a gh x gw token grid behind one class token
@@ -182,6 +182,30 @@ int cream_attn_rpe2d_bwd_img(void* dq, void* dk, void* dv, int64_t dsb, int64_t 
                              const float* tkv, const float* tkh, const float* tvv, const float* tvh,
                              int ldt, const void* timg, int B, int H, int N, int gh, int gw, int mr,
                              float scale, int dtype, void* stream);
+
+/* The same two entry points with ATTENTION DROPOUT between the softmax and the two value-side products
+ * (multihead_super.py:145 `attn = self.attn_drop(attn)`): P[i,j] -> keep[i,j] P[i,j] / (1 - dropout_p) for the P.V product and
+ * the value-side bucket sums alike; lse is that of the undropped softmax.  keep is a pure function of (dropout_seed, b * H + h,
+ * i, j) — a 32-bit counter-based mix (csrc/attn_common.hpp drop_keep; cream_amd/irpe_fused.py dropout_keep_mask restates it),
+ * kept iff hash >= round(dropout_p 2^32) — so the backward regenerates the forward's mask from the same (dropout_p,
+ * dropout_seed): no N x N mask exists in memory, and a run is reproducible from its seeds.  0 <= dropout_p < 1
+ * (CREAM_ERR_BAD_ARG otherwise); dropout_p == 0 IS cream_attn_rpe2d_fwd_img / _bwd_img.  With dropout_p > 0 every geometry and
+ * dtype runs the tile-streamed forward and the two-launch backward (whose score tiles are in registers where the mask applies);
+ * timg is not used then. */
+int cream_attn_rpe2d_fwd_drop(void* out, float* lse, void* sp,
+                              const void* q, const void* k, const void* v,
+                              int64_t sb, int64_t sn, int64_t sh,
+                              const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                              int ldt, const void* timg, int B, int H, int N, int gh, int gw, int mr,
+                              float scale, float dropout_p, uint32_t dropout_seed, int dtype, void* stream);
+int cream_attn_rpe2d_bwd_drop(void* dq, void* dk, void* dv, int64_t dsb, int64_t dsn, int64_t dsh,
+                              float* dtab, void* dlt, void* qe, void* de, float* delta,
+                              const void* dout, const void* out, const float* lse, const void* sp,
+                              const void* q, const void* k, const void* v,
+                              int64_t sb, int64_t sn, int64_t sh,
+                              const float* tkv, const float* tkh, const float* tvv, const float* tvh,
+                              int ldt, const void* timg, int B, int H, int N, int gh, int gw, int mr,
+                              float scale, float dropout_p, uint32_t dropout_seed, int dtype, void* stream);
 
 /* ---- the two ends of the supernet around the block stack (csrc/stem_tail.hip) --------------------
  * Reference: Vision_TransformerSuper.forward_features, AutoFormer/model/supernet_transformer.py:147-172

@@ -80,7 +80,7 @@ def attention(sd, prefix, x, E, H, max_rel=14, change_qkv=True, relative_positio
     return F.linear(out, sd[prefix + 'proj.weight'][:E, :Q], sd[prefix + 'proj.bias'][:E])
 
 
-def attention_core(qkv, tkv, tkh, tvv, tvh, scale, max_rel=14):
+def attention_core(qkv, tkv, tkh, tvv, tvh, scale, max_rel=14, attn_keep=None):
     """The part of model/module/multihead_super.py:135-154 between the qkv and proj GEMMs, in the
     reference's DENSE formulation: qkv (B, N, 3, H, d) -> (B, N, H, d).  (What the fused HIP
     kernels cream_attn_rpe2d_fwd/bwd replace; autograd of this function is their backward oracle.)"""
@@ -91,6 +91,8 @@ def attention_core(qkv, tkv, tkh, tvv, tvh, scale, max_rel=14):
     attn = attn + (q.permute(2, 0, 1, 3).reshape(N, H * B, -1) @ r_p_k.transpose(2, 1)) \
         .transpose(1, 0).reshape(B, H, N, N) * scale                                      # :141-142
     attn = attn.softmax(dim=-1)                                                           # :144
+    if attn_keep is not None:               # :145 `attn = self.attn_drop(attn)` under a GIVEN mask: attn_keep (B, H, N, N) holds
+        attn = attn * attn_keep             # keep / (1 - p) — nn.Dropout's scaling with the random draw taken out
     out = (attn @ v).transpose(1, 2).reshape(B, N, -1)                                    # :147
     r_p_v, _, _ = rel_pos_embeddings(tvv, tvh, N, max_rel)                                # :149
     attn_1 = attn.permute(2, 0, 1, 3).reshape(N, B * H, -1)

@@ -221,3 +221,124 @@ def test_role_split_backward_equals_the_one_pass_kernel(B, H):
     assert torch.isfinite(g2[0]).all() and torch.equal(g2[0], g1[0])
     for i in range(1, len(g1)):
         assert torch.isfinite(g2[i]).all() and _rel(g2[i], g1[i]) < 1e-5, (i, _rel(g2[i], g1[i]))
+
+
+# ---- attention dropout inside the fused kernels (multihead_super.py:145 `attn = self.attn_drop(attn)`) --------------------------
+def _keep(seed, p, B, H, N):
+    """keep / (1 - p) as the kernels regenerate it (numpy restatement of csrc/attn_common.hpp drop_keep)."""
+    from cream_amd import irpe_fused
+    import numpy as np
+    h = irpe_fused.dropout_keep_mask(seed, B, H, N)
+    return torch.from_numpy((h >= np.uint32(irpe_fused.dropout_threshold(p))).astype("float32")) / (1.0 - p)
+
+
+def _oracle_drop(qkv, tabs, go, mr, keep):
+    x = [qkv.clone().requires_grad_()] + [t.clone().requires_grad_() for t in tabs]
+    out = AO.attention_core(x[0], *x[1:], 0.125, mr, attn_keep=keep)
+    out.backward(go)
+    return out.detach(), [t.grad for t in x]
+
+
+def _fused_drop(qkv, tabs, go, mr, dtype, p, seed):
+    from cream_amd.autoformer import fused_attention as FA
+    x = [qkv.to(DEV, dtype).requires_grad_()] + [t.to(DEV).requires_grad_() for t in tabs]
+    out = FA.attention_rpe2d_fused(x[0], *x[1:], 0.125, mr, dropout_p=p, seed=seed)
+    out.backward(go.to(DEV, dtype))
+    return out.detach(), [t.grad for t in x]
+
+
+@pytest.mark.parametrize("B,H,side,mr", CASES)
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_fused_attention_dropout_fp32_matches_oracle_under_the_same_mask(B, H, side, mr, p):
+    """Every geometry of the kernel family with attn_drop > 0: outputs and all five gradients against the dense
+    restatement evaluated under the mask the kernels regenerate from the seed."""
+    qkv, tabs, go = _inputs(B, H, side, mr, seed=5)
+    keep = _keep(1234 + side, p, B, H, side * side + 1)
+    ref_out, ref_g = _oracle_drop(qkv, tabs, go, mr, keep)
+    out, g = _fused_drop(qkv, tabs, go, mr, torch.float32, p, 1234 + side)
+    assert _rel(out, ref_out) < 1e-3
+    for a, b in zip(g, ref_g):
+        assert _rel(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,side,mr", CASES[:4])
+def test_fused_attention_dropout_bf16_documented_tolerance(B, H, side, mr):
+    qkv, tabs, go = _inputs(B, H, side, mr, seed=6)
+    keep = _keep(77, 0.2, B, H, side * side + 1)
+    ref_out, ref_g = _oracle_drop(qkv, tabs, go, mr, keep)
+    out, g = _fused_drop(qkv, tabs, go, mr, torch.bfloat16, 0.2, 77)
+    assert _rel(out, ref_out) < 2e-2
+    for a, b in zip(g, ref_g):
+        assert _rel(a, b) < 3e-2
+
+
+def test_fused_attention_dropout_properties_at_full_size():
+    """B = 128, H = 6, N = 197 in bf16: with V = 1 and zero value tables a row of the output is (kept count) / (1 - p) of
+    softmax mass — its mean over everything is 1 within sampling noise and it is NOT constant; the same seed replays bit
+    for bit (forward and backward), another seed gives another mask; p = 0 through the _drop entry points IS the plain path."""
+    from cream_amd.autoformer import fused_attention as FA
+    B, H, N, mr, p = 128, 6, 197, 14, 0.1
+    g = torch.Generator(device=DEV).manual_seed(8)
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).bfloat16()
+    tabs = [torch.randn(30, 64, device=DEV, generator=g) * 0.5 for _ in range(4)]
+    zero = torch.zeros(30, 64, device=DEV)
+    q1 = qkv.clone()
+    q1[:, :, 2] = 1
+    out = FA.attention_rpe2d_fused(q1, tabs[0], tabs[1], zero, zero, 0.125, mr, dropout_p=p, seed=3).float()
+    assert abs(float(out.mean()) - 1.0) < 5e-3 and float(out.std()) > 1e-2
+    res = []
+    for seed in (11, 11, 12):
+        x = [qkv.clone().requires_grad_()] + [t.clone().requires_grad_() for t in tabs]
+        o = FA.attention_rpe2d_fused(x[0], *x[1:], 0.125, mr, dropout_p=p, seed=seed)
+        o.backward(torch.ones_like(o))
+        res.append([o.detach()] + [t.grad for t in x])
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][0], res[2][0])
+    plain = FA.attention_rpe2d_fused(qkv, *tabs, 0.125, mr)
+    assert torch.equal(FA.attention_rpe2d_fused(qkv, *tabs, 0.125, mr, dropout_p=0.0, seed=5), plain)
+
+
+def test_attention_super_with_attn_drop_takes_the_fused_kernels():
+    """AttentionSuper(attn_drop = 0.1) in training mode: 'auto' now resolves to the fused kernels (the run is replayed by
+    torch.manual_seed), eval mode is the undropped path."""
+    from cream_amd.autoformer import fused_attention as FA
+    from cream_amd.autoformer.modules import AttentionSuper
+    torch.manual_seed(0)
+    m = AttentionSuper(384, num_heads=6, qkv_bias=True, attn_drop=0.1, relative_position=True, change_qkv=True,
+                       max_relative_position=14).to(DEV)
+    m.set_sample_config(sample_q_embed_dim=384, sample_num_heads=6, sample_in_embed_dim=384)
+    x = torch.randn(2, 197, 384, device=DEV)
+    calls = []
+    orig = FA.attention_rpe2d_fused
+    FA.attention_rpe2d_fused = lambda *a, **k: (calls.append(k.get("dropout_p")), orig(*a, **k))[1]
+    try:
+        m.train()
+        torch.manual_seed(1); y1 = m(x)
+        torch.manual_seed(1); y2 = m(x)
+        torch.manual_seed(2); y3 = m(x)
+        m.eval()
+        y4 = m(x)
+    finally:
+        FA.attention_rpe2d_fused = orig
+    assert calls == [0.1, 0.1, 0.1, 0.0]
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1, y4)
+
+
+def test_c_abi_dropout_rejects_bad_rates():
+    import ctypes
+    from cream_amd import _lib
+    lib = _lib.load()
+    q = torch.zeros(1, 5, 3, 1, 64, device=DEV)
+    out = torch.zeros(1, 5, 1, 64, device=DEV)
+    lse = torch.zeros(1, 1, 5, device=DEV)
+    sp = torch.zeros(1, 1, 64, 32, device=DEV)
+    t = torch.zeros(30, 64, device=DEV)
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    args = lambda rate: (p(out), p(lse), p(sp), p(q), p(q), p(q), 960, 192, 64, p(t), p(t), p(t), p(t), 64, None,
+                         1, 1, 5, 2, 2, 14, 0.125, rate, 7, _lib.F32, None)
+    assert lib.cream_attn_rpe2d_fwd_drop(*args(0.25)) == 0
+    assert lib.cream_attn_rpe2d_fwd_drop(*args(1.0)) == -1
+    assert lib.cream_attn_rpe2d_fwd_drop(*args(-0.1)) == -1
+    assert lib.cream_attn_rpe2d_fwd_drop(*args(float("nan"))) == -1
+    torch.cuda.synchronize()
