@@ -555,16 +555,37 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     // loaded into register set u % PF a full PF tile-iterations before it is written to LDS buffer
     // u & 1 (one iteration of ~1.3k cycles is shorter than an HBM round trip under load: with
     // a single tile in flight every iteration ended in a wait for memory)
-    constexpr int PF = sizeof(E) == 2 ? 3 : 1;      // fp32 tiles are twice the registers: one in flight
+    // ONLINE (row blocks of 5+ key tiles): the tiles alternate K_0 V_0 K_1 V_1 ... and the softmax runs online, tile by
+    // tile, against a running maximum — the whole score row block (NT x 16 registers beside 48 of accumulators, the
+    // operand fragments and the tiles in flight) does not fit the 256 registers of a wave at two waves per SIMD: the
+    // exact-softmax form of this kernel kept 690-1050 bytes per lane in scratch at NT = 7 / 8.
+    constexpr bool ONLINE = NT > 4;
+    // (ONLINE: K tiles travel in ring[0], V tiles in ring[1] — static register indices under a loop that is NOT unrolled)
+    constexpr int PF = ONLINE ? 2 : (sizeof(E) == 2 ? 3 : 1);      // exact form in fp32: tiles are twice the registers, one in flight
     TileRegs<T, 32, 64> ring[PF];
     auto issue = [&](int u) {
+        if constexpr (ONLINE) {
+            if (u < 2 * nt) {
+                if (u & 1) tile_load<T, 32, 64>(ring[PF - 1], vpg, a.sn, (u >> 1) * 32, N);
+                else tile_load<T, 32, 64>(ring[0], kpg, a.sn, (u >> 1) * 32, N);
+            }
+        } else {
         if (u < nt) tile_load<T, 32, 64>(ring[u % PF], kpg, a.sn, u * 32, N);
         else if (u < 2 * nt) tile_load<T, 32, 64>(ring[u % PF], vpg, a.sn, (u - nt) * 32, N);
+        }
     };
     auto commit = [&](int u) {
         E* dst = (u & 1) ? buf1 : buf0;
-        if (u < nt) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
-        else if (u < 2 * nt) {
+        const bool is_k = ONLINE ? !(u & 1) : u < nt;
+        if (u >= 2 * nt) return;
+        if constexpr (ONLINE) {
+            if (is_k) tile_store<T, 32, 64, true, false>(ring[0], buf0, kp, nullptr, 0);
+            else if constexpr (sizeof(E) == 2) tile_store<T, 32, 64, true, false>(ring[PF - 1], buf1, kp, nullptr, 0);
+            else tile_store<T, 32, 64, false, true>(ring[PF - 1], nullptr, 0, buf1, vp);
+            return;
+        }
+        if (is_k) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
+        else {
             // V tiles: bf16 keeps them row-major (the P.V product reads them through ds_read_b64_tr_b16)
             if constexpr (sizeof(E) == 2) tile_store<T, 32, 64, true, false>(ring[u % PF], dst, kp, nullptr, 0);
             else tile_store<T, 32, 64, false, true>(ring[u % PF], nullptr, 0, dst, vp);
@@ -593,6 +614,77 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     }
     PROF_MARK();
 
+    f32x16 o[2] = {f32x16{}, f32x16{}};
+    f32x16 ox = {};
+    float inv_l;
+    if constexpr (ONLINE) {
+    // ---- one pass over (K_t, V_t): scores of 32 keys, online softmax, [O | slot sums]^T += [V | one-hot]^T . P^T --------
+    const float sc = a.scale * LOG2E;
+    float m_run = -INFINITY, l = 0.f;                  // running maximum of the raw scores / this lane's half of the running sum
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t)
+        {
+            f32x16 st = {};
+            if (active) {
+#pragma unroll
+                for (int ks = 0; ks < S64; ++ks)
+                    st = TT::mma(TT::load(buf0 + c32 * kp + ks * KI + g * EPL), qb[ks], st);
+                const uint32_t km = masks[t * 32 + c32];
+#pragma unroll
+                for (int ks = 0; ks < S32; ++ks) st = TT::mma(TT::onehot_row(km, ks, g), qe[ks], st);
+            }
+            commit(2 * t + 1);                         // V_t
+            __syncthreads();
+            issue(2 * t + 1 + PF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)               // keys >= N (they exist only in the last tile)
+                if (t * 32 + acc_row(r, g) >= N) st[r] = -INFINITY;
+            float m4[4] = {st[0], st[1], st[2], st[3]};
+#pragma unroll
+            for (int r = 4; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], st[r]);
+            float mt = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run, mt);      // (every tile holds a key < N: finite from the first tile on)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);      // first tile: exp2(-inf) = 0 on zeros
+            const float msc = m_new * sc;
+            m_run = m_new;
+            float l4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -msc));
+                st[r] = p;
+                l4[r & 3] += p;
+            }
+            l = __builtin_fmaf(l, alpha, (l4[0] + l4[1]) + (l4[2] + l4[3]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ox[r] *= alpha; }
+            if constexpr (DROP) {                      // the normaliser is the undropped sum
+                const uint32_t dkey = drop_key(a.drop_seed, item);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[r] = drop_keep(dkey, qi, t * 32 + acc_row(r, g), a.drop_thr) ? st[r] * a.drop_scale : 0.f;
+            }
+            if (active) {
+#pragma unroll
+                for (int st2 = 0; st2 < S32; ++st2) {
+                    const F pb = TT::from_acc(st, st2);
+                    o[0] = TT::mma(perm_operand<T>(buf1, kp, buf1, vp, 0, st2, lane), pb, o[0]);
+                    o[1] = TT::mma(perm_operand<T>(buf1, kp, buf1, vp, 1, st2, lane), pb, o[1]);
+                    ox = TT::mma(TT::onehot_perm(masks + t * 32, st2, g, c32), pb, ox);
+                }
+            }
+            if (t + 1 < nt) {
+                commit(2 * t + 2);                     // K_{t+1}
+                __syncthreads();
+                issue(2 * t + 2 + PF);
+            }
+        }
+    l += __shfl_xor(l, 32);
+    inv_l = 1.f / l;
+    if (active && qok && g == 0)
+        a.lse[((int64_t)b * a.H + h) * N + qi] = (m_run * sc + log2f(l)) * (1.f / LOG2E);
+    PROF_MARK();
+    } else {
     // ---- S^T tiles: scores of all keys against this wave's 32 queries (K streamed) ------
     f32x16 s[NT];
 #pragma unroll
@@ -655,7 +747,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
         }
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
     l += __shfl_xor(l, 32);
-    const float inv_l = 1.f / l;
+    inv_l = 1.f / l;
     if (active && qok && g == 0)
         a.lse[((int64_t)b * a.H + h) * N + qi] = (msc + log2f(l)) * (1.f / LOG2E);
     if constexpr (DROP) {                          // the normaliser above is the undropped sum; V product and slot sums take the dropped map
@@ -671,8 +763,6 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
     PROF_MARK();
 
     // ---- [O | slot sums]^T = [V | one-hot]^T . P^T   (V^T streamed) -------------------------
-    f32x16 o[2] = {f32x16{}, f32x16{}};
-    f32x16 ox = {};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (t < nt) {
@@ -693,6 +783,7 @@ __global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void attn_rpe2d_fwd_kernel(
                 issue(nt + t + 1 + PF);
             }
         }
+    }   // exact softmax over the whole row block (NT <= 4)
     if (active) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; ox[r] *= inv_l; }
