@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(512) void attn_rpe2d_bwd_kv_kernel(const BwdArgs a)
     for (;;) {
     __syncthreads();                                  // previous item done with the staged tiles and lse / delta
     const int b = P.b, h = P.h;
-    const int64_t bh = P.bh;
+    [[maybe_unused]] const int64_t bh = P.bh;
     PROF_DECL
     PROF_MARK();
     if (threadIdx.x < NP) { lse2[threadIdx.x] = lse_r; dlt_s[threadIdx.x] = dlt_r; }
