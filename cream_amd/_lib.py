@@ -106,6 +106,8 @@ SIGNATURES = {
     "cream_block_layout_epoch": (_i, []),
     "cream_cu_reserve": (_i, [_i]),
     "cream_mixup_cutmix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _f, _vp]),
+    "cream_image_batch_plan": (_i64, [_vp, _i, _i, _i]),
+    "cream_image_batch_transform": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     "cream_cu_count": (_i, []),
     "cream_linear_wgrad_parts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "cream_linear_wgrad_parts_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -137,6 +139,14 @@ class GradJob(ctypes.Structure):
     _fields_ = [("dst", _vp), ("src", _vp), ("ld", _i64), ("pstride", _i64),
                 ("nparts", _c.c_int32), ("rows", _c.c_int32), ("cols", _c.c_int32),
                 ("interleave", _c.c_int32), ("src_bf16", _c.c_int32), ("overwrite", _c.c_int32)]
+
+class ImageDesc(ctypes.Structure):
+    """struct cream_image_desc of include/cream_amd.h."""
+    _fields_ = ([("offset", _i64)] +
+                [(n, _c.c_int32) for n in ("height", "width", "row_stride", "box_top", "box_left", "box_h", "box_w", "resized_h",
+                                           "resized_w", "win_top", "win_left", "flip", "row0", "nrows")] +
+                [("tmp_off", _i64)])
+
 
 class SliceJob(ctypes.Structure):
     """struct cream_slice_job of include/cream_amd.h."""

@@ -137,3 +137,119 @@ class Mixup:
             else:
                 x.copy_(x * lam + x.flip(0) * (1.0 - lam))
         return x, self.mix_targets(target, lam)
+
+
+# ---- the uint8 -> normalised float transform of a batch on the device (lib/datasets.py:189-220) ---------------------------------
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)       # timm.data.constants, imported at lib/datasets.py:10
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+def eval_crop_params(height, width, input_size=224):
+    """`Resize(int(256 / 224 * input_size), interpolation=3)` + `CenterCrop(input_size)` (lib/datasets.py:211-216) as
+    (box, resized, window): torchvision's F.resize sends the shorter side to `size` and the other to int(size * long / short);
+    F.center_crop starts at int(round((h - th) / 2.))."""
+    size = int((256 / 224) * input_size)
+    if width <= height:
+        rw, rh = size, int(size * height / width)
+    else:
+        rh, rw = size, int(size * width / height)
+    return (0, 0, height, width), (rh, rw), (int(round((rh - input_size) / 2.)), int(round((rw - input_size) / 2.)))
+
+
+def train_crop_params(height, width, rng, input_size=224, scale=(0.08, 1.0), ratio=(3. / 4., 4. / 3.), hflip=0.5):
+    """The geometric head of timm's training transform (create_transform(is_training=True), lib/datasets.py:193-202):
+    RandomResizedCropAndInterpolation.get_params followed by RandomHorizontalFlip, drawn from `rng` (a `random.Random`) in
+    that order of calls.  timm is third-party and not vendored in the reference: restated from its published definition
+    (ten attempts of area x aspect sampling, then the central crop clamped to the ratio range) — parity unpinned by the
+    reference; the RESAMPLING of the crop is pinned against Pillow.  -> (box, resized, window, flip)."""
+    area = width * height
+    box = None
+    for _ in range(10):
+        target_area = rng.uniform(*scale) * area
+        aspect = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1])))
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if w <= width and h <= height:
+            top = rng.randint(0, height - h)
+            left = rng.randint(0, width - w)
+            box = (top, left, h, w)
+            break
+    if box is None:
+        in_ratio = width / height
+        if in_ratio < min(ratio):
+            w = width
+            h = int(round(w / min(ratio)))
+        elif in_ratio > max(ratio):
+            h = height
+            w = int(round(h * max(ratio)))
+        else:
+            w, h = width, height
+        box = ((height - h) // 2, (width - w) // 2, h, w)
+    flip = rng.random() < hflip
+    return box, (input_size, input_size), (0, 0), flip
+
+
+class DeviceTransform:
+    """A batch of decoded frames (HWC uint8 RGB arrays of any sizes) -> (B, 3, S, S) float32 on the device, as the reference's
+    per-image transforms produce it: F.crop -> Pillow's bicubic F.resize -> window (CenterCrop) -> mirror -> ToTensor -> Normalize,
+    two launches for the whole batch (cream_image_batch_transform; byte-exact with Pillow's resize, bit-exact float ops).
+    The frames travel as ONE packed uint8 buffer (each frame at a 4-byte aligned offset) from pinned memory; RandAugment /
+    RandomErasing of the training recipe stay host-side (out of scope)."""
+
+    def __init__(self, input_size=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device="cuda"):
+        import ctypes
+        self.size, self.device = int(input_size), torch.device(device)
+        self._mean = (ctypes.c_float * 3)(*mean)
+        self._std = (ctypes.c_float * 3)(*std)
+        self._ws = None
+
+    def plan(self, shapes, params):
+        """shapes: [(H, W)], params: [(box, resized, window[, flip])] -> (ImageDesc array (planned), packed byte count, workspace bytes)."""
+        from .. import _lib
+        B = len(shapes)
+        descs = (_lib.ImageDesc * B)()
+        off = 0
+        for d, (h, w), p in zip(descs, shapes, params):
+            box, resized, window = p[0], p[1], p[2]
+            d.offset, d.height, d.width, d.row_stride = off, h, w, 3 * w
+            d.box_top, d.box_left, d.box_h, d.box_w = box
+            d.resized_h, d.resized_w = resized
+            d.win_top, d.win_left = window
+            d.flip = 1 if (len(p) > 3 and p[3]) else 0
+            off += (h * w * 3 + 3) // 4 * 4
+        ws = _lib.load().cream_image_batch_plan(descs, B, self.size, self.size)
+        if ws < 0:
+            _lib.check(int(ws), "cream_image_batch_plan")
+        return descs, off, int(ws)
+
+    def __call__(self, frames, params):
+        """frames: list of (H, W, 3) uint8 numpy arrays / tensors; params as for `plan`."""
+        import ctypes
+        import numpy as np
+        from .. import _lib
+        B = len(frames)
+        shapes = [tuple(f.shape[:2]) for f in frames]
+        descs, nbytes, ws_bytes = self.plan(shapes, params)
+        packed = torch.empty(nbytes, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+        pk = packed.numpy()
+        for d, f in zip(descs, frames):
+            a = np.ascontiguousarray(f.numpy() if isinstance(f, torch.Tensor) else f, dtype=np.uint8)
+            pk[d.offset:d.offset + a.size] = a.reshape(-1)
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+        if self.device.type == "cuda":
+            raw = raw.pin_memory()
+        with torch.cuda.device(self.device):
+            pix = packed.to(self.device, non_blocking=True)
+            dd = raw.to(self.device, non_blocking=True)
+            if self._ws is None or self._ws.numel() < ws_bytes:
+                self._ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
+            out = torch.empty((B, 3, self.size, self.size), dtype=torch.float32, device=self.device)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.load().cream_image_batch_transform(
+                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(pix.data_ptr()), nbytes, descs, ctypes.c_void_p(dd.data_ptr()), B,
+                self.size, self.size, self._mean, self._std, ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), st),
+                "cream_image_batch_transform")
+            # the staging tensors are read by the copies / kernels enqueued above
+            pix.record_stream(torch.cuda.current_stream())
+            dd.record_stream(torch.cuda.current_stream())
+        return out

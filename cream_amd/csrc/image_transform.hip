@@ -1,0 +1,287 @@
+// image_transform.hip — the uint8 -> normalised float input transform of both reference pipelines, on the device, for a whole batch.
+//
+// Reference: AutoFormer/lib/datasets.py:189-220 (`build_transform`):
+//     eval :  Resize(int(256 / 224 * input_size), interpolation=3) -> CenterCrop(input_size) -> ToTensor -> Normalize
+//     train:  timm create_transform(is_training=True, interpolation='bicubic') = RandomResizedCropAndInterpolation ->
+//             RandomHorizontalFlip -> [RandAugment, host side, out of scope] -> ToTensor -> Normalize -> [RandomErasing, out of scope]
+// On the PIL images of the reference's ImageFolder every resize above is Pillow's `Image.resize(size, BICUBIC)` (third-party, not
+// vendored in /root/reference).  These kernels restate Pillow's 8-bit algorithm (libImaging/Resample.c: precompute_coeffs,
+// normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc, ImagingResampleVertical_8bpc; bicubic a = -0.5; 22 fixed-point bits) integer
+// for integer — the coefficient doubles are evaluated on the device in the same order of IEEE operations as the C code (this library
+// is built with -ffp-contract=off) — followed by torchvision's two float32 operations x / 255 and (x - mean) / std.  Byte-exact against
+// Pillow itself and bit-exact against torch's CPU float ops (tests/test_image_transform_gpu.py).
+//
+// One image = { crop box of the decoded HWC uint8 frame (F.crop), size it is resized to (F.resize), window of the resized image that
+// becomes the output (CenterCrop; the whole thing for the training crop), mirror flag }.  Two launches for the whole batch:
+//   H  horizontal pass: for the box rows the window's vertical pass will read, the window's columns -> uint8 rows in the workspace.
+//      A workgroup builds the fixed-point coefficient table of the output columns once (LDS, tap-major), then walks its rows: the
+//      source row segment is staged in LDS with aligned 4-byte loads, a thread owns one output column (3 channels).
+//   V  vertical pass + ToTensor + Normalize (+ mirror): a thread owns 4 consecutive output columns x 3 channels of one output row —
+//      three aligned 4-byte loads per tap — and writes three 16-byte vectors of the (B, 3, out_h, out_w) fp32 batch.
+// Traffic per image of a 500 x 375 frame -> 224 x 224: 0.56 MB read, 0.25 MB intermediate written + read, 0.6 MB written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cream_amd.h"
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+constexpr int LDS_TABLE_BYTES = 40 * 1024;          // coefficient table of the horizontal pass: ksize x out_w int32
+constexpr int LDS_ROW_BYTES = 14 * 1024;            // staged source row segment (box_w * 3 + 6 bytes)
+constexpr int ROWS_PER_WG = 16;
+constexpr int V_ROWS_MAX = 8;                       // output rows per workgroup of the vertical pass: 256 / (out_w / 4), at most this
+
+typedef cream_image_desc Dev;                       // (planned: row0 / nrows / tmp_off filled by cream_image_batch_plan)
+
+__device__ __forceinline__ double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// precompute_coeffs for ONE output index of an axis (in0 = 0, in1 = in_size)
+struct Axis {
+    double scale, support, ss;
+    int in_size;
+    __host__ __device__ Axis(int in, int out) : in_size(in) {
+        scale = (double)in / (double)out;
+        const double filterscale = scale < 1.0 ? 1.0 : scale;
+        support = 2.0 * filterscale;
+        ss = 1.0 / filterscale;
+    }
+    __host__ __device__ int ksize() const {
+        int c = (int)support;
+        if ((double)c < support) ++c;                // ceil
+        return c * 2 + 1;
+    }
+    __host__ __device__ void bounds(int xx, int& xmin, int& cnt, double& center) const {
+        center = 0.0 + (xx + 0.5) * scale;
+        xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        cnt = xmax - xmin;
+    }
+    __device__ double weight(int x, int xmin, double center) const { return bicubic_filter((x + xmin - center + 0.5) * ss); }
+    __device__ double norm(int xmin, int cnt, double center) const {
+        double ww = 0.0;
+        for (int x = 0; x < cnt; ++x) ww += weight(x, xmin, center);
+        return ww;
+    }
+    __device__ int fixed(int x, int xmin, double center, double ww) const {
+        double w = weight(x, xmin, center);
+        if (ww != 0.0) w /= ww;
+        return w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
+    }
+};
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// ---- H ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restrict__ tmp, const uint8_t* __restrict__ pixels,
+                                                               const Dev* __restrict__ descs, int out_w)
+{
+    __shared__ __attribute__((aligned(16))) int ktab[LDS_TABLE_BYTES / 4];       // [tap][out_w]
+    __shared__ unsigned short x0s[1024];
+    __shared__ unsigned char cnts[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[LDS_ROW_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t outbuf[768];                // out_w * 3 bytes (out_w <= 1024)
+
+    const Dev d = descs[blockIdx.y];
+    const int first = blockIdx.x * ROWS_PER_WG;
+    if (first >= d.nrows) return;
+    const Axis ax(d.box_w, d.resized_w);
+    const int ks = ax.ksize();
+    for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
+        int xmin, cnt;
+        double center;
+        ax.bounds(d.win_left + xo, xmin, cnt, center);
+        const double ww = ax.norm(xmin, cnt, center);
+        for (int x = 0; x < ks; ++x) ktab[x * out_w + xo] = x < cnt ? ax.fixed(x, xmin, center, ww) : 0;
+        x0s[xo] = (unsigned short)xmin;
+        cnts[xo] = (unsigned char)cnt;
+    }
+    const int seg_bytes = d.box_w * 3;
+    const int last = min(first + ROWS_PER_WG, d.nrows);
+    for (int r = first; r < last; ++r) {
+        // the row segment [box_left, box_left + box_w) of source row box_top + row0 + r, staged with aligned 4-byte loads
+        const int64_t a0 = d.offset + (int64_t)(d.box_top + d.row0 + r) * d.row_stride + (int64_t)d.box_left * 3;
+        const int sh = (int)(a0 & 3);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(pixels + (a0 - sh));
+        const int nd = (sh + seg_bytes + 3) >> 2;
+        __syncthreads();                                            // table ready / previous row's readers done
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) rowbuf[i] = src[i];
+        __syncthreads();
+        const uint8_t* row = reinterpret_cast<const uint8_t*>(rowbuf) + sh;
+        uint8_t* ob = reinterpret_cast<uint8_t*>(outbuf);
+        for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
+            const int xmin = x0s[xo], cnt = cnts[xo];
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            const uint8_t* p = row + xmin * 3;
+            for (int x = 0; x < cnt; ++x) {
+                const int k = ktab[x * out_w + xo];
+                s0 += (int)p[3 * x] * k;
+                s1 += (int)p[3 * x + 1] * k;
+                s2 += (int)p[3 * x + 2] * k;
+            }
+            ob[3 * xo] = (uint8_t)clip8(s0);
+            ob[3 * xo + 1] = (uint8_t)clip8(s1);
+            ob[3 * xo + 2] = (uint8_t)clip8(s2);
+        }
+        __syncthreads();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tmp + d.tmp_off + (int64_t)r * out_w * 3);
+        for (int i = threadIdx.x; i < (out_w * 3) >> 2; i += blockDim.x) dst[i] = outbuf[i];
+    }
+}
+
+// ---- V + ToTensor + Normalize ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict__ out, const uint8_t* __restrict__ tmp,
+                                                               const Dev* __restrict__ descs, int out_h, int out_w, int V_ROWS,
+                                                               float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    extern __shared__ int ky[];                                     // [V_ROWS][ks] then y0[V_ROWS], cnt[V_ROWS]
+    const Dev d = descs[blockIdx.y];
+    const Axis ay(d.box_h, d.resized_h);
+    const int ks = ay.ksize();
+    int* y0s = ky + V_ROWS * ks;
+    int* cnts = y0s + V_ROWS;
+    const int yo0 = blockIdx.x * V_ROWS;
+    if ((int)threadIdx.x < V_ROWS && yo0 + (int)threadIdx.x < out_h) {
+        const int j = threadIdx.x;
+        int ymin, cnt;
+        double center;
+        ay.bounds(d.win_top + yo0 + j, ymin, cnt, center);
+        const double ww = ay.norm(ymin, cnt, center);
+        for (int y = 0; y < cnt; ++y) ky[j * ks + y] = ay.fixed(y, ymin, center, ww);
+        y0s[j] = ymin - d.row0;                                     // row of the intermediate
+        cnts[j] = cnt;
+    }
+    __syncthreads();
+    const int groups = out_w >> 2;                                  // 4 output columns per thread
+    const int j = threadIdx.x / groups, gx = threadIdx.x - j * groups;
+    if (j >= V_ROWS || yo0 + j >= out_h) return;
+    const int row_bytes = out_w * 3;
+    const uint8_t* base = tmp + d.tmp_off + (int64_t)y0s[j] * row_bytes + gx * 12;
+    int acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
+    const int cnt = cnts[j];
+    for (int y = 0; y < cnt; ++y) {
+        const int k = ky[j * ks + y];
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (int64_t)y * row_bytes);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += (int)((w0 >> (8 * e)) & 255u) * k;
+            acc[4 + e] += (int)((w1 >> (8 * e)) & 255u) * k;
+            acc[8 + e] += (int)((w2 >> (8 * e)) & 255u) * k;
+        }
+    }
+    // torchvision F.to_tensor: float(v) / 255; F.normalize: (x - mean) / std — two IEEE float32 divisions, no contraction
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    const int yo = yo0 + j;
+    float* ob = out + (int64_t)blockIdx.y * 3 * out_h * out_w + (int64_t)yo * out_w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 v;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const float x = (float)clip8(acc[3 * px + c]) / 255.f;
+            v[d.flip ? 3 - px : px] = (x - mean[c]) / sd[c];
+        }
+        const int xo = d.flip ? out_w - 4 - 4 * gx : 4 * gx;
+        *reinterpret_cast<f32x4*>(ob + (int64_t)c * out_h * out_w + xo) = v;
+    }
+}
+
+// rows of the box that the vertical pass of the window reads: [first ymin, last ymin + cnt)
+void window_rows(const cream_image_desc& d, int out_h, int& row0, int& nrows) {
+    const Axis ay(d.box_h, d.resized_h);
+    int ymin, cnt, ymin2, cnt2;
+    double c;
+    ay.bounds(d.win_top, ymin, cnt, c);
+    ay.bounds(d.win_top + out_h - 1, ymin2, cnt2, c);
+    row0 = ymin;
+    nrows = ymin2 + cnt2 - ymin;
+}
+
+int v_rows(int out_w) {
+    const int r = 256 / (out_w / 4);
+    return r > V_ROWS_MAX ? V_ROWS_MAX : r;
+}
+
+int check(const cream_image_desc& d, int out_h, int out_w, int64_t pixels_bytes) {
+    if (d.height <= 0 || d.width <= 0 || d.row_stride < 3 * d.width || d.offset < 0) return CREAM_ERR_BAD_ARG;
+    if (d.box_h <= 0 || d.box_w <= 0 || d.box_top < 0 || d.box_left < 0 || d.box_top + d.box_h > d.height ||
+        d.box_left + d.box_w > d.width)
+        return CREAM_ERR_BAD_ARG;
+    if (d.resized_h <= 0 || d.resized_w <= 0 || d.win_top < 0 || d.win_left < 0 || d.win_top + out_h > d.resized_h ||
+        d.win_left + out_w > d.resized_w)
+        return CREAM_ERR_BAD_ARG;
+    if (d.offset + (int64_t)(d.height - 1) * d.row_stride + 3 * (int64_t)d.width > pixels_bytes) return CREAM_ERR_BAD_ARG;
+    const Axis ax(d.box_w, d.resized_w), ay(d.box_h, d.resized_h);
+    if ((int64_t)ax.ksize() * out_w * 4 > LDS_TABLE_BYTES || ax.ksize() > 255 || d.box_w * 3 + 6 > LDS_ROW_BYTES || d.box_w > 65535)
+        return CREAM_ERR_TOO_LARGE;
+    if (((int64_t)v_rows(out_w) * ay.ksize() + 2 * V_ROWS_MAX) * 4 > 60 * 1024) return CREAM_ERR_TOO_LARGE;
+    return CREAM_OK;
+}
+
+int64_t align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
+bool shape_ok(int B, int out_h, int out_w) { return B > 0 && out_h > 0 && out_w >= 4 && out_w % 4 == 0 && out_w <= 1024; }
+}  // namespace
+
+extern "C" int64_t cream_image_batch_plan(cream_image_desc* descs, int B, int out_h, int out_w)
+{
+    if (!descs || !shape_ok(B, out_h, out_w)) return CREAM_ERR_BAD_ARG;
+    int64_t off = 0;
+    for (int b = 0; b < B; ++b) {
+        const int rc = check(descs[b], out_h, out_w, INT64_MAX);
+        if (rc != CREAM_OK) return rc;
+        window_rows(descs[b], out_h, descs[b].row0, descs[b].nrows);
+        descs[b].tmp_off = off;
+        off += align16((int64_t)descs[b].nrows * out_w * 3);
+    }
+    return off;
+}
+
+extern "C" int cream_image_batch_transform(float* out, const uint8_t* pixels, int64_t pixels_bytes, const cream_image_desc* descs,
+                                           const cream_image_desc* descs_dev, int B, int out_h, int out_w, const float* mean,
+                                           const float* stdev, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (B == 0) return CREAM_OK;
+    if (!out || !pixels || !descs || !descs_dev || !mean || !stdev || !workspace || !shape_ok(B, out_h, out_w)) return CREAM_ERR_BAD_ARG;
+    if (((uintptr_t)out) % 16 || ((uintptr_t)pixels) % 4 || ((uintptr_t)workspace) % 16 || ((uintptr_t)descs_dev) % 8 || pixels_bytes % 4)
+        return CREAM_ERR_BAD_ARG;
+    int64_t off = 0;
+    int max_rows = 0, max_ks = 0;
+    for (int b = 0; b < B; ++b) {                                  // the plan is re-derived: a stale or hand-made one is an error, not a fault
+        const cream_image_desc& d = descs[b];
+        const int rc = check(d, out_h, out_w, pixels_bytes);
+        if (rc != CREAM_OK) return rc;
+        int row0, nrows;
+        window_rows(d, out_h, row0, nrows);
+        if (d.row0 != row0 || d.nrows != nrows || d.tmp_off != off) return CREAM_ERR_BAD_ARG;
+        off += align16((int64_t)nrows * out_w * 3);
+        if (nrows > max_rows) max_rows = nrows;
+        const int ks = Axis(d.box_h, d.resized_h).ksize();
+        if (ks > max_ks) max_ks = ks;
+    }
+    if (workspace_bytes < off) return CREAM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* tmp = reinterpret_cast<uint8_t*>(workspace);
+    hipLaunchKernelGGL(image_resample_h_kernel, dim3((max_rows + ROWS_PER_WG - 1) / ROWS_PER_WG, B), dim3(256), 0, st, tmp, pixels,
+                       descs_dev, out_w);
+    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    const int vr = v_rows(out_w);
+    const size_t lds = ((size_t)vr * max_ks + 2 * V_ROWS_MAX) * 4;
+    hipLaunchKernelGGL(image_resample_v_kernel, dim3((out_h + vr - 1) / vr, B), dim3(256), lds, st, out, tmp, descs_dev, out_h, out_w, vr,
+                       mean[0], mean[1], mean[2], stdev[0], stdev[1], stdev[2]);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}

@@ -520,6 +520,38 @@ typedef struct cream_grad_job {
 #define CREAM_MAX_GRAD_JOBS 24
 int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
 
+/* ---- the uint8 -> normalised float input transform of a batch, on the device (csrc/image_transform.hip) -----------------
+ * AutoFormer/lib/datasets.py:189-220 (`build_transform`): eval = Resize(int(256 / 224 * input_size), bicubic) -> CenterCrop ->
+ * ToTensor -> Normalize; train = timm's RandomResizedCropAndInterpolation(bicubic) -> RandomHorizontalFlip -> [RandAugment: host
+ * side] -> ToTensor -> Normalize.  On the reference's PIL images every resize is Pillow's Image.resize(size, BICUBIC); the kernels
+ * restate that 8-bit algorithm (libImaging/Resample.c, 22-bit fixed-point coefficients from doubles, horizontal pass then vertical
+ * pass with a uint8 intermediate) integer for integer, then torchvision's x / 255 and (x - mean) / std in float32: byte-exact
+ * against Pillow, bit-exact against torch's CPU ops (tests/test_image_transform_gpu.py).
+ * One image: the decoded frame (HWC uint8 RGB at pixels + offset, row_stride bytes per row), the box F.crop takes, the size F.resize
+ * gives the crop, the (win_top, win_left) + (out_h, out_w) window of the resized image that becomes the output (CenterCrop; (0, 0) with
+ * resized == out for the training crop) and the mirror flag of RandomHorizontalFlip.
+ * cream_image_batch_plan (host only, no device work) validates the B descriptors, fills row0 / nrows (the box rows the window's
+ * vertical pass reads) and tmp_off, and returns the workspace size in bytes (>= 0) or an error code (< 0): CREAM_ERR_TOO_LARGE when
+ * a crop is wider than 4776 pixels or shrinks by more than (40960 / (4 out_w) - 1) / 4 (x 11 at out_w = 224).
+ * cream_image_batch_transform takes the planned descriptors twice — the host array (validated again, sizes the grids) and a copy
+ * of it in device memory (the caller uploads it as it likes: one async copy from pinned memory) — and enqueues two launches on
+ * `stream`: out (B, 3, out_h, out_w) fp32.  pixels: 4-byte aligned, pixels_bytes a multiple of 4 (rows are staged with aligned
+ * 4-byte loads); out, workspace: 16-byte aligned; out_w % 4 == 0, out_w <= 1024. */
+typedef struct cream_image_desc {
+    int64_t offset;                                 /* byte offset of the frame in `pixels` */
+    int32_t height, width, row_stride;              /* decoded frame; row_stride >= 3 * width bytes */
+    int32_t box_top, box_left, box_h, box_w;        /* F.crop */
+    int32_t resized_h, resized_w;                   /* F.resize of the crop */
+    int32_t win_top, win_left;                      /* window of the resized image */
+    int32_t flip;                                   /* != 0: mirrored */
+    int32_t row0, nrows;                            /* filled by cream_image_batch_plan */
+    int64_t tmp_off;                                /* filled by cream_image_batch_plan */
+} cream_image_desc;
+int64_t cream_image_batch_plan(cream_image_desc* descs, int B, int out_h, int out_w);
+int cream_image_batch_transform(float* out, const uint8_t* pixels, int64_t pixels_bytes, const cream_image_desc* descs,
+                                const cream_image_desc* descs_dev, int B, int out_h, int out_w, const float* mean,
+                                const float* stdev, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- batch-mode Mixup / CutMix + smoothed soft targets, one launch (csrc/mixup.hip) -----------------
  * `samples, targets = mixup_fn(samples, targets)` of the step body (AutoFormer/supernet_engine.py:52-53; timm.data.Mixup as
  * constructed at supernet_train.py:245-251: mode 'batch' — third-party, not vendored, restated; parity unpinned by the reference,

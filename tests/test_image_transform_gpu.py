@@ -1,0 +1,101 @@
+"""GPU: the device input transform (cream_image_batch_transform, called through the C ABI by autoformer.data.DeviceTransform) against
+the oracle's restatement of Pillow's resize + torchvision's ToTensor / Normalize, against the Pillow-made fixtures and against Pillow
+itself: BIT-EXACT (integer resampling; two IEEE float32 divisions)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import image_transform_oracle as O
+from cream_amd.autoformer import data as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = np.load(__file__.rsplit("/", 1)[0] + "/golden/image_transform.npz")
+NCASES = sum(1 for k in GOLD.files if k.startswith("frame"))
+
+
+def _ref(frame, box, resized, window, size, flip):
+    return O.to_tensor_normalize(O.resized_window(frame, box, resized, window, (size, size), flip))
+
+
+def test_fixtures_bit_exact_as_one_ragged_batch_per_size():
+    by_size = {}
+    for i in range(NCASES):
+        p = [int(v) for v in GOLD[f"params{i}"]]
+        by_size.setdefault(p[9], []).append((GOLD[f"frame{i}"], (tuple(p[0:4]), tuple(p[4:6]), tuple(p[6:8]), bool(p[8])), GOLD[f"u8_{i}"]))
+    for size, cases in by_size.items():
+        T = D.DeviceTransform(size, device=DEV)
+        out = T([c[0] for c in cases], [c[1] for c in cases]).cpu()
+        for o, (frame, prm, u8) in zip(out, cases):
+            assert torch.equal(o, O.to_tensor_normalize(u8))            # the Pillow-made bytes, then the two float ops
+            assert torch.equal(o, _ref(frame, *prm[:3], size, prm[3]))
+
+
+@pytest.mark.parametrize("pipeline", ["eval", "train"])
+def test_imagenet_shaped_batch_bit_exact_against_the_oracle_and_pillow(pipeline):
+    """Ragged frames of ImageNet-like sizes (up- and down-scaling, portrait / landscape, a tiny and a large one) -> 224 x 224."""
+    rng = np.random.default_rng(11)
+    pr = random.Random(5)
+    shapes = [(375, 500), (500, 375), (333, 500), (224, 224), (64, 80), (768, 1024), (1200, 900), (100, 400)]
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    if pipeline == "eval":
+        params = [D.eval_crop_params(h, w) + (False,) for h, w in shapes]
+    else:
+        params = [D.train_crop_params(h, w, pr) for h, w in shapes]
+    out = D.DeviceTransform(224, device=DEV)(frames, params).cpu()
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    for o, f, (box, resized, window, flip) in zip(out, frames, params):
+        assert torch.equal(o, _ref(f, box, resized, window, 224, flip))
+        if Image is not None:
+            t, l, h, w = box
+            im = Image.fromarray(f).crop((l, t, l + w, t + h)).resize((resized[1], resized[0]), Image.BICUBIC)
+            im = im.crop((window[1], window[0], window[1] + 224, window[0] + 224))
+            if flip:
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            assert torch.equal(o, O.to_tensor_normalize(np.asarray(im)))
+
+
+def test_properties_at_batch_128():
+    """A constant frame stays constant through both passes (the fixed-point coefficients of a row sum to 2^22 within the rounding
+    Pillow itself has: checked against the oracle, not assumed); the mirror flag is a pure column reversal; identical frames in one
+    batch give identical outputs; 384 x 384 outputs (DeiT-base-384) take the same path."""
+    rng = np.random.default_rng(2)
+    f = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    T = D.DeviceTransform(224, device=DEV)
+    prm = D.eval_crop_params(300, 400)
+    out = T([f] * 128, [prm + (i % 2 == 1,) for i in range(128)])
+    assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[127])
+    assert torch.equal(out[1], out[0].flip(-1))
+    const = np.full((300, 400, 3), 77, dtype=np.uint8)
+    o = T([const], [prm]).cpu()
+    assert torch.equal(o[0], _ref(const, *prm, 224, False))
+    T384 = D.DeviceTransform(384, device=DEV)
+    p384 = D.eval_crop_params(500, 700, 384)
+    assert torch.equal(T384([f], [((0, 0, 300, 400), (438, 584), (27, 100))]).cpu()[0],
+                       _ref(f, (0, 0, 300, 400), (438, 584), (27, 100), 384, False))
+    assert p384[1][0] == 438
+
+
+def test_c_abi_rejects_unplanned_descriptors():
+    import ctypes
+    from cream_amd import _lib
+    lib = _lib.load()
+    T = D.DeviceTransform(224, device=DEV)
+    descs, nbytes, ws = T.plan([(300, 400)], [D.eval_crop_params(300, 400)])
+    pix = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    dd = torch.zeros(ctypes.sizeof(_lib.ImageDesc), dtype=torch.uint8, device=DEV)
+    out = torch.empty(1, 3, 224, 224, device=DEV)
+    wsb = torch.empty(ws, dtype=torch.uint8, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    call = lambda d, nb, w: lib.cream_image_batch_transform(p(out), p(pix), nb, d, p(dd), 1, 224, 224, T._mean, T._std, p(wsb), w, None)
+    assert call(descs, nbytes, ws) == 0
+    assert call(descs, nbytes, ws - 16) == -1                      # workspace too small
+    assert call(descs, nbytes - 4, ws) == -1                       # frame reaches past the pixel buffer
+    descs[0].nrows += 1
+    assert call(descs, nbytes, ws) == -1                           # not the plan of these descriptors
+    torch.cuda.synchronize()
