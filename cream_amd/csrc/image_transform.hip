@@ -22,15 +22,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "cream_amd.h"
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
-constexpr int LDS_TABLE_BYTES = 40 * 1024;          // coefficient table of the horizontal pass: ksize x out_w int32
-constexpr int LDS_ROW_BYTES = 14 * 1024;            // staged source row segment (box_w * 3 + 6 bytes)
-constexpr int ROWS_PER_WG = 16;
+constexpr int LDS_H_BYTES = 64 * 1024;              // horizontal pass: coefficient table (ksize x out_w int32) + staged row + output row
+constexpr int LDS_ROW_BYTES = 14 * 1024;            // widest box: 3 bytes per pixel of a row fit this
 constexpr int V_ROWS_MAX = 8;                       // output rows per workgroup of the vertical pass: 256 / (out_w / 4), at most this
 
 typedef cream_image_desc Dev;                       // (planned: row0 / nrows / tmp_off filled by cream_image_batch_plan)
@@ -72,12 +73,20 @@ struct Axis {
         for (int x = 0; x < cnt; ++x) ww += weight(x, xmin, center);
         return ww;
     }
-    __device__ int fixed(int x, int xmin, double center, double ww) const {
-        double w = weight(x, xmin, center);
+    __device__ int fixed(int x, int xmin, double center, double ww) const { return fixed_of(weight(x, xmin, center), ww); }
+    static __device__ int fixed_of(double w, double ww) {
         if (ww != 0.0) w /= ww;
         return w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
     }
 };
+
+// acc + v * k for a pixel value v < 2^8: one full-rate 24-bit multiply-add when |k| < 2^23 (every coefficient of an ordinary
+// resize: the normalised weights stay below 2), the 32-bit product (quarter rate) otherwise — the table builders say which
+template <bool WIDE> __device__ __forceinline__ int madk(int acc, int v, int k) {
+    if constexpr (WIDE) return acc + v * k;
+    else return acc + __mul24(v, k);
+}
+__device__ __forceinline__ bool needs_wide(int k) { return k >= (1 << 23) || k <= -(1 << 23); }
 
 __device__ __forceinline__ int clip8(int v) {
     v >>= PRECISION_BITS;
@@ -85,59 +94,111 @@ __device__ __forceinline__ int clip8(int v) {
 }
 
 // ---- H ---------------------------------------------------------------------------------------------------------------------------
+// R box rows at a time: the rows are staged as one aligned 4-byte word per pixel (R | G << 8 | B << 16, scattered byte-wise from
+// aligned 4-byte global loads), a thread owns one output column of ALL R rows — a tap is one coefficient read and R pixel reads
+// for 3 R multiply-adds — and the R output rows leave through LDS as whole words.  ITER groups per workgroup amortise the table.
+constexpr int H_ITER = 4;
+template <int R>
 __global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restrict__ tmp, const uint8_t* __restrict__ pixels,
-                                                               const Dev* __restrict__ descs, int out_w)
+                                                               const Dev* __restrict__ descs, int out_w, int ks_max, int box_w_max)
 {
-    __shared__ __attribute__((aligned(16))) int ktab[LDS_TABLE_BYTES / 4];       // [tap][out_w]
-    __shared__ unsigned short x0s[1024];
-    __shared__ unsigned char cnts[1024];
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[LDS_ROW_BYTES / 4];
-    __shared__ __attribute__((aligned(16))) uint32_t outbuf[768];                // out_w * 3 bytes (out_w <= 1024)
+    // LDS sized by the launch for the batch's largest table / widest box (typically 25-40 KB: four to six workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) int hlds[];
+    int* ktab = hlds;                                                            // [tap][out_w]
+    uint32_t* pix = reinterpret_cast<uint32_t*>(ktab + ks_max * out_w);          // [R][box_w_max]
+    uint32_t* outbuf = pix + R * box_w_max;                                      // [R][out_w * 3 / 4]
+    unsigned short* x0s = reinterpret_cast<unsigned short*>(outbuf + R * ((out_w * 3) / 4));
+    unsigned char* cnts = reinterpret_cast<unsigned char*>(x0s + out_w);
 
     const Dev d = descs[blockIdx.y];
-    const int first = blockIdx.x * ROWS_PER_WG;
+    const int first = blockIdx.x * (R * H_ITER);
     if (first >= d.nrows) return;
     const Axis ax(d.box_w, d.resized_w);
     const int ks = ax.ksize();
+    int wide_l = 0;
     for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
         int xmin, cnt;
         double center;
         ax.bounds(d.win_left + xo, xmin, cnt, center);
         const double ww = ax.norm(xmin, cnt, center);
-        for (int x = 0; x < ks; ++x) ktab[x * out_w + xo] = x < cnt ? ax.fixed(x, xmin, center, ww) : 0;
+        for (int x = 0; x < ks; ++x) {
+            const int k = x < cnt ? ax.fixed(x, xmin, center, ww) : 0;
+            ktab[x * out_w + xo] = k;
+            wide_l |= needs_wide(k);
+        }
         x0s[xo] = (unsigned short)xmin;
         cnts[xo] = (unsigned char)cnt;
     }
+    const bool wide = __syncthreads_or(wide_l) != 0;                // (also: table ready)
     const int seg_bytes = d.box_w * 3;
-    const int last = min(first + ROWS_PER_WG, d.nrows);
-    for (int r = first; r < last; ++r) {
-        // the row segment [box_left, box_left + box_w) of source row box_top + row0 + r, staged with aligned 4-byte loads
-        const int64_t a0 = d.offset + (int64_t)(d.box_top + d.row0 + r) * d.row_stride + (int64_t)d.box_left * 3;
-        const int sh = (int)(a0 & 3);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(pixels + (a0 - sh));
-        const int nd = (sh + seg_bytes + 3) >> 2;
-        __syncthreads();                                            // table ready / previous row's readers done
-        for (int i = threadIdx.x; i < nd; i += blockDim.x) rowbuf[i] = src[i];
-        __syncthreads();
-        const uint8_t* row = reinterpret_cast<const uint8_t*>(rowbuf) + sh;
-        uint8_t* ob = reinterpret_cast<uint8_t*>(outbuf);
-        for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
-            const int xmin = x0s[xo], cnt = cnts[xo];
-            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-            const uint8_t* p = row + xmin * 3;
-            for (int x = 0; x < cnt; ++x) {
-                const int k = ktab[x * out_w + xo];
-                s0 += (int)p[3 * x] * k;
-                s1 += (int)p[3 * x + 1] * k;
-                s2 += (int)p[3 * x + 2] * k;
+    const int last = min(first + R * H_ITER, d.nrows);
+    const int ow_dwords = (out_w * 3) >> 2;
+    for (int r0 = first; r0 < last; r0 += R) {
+        const int nr = min(R, last - r0);
+        __syncthreads();                                            // the previous group's readers are done with pix / outbuf
+        {
+            // row segment [box_left, box_left + box_w) of source rows box_top + row0 + r0 + rr: aligned 4-byte loads (the R rows'
+            // requests of one step in flight together), each byte dropped into its pixel's word
+            const int64_t a00 = d.offset + (int64_t)(d.box_top + d.row0 + r0) * d.row_stride + (int64_t)d.box_left * 3;
+            const int nd_max = (3 + seg_bytes + 3) >> 2;
+            for (int idx = threadIdx.x; idx < nd_max; idx += blockDim.x) {
+                uint32_t v[R];
+                int sh[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int64_t a0 = a00 + (int64_t)rr * d.row_stride;
+                    sh[rr] = (int)(a0 & 3);
+                    const int nd = (sh[rr] + seg_bytes + 3) >> 2;
+                    v[rr] = (rr < nr && idx < nd) ? reinterpret_cast<const uint32_t*>(pixels + (a0 - sh[rr]))[idx] : 0u;
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    uint8_t* pb = reinterpret_cast<uint8_t*>(pix + rr * box_w_max);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int b = idx * 4 + e - sh[rr];
+                        if (b >= 0 && b < seg_bytes) {
+                            const int px = b / 3;
+                            pb[4 * px + (b - 3 * px)] = (uint8_t)(v[rr] >> (8 * e));
+                        }
+                    }
+                }
             }
-            ob[3 * xo] = (uint8_t)clip8(s0);
-            ob[3 * xo + 1] = (uint8_t)clip8(s1);
-            ob[3 * xo + 2] = (uint8_t)clip8(s2);
         }
         __syncthreads();
-        uint32_t* dst = reinterpret_cast<uint32_t*>(tmp + d.tmp_off + (int64_t)r * out_w * 3);
-        for (int i = threadIdx.x; i < (out_w * 3) >> 2; i += blockDim.x) dst[i] = outbuf[i];
+        auto row_pass = [&](auto W) {
+            constexpr bool WIDE = decltype(W)::value;
+            for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
+                const int cnt = cnts[xo];
+                int acc[R][3];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) acc[rr][0] = acc[rr][1] = acc[rr][2] = 1 << (PRECISION_BITS - 1);
+                const uint32_t* p = pix + x0s[xo];
+                const int* kc = ktab + xo;
+                for (int x = 0; x < cnt; ++x) {
+                    const int k = kc[x * out_w];
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        const uint32_t v = p[rr * box_w_max + x];
+                        acc[rr][0] = madk<WIDE>(acc[rr][0], (int)(v & 255u), k);
+                        acc[rr][1] = madk<WIDE>(acc[rr][1], (int)((v >> 8) & 255u), k);
+                        acc[rr][2] = madk<WIDE>(acc[rr][2], (int)((v >> 16) & 255u), k);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    uint8_t* ob = reinterpret_cast<uint8_t*>(outbuf + rr * ow_dwords) + 3 * xo;
+                    ob[0] = (uint8_t)clip8(acc[rr][0]);
+                    ob[1] = (uint8_t)clip8(acc[rr][1]);
+                    ob[2] = (uint8_t)clip8(acc[rr][2]);
+                }
+            }
+        };
+        if (wide) row_pass(std::true_type{});
+        else row_pass(std::false_type{});
+        __syncthreads();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tmp + d.tmp_off + (int64_t)r0 * out_w * 3);     // the nr rows are contiguous
+        for (int i = threadIdx.x; i < nr * ow_dwords; i += blockDim.x) dst[i] = outbuf[i];
     }
 }
 
@@ -146,24 +207,43 @@ __global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict
                                                                const Dev* __restrict__ descs, int out_h, int out_w, int V_ROWS,
                                                                float m0, float m1, float m2, float s0, float s1, float s2)
 {
-    extern __shared__ int ky[];                                     // [V_ROWS][ks] then y0[V_ROWS], cnt[V_ROWS]
+    // LDS: weights [V_ROWS][ks] (double) | their sums [V_ROWS] (double) | coefficients [V_ROWS][ks] | y0, cnt [V_ROWS]
+    extern __shared__ __attribute__((aligned(16))) double vlds[];
     const Dev d = descs[blockIdx.y];
     const Axis ay(d.box_h, d.resized_h);
     const int ks = ay.ksize();
+    double* wtmp = vlds;
+    double* wws = wtmp + V_ROWS * ks;
+    int* ky = reinterpret_cast<int*>(wws + V_ROWS);
     int* y0s = ky + V_ROWS * ks;
     int* cnts = y0s + V_ROWS;
     const int yo0 = blockIdx.x * V_ROWS;
-    if ((int)threadIdx.x < V_ROWS && yo0 + (int)threadIdx.x < out_h) {
-        const int j = threadIdx.x;
+    // the coefficient rows of this workgroup's output rows: the weights (and, below, their divisions) by all threads, the SUM of a
+    // row's weights by one thread in Pillow's order (ww += w for x = 0, 1, ...: the rounding of that sum is part of the result)
+    for (int i = threadIdx.x; i < V_ROWS * ks; i += blockDim.x) {
+        const int j = i / ks, y = i - j * ks;
         int ymin, cnt;
         double center;
-        ay.bounds(d.win_top + yo0 + j, ymin, cnt, center);
-        const double ww = ay.norm(ymin, cnt, center);
-        for (int y = 0; y < cnt; ++y) ky[j * ks + y] = ay.fixed(y, ymin, center, ww);
-        y0s[j] = ymin - d.row0;                                     // row of the intermediate
-        cnts[j] = cnt;
+        ay.bounds(d.win_top + min(yo0 + j, out_h - 1), ymin, cnt, center);
+        wtmp[i] = y < cnt ? ay.weight(y, ymin, center) : 0.0;
+        if (y == 0) { y0s[j] = ymin - d.row0; cnts[j] = cnt; }      // (row of the intermediate)
     }
     __syncthreads();
+    if ((int)threadIdx.x < V_ROWS) {
+        const int j = threadIdx.x, cnt = cnts[j];
+        double ww = 0.0;
+        for (int y = 0; y < cnt; ++y) ww += wtmp[j * ks + y];
+        wws[j] = ww;
+    }
+    __syncthreads();
+    int wide_l = 0;
+    for (int i = threadIdx.x; i < V_ROWS * ks; i += blockDim.x) {
+        const int j = i / ks, y = i - j * ks;
+        const int k = y < cnts[j] ? Axis::fixed_of(wtmp[i], wws[j]) : 0;
+        ky[i] = k;
+        wide_l |= needs_wide(k);
+    }
+    const bool wide = __syncthreads_or(wide_l) != 0;
     const int groups = out_w >> 2;                                  // 4 output columns per thread
     const int j = threadIdx.x / groups, gx = threadIdx.x - j * groups;
     if (j >= V_ROWS || yo0 + j >= out_h) return;
@@ -173,17 +253,23 @@ __global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
     const int cnt = cnts[j];
-    for (int y = 0; y < cnt; ++y) {
-        const int k = ky[j * ks + y];
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (int64_t)y * row_bytes);
-        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    auto col_pass = [&](auto W) {
+        constexpr bool WIDE = decltype(W)::value;
+#pragma unroll 4
+        for (int y = 0; y < cnt; ++y) {
+            const int k = ky[j * ks + y];
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (int64_t)y * row_bytes);
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[e] += (int)((w0 >> (8 * e)) & 255u) * k;
-            acc[4 + e] += (int)((w1 >> (8 * e)) & 255u) * k;
-            acc[8 + e] += (int)((w2 >> (8 * e)) & 255u) * k;
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = madk<WIDE>(acc[e], (int)((w0 >> (8 * e)) & 255u), k);
+                acc[4 + e] = madk<WIDE>(acc[4 + e], (int)((w1 >> (8 * e)) & 255u), k);
+                acc[8 + e] = madk<WIDE>(acc[8 + e], (int)((w2 >> (8 * e)) & 255u), k);
+            }
         }
-    }
+    };
+    if (wide) col_pass(std::true_type{});
+    else col_pass(std::false_type{});
     // torchvision F.to_tensor: float(v) / 255; F.normalize: (x - mean) / std — two IEEE float32 divisions, no contraction
     const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
     const int yo = yo0 + j;
@@ -212,6 +298,20 @@ void window_rows(const cream_image_desc& d, int out_h, int& row0, int& nrows) {
     nrows = ymin2 + cnt2 - ymin;
 }
 
+int64_t h_lds_bytes(int ks, int box_w, int out_w, int R = 1) {
+    return (int64_t)ks * out_w * 4 + (int64_t)R * box_w * 4 + (int64_t)R * out_w * 3 + (int64_t)out_w * 2 + out_w;
+}
+template <int R>
+int launch_h(uint8_t* tmp, const uint8_t* pixels, const cream_image_desc* dd, int B, int out_w, int max_rows, int ks, int box_w,
+             hipStream_t st) {
+    const int per_wg = R * H_ITER;
+    hipLaunchKernelGGL(image_resample_h_kernel<R>, dim3((max_rows + per_wg - 1) / per_wg, B), dim3(256),
+                       (size_t)h_lds_bytes(ks, box_w, out_w, R), st, tmp, pixels, dd, out_w, ks, box_w);
+    return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
+}
+
+int64_t v_lds_bytes(int vr, int ks) { return (int64_t)vr * ks * 12 + (int64_t)vr * 16; }
+
 int v_rows(int out_w) {
     const int r = 256 / (out_w / 4);
     return r > V_ROWS_MAX ? V_ROWS_MAX : r;
@@ -227,9 +327,9 @@ int check(const cream_image_desc& d, int out_h, int out_w, int64_t pixels_bytes)
         return CREAM_ERR_BAD_ARG;
     if (d.offset + (int64_t)(d.height - 1) * d.row_stride + 3 * (int64_t)d.width > pixels_bytes) return CREAM_ERR_BAD_ARG;
     const Axis ax(d.box_w, d.resized_w), ay(d.box_h, d.resized_h);
-    if ((int64_t)ax.ksize() * out_w * 4 > LDS_TABLE_BYTES || ax.ksize() > 255 || d.box_w * 3 + 6 > LDS_ROW_BYTES || d.box_w > 65535)
+    if (ax.ksize() > 255 || d.box_w * 3 + 6 > LDS_ROW_BYTES || d.box_w > 65535 || h_lds_bytes(ax.ksize(), d.box_w, out_w) > LDS_H_BYTES)
         return CREAM_ERR_TOO_LARGE;
-    if (((int64_t)v_rows(out_w) * ay.ksize() + 2 * V_ROWS_MAX) * 4 > 60 * 1024) return CREAM_ERR_TOO_LARGE;
+    if (v_lds_bytes(v_rows(out_w), ay.ksize()) > 60 * 1024) return CREAM_ERR_TOO_LARGE;
     return CREAM_OK;
 }
 
@@ -260,7 +360,7 @@ extern "C" int cream_image_batch_transform(float* out, const uint8_t* pixels, in
     if (((uintptr_t)out) % 16 || ((uintptr_t)pixels) % 4 || ((uintptr_t)workspace) % 16 || ((uintptr_t)descs_dev) % 8 || pixels_bytes % 4)
         return CREAM_ERR_BAD_ARG;
     int64_t off = 0;
-    int max_rows = 0, max_ks = 0;
+    int max_rows = 0, max_ks = 0, max_ksx = 0, max_box_w = 0;
     for (int b = 0; b < B; ++b) {                                  // the plan is re-derived: a stale or hand-made one is an error, not a fault
         const cream_image_desc& d = descs[b];
         const int rc = check(d, out_h, out_w, pixels_bytes);
@@ -272,15 +372,23 @@ extern "C" int cream_image_batch_transform(float* out, const uint8_t* pixels, in
         if (nrows > max_rows) max_rows = nrows;
         const int ks = Axis(d.box_h, d.resized_h).ksize();
         if (ks > max_ks) max_ks = ks;
+        const int ksx = Axis(d.box_w, d.resized_w).ksize();
+        if (ksx > max_ksx) max_ksx = ksx;
+        if (d.box_w > max_box_w) max_box_w = d.box_w;
     }
     if (workspace_bytes < off) return CREAM_ERR_BAD_ARG;
+    if (h_lds_bytes(max_ksx, max_box_w, out_w) > LDS_H_BYTES) return CREAM_ERR_TOO_LARGE;      // (largest table and widest box in ONE batch)
     hipStream_t st = (hipStream_t)stream;
     uint8_t* tmp = reinterpret_cast<uint8_t*>(workspace);
-    hipLaunchKernelGGL(image_resample_h_kernel, dim3((max_rows + ROWS_PER_WG - 1) / ROWS_PER_WG, B), dim3(256), 0, st, tmp, pixels,
-                       descs_dev, out_w);
-    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    // rows per step of the horizontal pass: eight where the batch's largest table and widest box leave room for them
+    int rc;
+    if (h_lds_bytes(max_ksx, max_box_w, out_w, 8) <= 40 * 1024) rc = launch_h<8>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
+    else if (h_lds_bytes(max_ksx, max_box_w, out_w, 4) <= LDS_H_BYTES) rc = launch_h<4>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
+    else if (h_lds_bytes(max_ksx, max_box_w, out_w, 2) <= LDS_H_BYTES) rc = launch_h<2>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
+    else rc = launch_h<1>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
+    if (rc != CREAM_OK) return rc;
     const int vr = v_rows(out_w);
-    const size_t lds = ((size_t)vr * max_ks + 2 * V_ROWS_MAX) * 4;
+    const size_t lds = (size_t)v_lds_bytes(vr, max_ks);
     hipLaunchKernelGGL(image_resample_v_kernel, dim3((out_h + vr - 1) / vr, B), dim3(256), lds, st, out, tmp, descs_dev, out_h, out_w, vr,
                        mean[0], mean[1], mean[2], stdev[0], stdev[1], stdev[2]);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;

@@ -11,7 +11,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from cream_amd import _lib                                   # noqa: E402
 from cream_amd.autoformer import data as D                   # noqa: E402
 
