@@ -14,8 +14,9 @@
 // One image = { crop box of the decoded HWC uint8 frame (F.crop), size it is resized to (F.resize), window of the resized image that
 // becomes the output (CenterCrop; the whole thing for the training crop), mirror flag }.  Two launches for the whole batch:
 //   H  horizontal pass: for the box rows the window's vertical pass will read, the window's columns -> uint8 rows in the workspace.
-//      A workgroup builds the fixed-point coefficient table of the output columns once (LDS, tap-major), then walks its rows: the
-//      source row segment is staged in LDS with aligned 4-byte loads, a thread owns one output column (3 channels).
+//      A workgroup builds the fixed-point coefficient table of the output columns once (LDS, tap-major), then walks its rows R at a
+//      time: the source row segments are staged in LDS as one word per pixel (aligned 4-byte loads, bytes scattered), a thread owns
+//      one output column of all R rows (3 channels each).
 //   V  vertical pass + ToTensor + Normalize (+ mirror): a thread owns 4 consecutive output columns x 3 channels of one output row —
 //      three aligned 4-byte loads per tap — and writes three 16-byte vectors of the (B, 3, out_h, out_w) fp32 batch.
 // Traffic per image of a 500 x 375 frame -> 224 x 224: 0.56 MB read, 0.25 MB intermediate written + read, 0.6 MB written.
