@@ -30,6 +30,8 @@ Extra objects on the line:
                   timed on this box's host cores on a bounded sample at batch 64: best of 16 / 64 / all hardware
                   threads (rank 0, N=1 only), CPU model stated; plus one RPEAttention layer at config-4 shapes in
                   the reference's own pure-PyTorch formulation (oracle/irpe_oracle.py: flat-index gather, irpe.py:646).
+  input_transform — the device input transform of lib/datasets.py:189-220 (crop, Pillow's bicubic resize, window / mirror, ToTensor,
+                  Normalize) on 128 decoded frames resident in HBM: ms per batch, images/s, algorithmic GB/s (N=1 default run only);
   tinyclip_config5 — BASELINE config 5's distillation step on one device (student ViT-39M/16 + Text-19M, teacher ViT-B/16);
   irpe_config4  — BASELINE config 4 on the device: one RPEAttention layer (DeiT-B-384 + iRPE, L = 577) fwd+bwd
                   through the fused kernels of csrc/irpe_attn.hip, ms per layer (N=1 default run only); `model`: the whole
@@ -476,6 +478,50 @@ def deit_config4_model_leg(iters=6, batch=64):
                 ms_per_step=round(ms, 2), images_per_s=round(batch / ms * 1e3, 1))
 
 
+def input_transform_leg(B=128, iters=20):
+    """The device input transform of lib/datasets.py:189-220 (csrc/image_transform.hip) on B synthetic decoded frames of ImageNet's
+    typical sizes, frames resident in HBM: both pipelines' kernels (HIP events on the launch stream), images/s and the algorithmic
+    bytes per second (box rows read + intermediate written and read + fp32 batch written) against the 8 TB/s HBM peak."""
+    import ctypes
+    import random as _random
+    import numpy as np
+    from cream_amd import _lib
+    from cream_amd.autoformer import data as D
+    dev, size = "cuda:0", 224
+    rng, pr = np.random.default_rng(0), _random.Random(0)
+    shapes = [[(375, 500), (500, 375), (333, 500), (480, 640), (768, 1024)][i % 5] for i in range(B)]
+    frames = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in shapes]
+    T = D.DeviceTransform(size, device=dev)
+    lib = _lib.load()
+    out = torch.empty((B, 3, size, size), dtype=torch.float32, device=dev)
+    res = {"workload": f"{B} decoded frames (333x500 .. 768x1024, HWC uint8) -> ({B}, 3, {size}, {size}) fp32, frames resident in HBM"}
+    for name in ("train", "eval"):
+        params = [D.eval_crop_params(h, w) + (False,) if name == "eval" else D.train_crop_params(h, w, pr) for h, w in shapes]
+        descs, nbytes, ws = T.plan(shapes, params)
+        pix = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for d, f in zip(descs, frames):
+            pix[d.offset:d.offset + f.numel()] = f.reshape(-1).to(dev)
+        dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        wsb = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        call = lambda: lib.cream_image_batch_transform(p(out), p(pix), nbytes, descs, p(dd), B, size, size, T._mean, T._std, p(wsb),
+                                                       wsb.numel(), ctypes.c_void_p(st.cuda_stream))
+        for _ in range(3):
+            _lib.check(call(), "cream_image_batch_transform")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            call()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        algo = (sum(d.nrows * d.box_w * 3 for d in descs) + 2 * sum(d.nrows * size * 3 for d in descs) + B * 3 * size * size * 4)
+        res[name] = {"ms_per_batch": round(ms, 4), "images_per_sec": round(B / ms * 1e3), "algorithmic_bytes": int(algo),
+                     "GBps": round(algo / ms / 1e6, 1), "frac_of_hbm_peak": round(algo / ms / 1e6 / 8000, 3)}
+    return res
+
+
 def tinyclip_config5_leg(batch=256, iters=10):
     """BASELINE config 5 on ONE device: the affinity-mimicking distillation step of TinyCLIP — student
     TinyCLIP-ViT-39M/16 + Text-19M, frozen teacher ViT-B/16, ClipSoftLoss, gradient clipping 5, AdamW — on synthetic
@@ -522,7 +568,7 @@ def compact_line(line):
     method notes — goes to bench_extra.json, which the headline names."""
     extra = {}
     head = dict(line)
-    for k in ("rpe_index_config4", "irpe_config4", "tinyclip_config5", "host_unstalled", "per_embed_dim", "parity_unpinned",
+    for k in ("rpe_index_config4", "irpe_config4", "tinyclip_config5", "input_transform", "host_unstalled", "per_embed_dim", "parity_unpinned",
               "host_enqueue_ms_per_step"):
         if k in head:
             extra[k] = head.pop(k)
@@ -802,6 +848,10 @@ def main():
                 line["tinyclip_config5"] = tinyclip_config5_leg()
             except Exception as e:
                 sys.stderr.write(f"[bench] TinyCLIP config-5 leg failed: {e}\n")
+            try:
+                line["input_transform"] = input_transform_leg()
+            except Exception as e:
+                sys.stderr.write(f"[bench] input-transform leg failed: {e}\n")
         head, extra = compact_line(line)
         try:                                       # the side legs and the long-form notes: next to the headline, not in it
             with open(os.environ.get("CREAM_BENCH_EXTRA", "bench_extra.json"), "w") as fh:
