@@ -74,6 +74,9 @@ def test_properties_at_batch_128():
     const = np.full((300, 400, 3), 77, dtype=np.uint8)
     o = T([const], [prm]).cpu()
     assert torch.equal(o[0], _ref(const, *prm, 224, False))
+    # a frame that already has the output size (the training recipe with RandAugment on the host): both passes are identities
+    g = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    assert torch.equal(T([g], [((0, 0, 224, 224), (224, 224), (0, 0), False)]).cpu()[0], O.to_tensor_normalize(g))
     T384 = D.DeviceTransform(384, device=DEV)
     p384 = D.eval_crop_params(500, 700, 384)
     assert torch.equal(T384([f], [((0, 0, 300, 400), (438, 584), (27, 100))]).cpu()[0],
