@@ -29,6 +29,7 @@
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 constexpr int LDS_H_BYTES = 64 * 1024;              // horizontal pass: coefficient table (ksize x out_w int32) + staged row + output row
@@ -138,31 +139,35 @@ __global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restri
         const int nr = min(R, last - r0);
         __syncthreads();                                            // the previous group's readers are done with pix / outbuf
         {
-            // row segment [box_left, box_left + box_w) of source rows box_top + row0 + r0 + rr: aligned 4-byte loads (the R rows'
-            // requests of one step in flight together), each byte dropped into its pixel's word
+            // row segment [box_left, box_left + box_w) of source rows box_top + row0 + r0 + rr.  A thread takes the 12 bytes of four
+            // consecutive pixels: four aligned 4-byte loads (the row starts at any byte), three byte-alignments, one 16-byte LDS
+            // store of the four pixel words; the R rows' requests of a step are in flight together.
             const int64_t a00 = d.offset + (int64_t)(d.box_top + d.row0 + r0) * d.row_stride + (int64_t)d.box_left * 3;
-            const int nd_max = (3 + seg_bytes + 3) >> 2;
-            for (int idx = threadIdx.x; idx < nd_max; idx += blockDim.x) {
-                uint32_t v[R];
+            const int ngroups = (d.box_w + 3) >> 2;
+            for (int gi = threadIdx.x; gi < ngroups; gi += blockDim.x) {
+                uint32_t v[R][4];
                 int sh[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     const int64_t a0 = a00 + (int64_t)rr * d.row_stride;
                     sh[rr] = (int)(a0 & 3);
-                    const int nd = (sh[rr] + seg_bytes + 3) >> 2;
-                    v[rr] = (rr < nr && idx < nd) ? reinterpret_cast<const uint32_t*>(pixels + (a0 - sh[rr]))[idx] : 0u;
+                    const int nd = (sh[rr] + seg_bytes + 3) >> 2;             // words that hold bytes of this row segment
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(pixels + (a0 - sh[rr])) + 3 * gi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[rr][e] = (rr < nr && 3 * gi + e < nd) ? src[e] : 0u;
                 }
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    uint8_t* pb = reinterpret_cast<uint8_t*>(pix + rr * box_w_max);
+                    uint32_t w[3];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int b = idx * 4 + e - sh[rr];
-                        if (b >= 0 && b < seg_bytes) {
-                            const int px = b / 3;
-                            pb[4 * px + (b - 3 * px)] = (uint8_t)(v[rr] >> (8 * e));
-                        }
-                    }
+                    for (int e = 0; e < 3; ++e)                                // bytes [4e + sh, 4e + sh + 4) of the 16 loaded
+                        w[e] = sh[rr] ? (v[rr][e] >> (8 * sh[rr])) | (v[rr][e + 1] << (32 - 8 * sh[rr])) : v[rr][e];
+                    u32x4 q;
+                    q[0] = w[0] & 0xFFFFFFu;
+                    q[1] = (w[0] >> 24) | ((w[1] & 0xFFFFu) << 8);
+                    q[2] = (w[1] >> 16) | ((w[2] & 0xFFu) << 16);
+                    q[3] = w[2] >> 8;
+                    *reinterpret_cast<u32x4*>(pix + rr * box_w_max + 4 * gi) = q;
                 }
             }
         }
@@ -299,15 +304,16 @@ void window_rows(const cream_image_desc& d, int out_h, int& row0, int& nrows) {
     nrows = ymin2 + cnt2 - ymin;
 }
 
+int pad4(int v) { return (v + 3) & ~3; }
 int64_t h_lds_bytes(int ks, int box_w, int out_w, int R = 1) {
-    return (int64_t)ks * out_w * 4 + (int64_t)R * box_w * 4 + (int64_t)R * out_w * 3 + (int64_t)out_w * 2 + out_w;
+    return (int64_t)ks * out_w * 4 + (int64_t)R * pad4(box_w) * 4 + (int64_t)R * out_w * 3 + (int64_t)out_w * 2 + out_w;
 }
 template <int R>
 int launch_h(uint8_t* tmp, const uint8_t* pixels, const cream_image_desc* dd, int B, int out_w, int max_rows, int ks, int box_w,
              hipStream_t st) {
     const int per_wg = R * H_ITER;
     hipLaunchKernelGGL(image_resample_h_kernel<R>, dim3((max_rows + per_wg - 1) / per_wg, B), dim3(256),
-                       (size_t)h_lds_bytes(ks, box_w, out_w, R), st, tmp, pixels, dd, out_w, ks, box_w);
+                       (size_t)h_lds_bytes(ks, box_w, out_w, R), st, tmp, pixels, dd, out_w, ks, pad4(box_w));
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
 
