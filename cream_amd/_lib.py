@@ -145,7 +145,9 @@ class ImageDesc(ctypes.Structure):
     _fields_ = ([("offset", _i64)] +
                 [(n, _c.c_int32) for n in ("height", "width", "row_stride", "box_top", "box_left", "box_h", "box_w", "resized_h",
                                            "resized_w", "win_top", "win_left", "flip", "row0", "nrows")] +
-                [("tmp_off", _i64)])
+                [("tmp_off", _i64)] +
+                [(n, _c.c_int32) for n in ("erase_top", "erase_left", "erase_h", "erase_w")] +
+                [("erase_seed", _c.c_uint32), ("reserved", _c.c_int32)])
 
 
 class SliceJob(ctypes.Structure):

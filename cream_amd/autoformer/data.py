@@ -189,6 +189,49 @@ def train_crop_params(height, width, rng, input_size=224, scale=(0.08, 1.0), rat
     return box, (input_size, input_size), (0, 0), flip
 
 
+def random_erasing_params(rng, height=224, width=224, probability=0.25, min_area=0.02, max_area=1 / 3, min_aspect=0.3, count=1):
+    """The box of timm's RandomErasing (create_transform(re_prob=args.reprob, re_mode='pixel', re_count=1), lib/datasets.py:199-201)
+    for ONE image, drawn from `rng` (a `random.Random`) in timm's order of calls: the probability gate, then up to ten attempts of
+    area x aspect sampling.  Third-party, restated from its published definition (parity unpinned by the reference).
+    -> (top, left, h, w, seed) or None; `seed` names the noise the device writes into the box."""
+    if rng.random() > probability:
+        return None
+    area = height * width
+    log_lo, log_hi = math.log(min_aspect), math.log(1 / min_aspect)
+    for _ in range(10):
+        target_area = rng.uniform(min_area, max_area) * area / count
+        aspect = math.exp(rng.uniform(log_lo, log_hi))
+        h = int(round(math.sqrt(target_area * aspect)))
+        w = int(round(math.sqrt(target_area / aspect)))
+        if w < width and h < height:
+            top = rng.randint(0, height - h)
+            left = rng.randint(0, width - w)
+            return top, left, h, w, rng.getrandbits(32)
+    return None
+
+
+def erase_noise_reference(seed, C, H, W):
+    """numpy restatement of the device's noise (csrc/image_transform.hip: erase_noise) as a (C, H, W) float32 array — for the tests."""
+    import numpy as np
+
+    def mix32(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(16)
+        return x
+
+    c = np.arange(C, dtype=np.uint64)[:, None, None]
+    y = np.arange(H, dtype=np.uint64)[None, :, None]
+    x = np.arange(W, dtype=np.uint64)[None, None, :]
+    key = mix32(np.uint64(seed & 0xFFFFFFFF) ^ (((c + np.uint64(1)) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)))
+    h1 = mix32(key ^ ((y << np.uint64(16)) | x))
+    h2 = mix32(h1 ^ np.uint64(0x85EBCA6B))
+    u1 = ((h1 >> np.uint64(8)).astype(np.float32) + np.float32(1)) * np.float32(1 / 16777216)
+    u2 = (h2 >> np.uint64(8)).astype(np.float32) * np.float32(1 / 16777216)
+    return (np.sqrt(np.float32(-2) * np.log(u1)) * np.cos(np.float32(6.28318530717958647692) * u2)).astype(np.float32)
+
+
 class DeviceTransform:
     """A batch of decoded frames (HWC uint8 RGB arrays of any sizes) -> (B, 3, S, S) float32 on the device, as the reference's
     per-image transforms produce it: F.crop -> Pillow's bicubic F.resize -> window (CenterCrop) -> mirror -> ToTensor -> Normalize,
@@ -204,7 +247,8 @@ class DeviceTransform:
         self._ws = None
 
     def plan(self, shapes, params):
-        """shapes: [(H, W)], params: [(box, resized, window[, flip])] -> (ImageDesc array (planned), packed byte count, workspace bytes)."""
+        """shapes: [(H, W)], params: [(box, resized, window[, flip[, erase]])] with erase = None | (top, left, h, w, seed)
+        (random_erasing_params) -> (ImageDesc array (planned), packed byte count, workspace bytes)."""
         from .. import _lib
         B = len(shapes)
         descs = (_lib.ImageDesc * B)()
@@ -216,6 +260,8 @@ class DeviceTransform:
             d.resized_h, d.resized_w = resized
             d.win_top, d.win_left = window
             d.flip = 1 if (len(p) > 3 and p[3]) else 0
+            if len(p) > 4 and p[4] is not None:
+                d.erase_top, d.erase_left, d.erase_h, d.erase_w, d.erase_seed = p[4]
             off += (h * w * 3 + 3) // 4 * 4
         ws = _lib.load().cream_image_batch_plan(descs, B, self.size, self.size)
         if ws < 0:

@@ -3,7 +3,8 @@
 // Reference: AutoFormer/lib/datasets.py:189-220 (`build_transform`):
 //     eval :  Resize(int(256 / 224 * input_size), interpolation=3) -> CenterCrop(input_size) -> ToTensor -> Normalize
 //     train:  timm create_transform(is_training=True, interpolation='bicubic') = RandomResizedCropAndInterpolation ->
-//             RandomHorizontalFlip -> [RandAugment, host side, out of scope] -> ToTensor -> Normalize -> [RandomErasing, out of scope]
+//             RandomHorizontalFlip -> [RandAugment, host side, out of scope] -> ToTensor -> Normalize -> RandomErasing ('pixel' mode:
+//             box from the host, standard-normal noise from a counter-based hash in the vertical-pass kernel)
 // On the PIL images of the reference's ImageFolder every resize above is Pillow's `Image.resize(size, BICUBIC)` (third-party, not
 // vendored in /root/reference).  These kernels restate Pillow's 8-bit algorithm (libImaging/Resample.c: precompute_coeffs,
 // normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc, ImagingResampleVertical_8bpc; bicubic a = -0.5; 22 fixed-point bits) integer
@@ -89,6 +90,23 @@ template <bool WIDE> __device__ __forceinline__ int madk(int acc, int v, int k) 
     else return acc + __mul24(v, k);
 }
 __device__ __forceinline__ bool needs_wide(int k) { return k >= (1 << 23) || k <= -(1 << 23); }
+
+// standard-normal noise of RandomErasing's 'pixel' mode: two 32-bit counter-based hashes of (seed, channel, row, column) through
+// Box-Muller (autoformer/data.py: erase_noise_reference restates it)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float erase_noise(uint32_t seed, int c, int y, int x) {
+    const uint32_t key = mix32(seed ^ ((uint32_t)(c + 1) * 0x9E3779B9u));
+    const uint32_t h1 = mix32(key ^ (((uint32_t)y << 16) | (uint32_t)x));
+    const uint32_t h2 = mix32(h1 ^ 0x85EBCA6Bu);
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);                   // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
 
 __device__ __forceinline__ int clip8(int v) {
     v >>= PRECISION_BITS;
@@ -289,6 +307,11 @@ __global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict
             v[d.flip ? 3 - px : px] = (x - mean[c]) / sd[c];
         }
         const int xo = d.flip ? out_w - 4 - 4 * gx : 4 * gx;
+        if (d.erase_h > 0 && yo >= d.erase_top && yo < d.erase_top + d.erase_h) {      // RandomErasing, mode 'pixel'
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+                if (xo + px >= d.erase_left && xo + px < d.erase_left + d.erase_w) v[px] = erase_noise(d.erase_seed, c, yo, xo + px);
+        }
         *reinterpret_cast<f32x4*>(ob + (int64_t)c * out_h * out_w + xo) = v;
     }
 }
@@ -333,6 +356,9 @@ int check(const cream_image_desc& d, int out_h, int out_w, int64_t pixels_bytes)
         d.win_left + out_w > d.resized_w)
         return CREAM_ERR_BAD_ARG;
     if (d.offset + (int64_t)(d.height - 1) * d.row_stride + 3 * (int64_t)d.width > pixels_bytes) return CREAM_ERR_BAD_ARG;
+    if (d.erase_h < 0 || d.erase_w < 0 || (d.erase_h > 0 && (d.erase_top < 0 || d.erase_left < 0 || d.erase_top + d.erase_h > out_h ||
+                                                              d.erase_left + d.erase_w > out_w)))
+        return CREAM_ERR_BAD_ARG;
     const Axis ax(d.box_w, d.resized_w), ay(d.box_h, d.resized_h);
     if (ax.ksize() > 255 || d.box_w * 3 + 6 > LDS_ROW_BYTES || d.box_w > 65535 || h_lds_bytes(ax.ksize(), d.box_w, out_w) > LDS_H_BYTES)
         return CREAM_ERR_TOO_LARGE;

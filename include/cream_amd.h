@@ -546,6 +546,14 @@ typedef struct cream_image_desc {
     int32_t flip;                                   /* != 0: mirrored */
     int32_t row0, nrows;                            /* filled by cream_image_batch_plan */
     int64_t tmp_off;                                /* filled by cream_image_batch_plan */
+    /* RandomErasing of the training recipe (timm, mode 'pixel': lib/datasets.py:199-201 re_prob / re_mode / re_count), applied to
+     * the NORMALISED output: elements [:, erase_top : + erase_h, erase_left : + erase_w] become standard-normal noise, a pure
+     * function of (erase_seed, channel, row, column) (a counter-based hash through Box-Muller); erase_h == 0: no erasing.  The box
+     * is drawn on the host (autoformer/data.py: random_erasing_params, timm's order of draws); the noise stream is this library's
+     * own (no two implementations share one). */
+    int32_t erase_top, erase_left, erase_h, erase_w;
+    uint32_t erase_seed;
+    int32_t reserved;
 } cream_image_desc;
 int64_t cream_image_batch_plan(cream_image_desc* descs, int B, int out_h, int out_w);
 int cream_image_batch_transform(float* out, const uint8_t* pixels, int64_t pixels_bytes, const cream_image_desc* descs,

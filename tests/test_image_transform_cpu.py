@@ -75,3 +75,20 @@ def test_plan_entry_point_validates_and_sizes_without_a_device():
     big[0].box_h, big[0].box_w, big[0].resized_h, big[0].resized_w = 100, 6000, 224, 224       # shrinks x 27: beyond the table
     assert lib.cream_image_batch_plan(big, 1, 224, 224) == -4
     assert lib.cream_image_batch_plan(descs, 2, 224, 222) == -1                               # out_w % 4
+
+
+def test_random_erasing_params_gate_and_ranges():
+    rng = random.Random(3)
+    boxes = [D.random_erasing_params(rng) for _ in range(4000)]
+    hit = [b for b in boxes if b is not None]
+    assert abs(len(hit) / 4000 - 0.25) < 0.03                       # re_prob 0.25 (supernet_train.py's --reprob default)
+    for t, l, h, w, seed in hit:
+        assert 0 < h < 224 and 0 < w < 224 and 0 <= t <= 224 - h and 0 <= l <= 224 - w and 0 <= seed < 2 ** 32
+        assert 0.02 * 224 * 224 * 0.7 <= h * w <= 224 * 224 / 3 * 1.3
+    # the plan entry point rejects a box outside the output
+    from cream_amd import _lib
+    T = D.DeviceTransform(224, device="cpu")
+    with pytest.raises(Exception):
+        T.plan([(300, 400)], [D.eval_crop_params(300, 400) + (False, (200, 10, 40, 40, 1))])
+    n = D.erase_noise_reference(7, 3, 64, 64)
+    assert n.shape == (3, 64, 64) and abs(float(n.mean())) < 0.05 and abs(float(n.var()) - 1) < 0.08

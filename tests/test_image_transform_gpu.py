@@ -102,3 +102,26 @@ def test_c_abi_rejects_unplanned_descriptors():
     descs[0].nrows += 1
     assert call(descs, nbytes, ws) == -1                           # not the plan of these descriptors
     torch.cuda.synchronize()
+
+
+def test_random_erasing_box_is_noise_and_the_rest_is_untouched():
+    """RandomErasing (mode 'pixel') on the normalised output: inside the box the device's counter-based standard-normal noise (the numpy
+    restatement within float-function rounding; mean / variance of a large box), outside bit for bit the un-erased result; the box is in
+    OUTPUT coordinates (after the mirror)."""
+    rng = np.random.default_rng(4)
+    f = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    T = D.DeviceTransform(224, device=DEV)
+    base = D.eval_crop_params(300, 400)
+    box = (30, 50, 120, 101, 0xC0FFEE)
+    plain = T([f, f], [base + (False, None), base + (True, None)]).cpu()
+    erased = T([f, f], [base + (False, box), base + (True, box)]).cpu()
+    noise = torch.from_numpy(D.erase_noise_reference(box[4], 3, 224, 224))
+    t, l, h, w, _ = box
+    for b in range(2):
+        inside = torch.zeros(224, 224, dtype=torch.bool)
+        inside[t:t + h, l:l + w] = True
+        assert torch.equal(erased[b][:, ~inside], plain[b][:, ~inside])
+        assert float((erased[b][:, inside] - noise[:, inside]).abs().max()) < 1e-4
+    z = erased[0][:, t:t + h, l:l + w]
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.03 and float(z.abs().max()) < 6.5
+    assert not torch.equal(erased[0][0, t:t + h, l:l + w], erased[0][1, t:t + h, l:l + w])       # channels differ
