@@ -299,3 +299,35 @@ class DeviceTransform:
             pix.record_stream(torch.cuda.current_stream())
             dd.record_stream(torch.cuda.current_stream())
         return out
+
+
+class DeviceBatches:
+    """`batches` for engine.evaluate / the train step from a loader of DECODED frames: wraps an iterable of
+    (frames: list of (H, W, 3) uint8 arrays, labels: int sequence) and yields (samples (B, 3, S, S) fp32 on the device, labels int64
+    on the device) — what `DataLoader(ImageFolder(root, transform=build_transform(...)))` yields in the reference (lib/datasets.py:
+    222-239, supernet_train.py:222-241), with the transform moved behind the loader and onto the device.
+    mode 'eval': Resize + CenterCrop; mode 'train': RandomResizedCrop + flip (+ RandomErasing with `reprob` > 0) from `rng`."""
+
+    def __init__(self, loader, transform, mode="eval", rng=None, reprob=0.0):
+        import random as _random
+        if mode not in ("eval", "train"):
+            raise ValueError(f"unknown mode {mode!r}")
+        self.loader, self.transform, self.mode, self.reprob = loader, transform, mode, float(reprob)
+        self.rng = rng if rng is not None else _random.Random(0)
+
+    def params_for(self, shapes):
+        size = self.transform.size
+        if self.mode == "eval":
+            return [eval_crop_params(h, w, size) + (False, None) for h, w in shapes]
+        out = []
+        for h, w in shapes:
+            box, resized, window, flip = train_crop_params(h, w, self.rng, size)
+            erase = random_erasing_params(self.rng, size, size, self.reprob) if self.reprob > 0 else None
+            out.append((box, resized, window, flip, erase))
+        return out
+
+    def __iter__(self):
+        for frames, labels in self.loader:
+            shapes = [tuple(f.shape[:2]) for f in frames]
+            samples = self.transform(frames, self.params_for(shapes))
+            yield samples, torch.as_tensor(labels, dtype=torch.int64).to(samples.device, non_blocking=True)

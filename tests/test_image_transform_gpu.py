@@ -125,3 +125,25 @@ def test_random_erasing_box_is_noise_and_the_rest_is_untouched():
     z = erased[0][:, t:t + h, l:l + w]
     assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.03 and float(z.abs().max()) < 6.5
     assert not torch.equal(erased[0][0, t:t + h, l:l + w], erased[0][1, t:t + h, l:l + w])       # channels differ
+
+
+def test_evaluate_runs_from_decoded_frames_through_the_device_transform():
+    """engine.evaluate fed by DeviceBatches (decoded frames -> device transform) gives the statistics of the same sub-network on the
+    tensors the reference's eval transform (Pillow + torch on the host: the oracle's restatement) produces."""
+    from cream_amd.autoformer import engine
+    from cream_amd.autoformer.supernet import Vision_TransformerSuper
+    torch.manual_seed(0)
+    model = Vision_TransformerSuper(img_size=224, patch_size=16, embed_dim=256, depth=2, num_heads=4, mlp_ratio=4.0, qkv_bias=True,
+                                    num_classes=10, gp=True, relative_position=True, change_qkv=True, max_relative_position=14).to(DEV)
+    cfg = dict(layer_num=2, embed_dim=[192] * 2, num_heads=[3] * 2, mlp_ratio=[3.5] * 2)
+    rng = np.random.default_rng(9)
+    shapes = [(300, 400), (400, 300), (256, 256), (500, 333)]
+    loader = [([rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes], [1, 2, 3, 4]) for _ in range(2)]
+    got = engine.evaluate(D.DeviceBatches(loader, D.DeviceTransform(224, device=DEV), "eval"), model, amp_dtype=torch.float32,
+                          mode="retrain", retrain_config=cfg)
+    host = []
+    for frames, labels in loader:
+        x = torch.stack([O.to_tensor_normalize(O.resized_window(f, *D.eval_crop_params(*f.shape[:2]), (224, 224))) for f in frames])
+        host.append((x.to(DEV), torch.tensor(labels, device=DEV)))
+    want = engine.evaluate(host, model, amp_dtype=torch.float32, mode="retrain", retrain_config=cfg)
+    assert got["loss"] == want["loss"] and got["acc1"] == want["acc1"] and got["acc5"] == want["acc5"]
