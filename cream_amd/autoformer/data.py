@@ -235,7 +235,7 @@ def erase_noise_reference(seed, C, H, W):
 class DeviceTransform:
     """A batch of decoded frames (HWC uint8 RGB arrays of any sizes) -> (B, 3, S, S) float32 on the device, as the reference's
     per-image transforms produce it: F.crop -> Pillow's bicubic F.resize -> window (CenterCrop) -> mirror -> ToTensor -> Normalize,
-    two launches for the whole batch (cream_image_batch_transform; byte-exact with Pillow's resize, bit-exact float ops).
+    three launches for the whole batch (cream_image_batch_transform; byte-exact with Pillow's resize, bit-exact float ops).
     The frames travel as ONE packed uint8 buffer (each frame at a 4-byte aligned offset) from pinned memory; RandAugment /
     RandomErasing of the training recipe stay host-side (out of scope)."""
 

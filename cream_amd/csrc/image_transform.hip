@@ -13,7 +13,8 @@
 // Pillow itself and bit-exact against torch's CPU float ops (tests/test_image_transform_gpu.py).
 //
 // One image = { crop box of the decoded HWC uint8 frame (F.crop), size it is resized to (F.resize), window of the resized image that
-// becomes the output (CenterCrop; the whole thing for the training crop), mirror flag }.  Two launches for the whole batch:
+// becomes the output (CenterCrop; the whole thing for the training crop), mirror flag }.  Three launches for the whole batch
+// (the first: the fixed-point coefficient tables of both axes, once per image, into the workspace):
 //   H  horizontal pass: for the box rows the window's vertical pass will read, the window's columns -> uint8 rows in the workspace.
 //      A workgroup builds the fixed-point coefficient table of the output columns once (LDS, tap-major), then walks its rows R at a
 //      time: the source row segments are staged in LDS as one word per pixel (aligned 4-byte loads, bytes scattered), a thread owns
@@ -113,6 +114,69 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+// ---- coefficient tables ----------------------------------------------------------------------------------------------------------
+// Per image and axis, ONCE (the resampling kernels read them through L2: a workgroup of the horizontal pass copies its image's
+// column table into LDS, the vertical pass reads a row's coefficients as wave-uniform loads).  Region of image b in the workspace
+// (ints):  xk [ksx][out_w] | x0 [out_w] | xcnt [out_w] | yk [out_h][ksy] | y0 [out_h] | ycnt [out_h] | wide_x, wide_y, 0, 0
+// with ksx / ksy the batch's largest tap counts (taps beyond an index's own count are 0).
+struct TabLayout {
+    int ksx, ksy, out_h, out_w;
+    int64_t stride;                                                 // ints per image (multiple of 4)
+    __host__ __device__ TabLayout(int ksx_, int ksy_, int oh, int ow) : ksx(ksx_), ksy(ksy_), out_h(oh), out_w(ow) {
+        const int64_t n = (int64_t)ksx * ow + 2 * ow + (int64_t)oh * ksy + 2 * oh + 4;
+        stride = (n + 3) & ~(int64_t)3;
+    }
+    __host__ __device__ int64_t xk() const { return 0; }
+    __host__ __device__ int64_t x0() const { return (int64_t)ksx * out_w; }
+    __host__ __device__ int64_t xcnt() const { return x0() + out_w; }
+    __host__ __device__ int64_t yk() const { return xcnt() + out_w; }
+    __host__ __device__ int64_t y0() const { return yk() + (int64_t)out_h * ksy; }
+    __host__ __device__ int64_t ycnt() const { return y0() + out_h; }
+    __host__ __device__ int64_t meta() const { return ycnt() + out_h; }
+};
+
+__global__ __launch_bounds__(256) void image_coeff_kernel(int* __restrict__ tabs, const Dev* __restrict__ descs, int out_h, int out_w,
+                                                          int ksx, int ksy)
+{
+    const TabLayout L(ksx, ksy, out_h, out_w);
+    const Dev d = descs[blockIdx.y];
+    int* t = tabs + (int64_t)blockIdx.y * L.stride;
+    int wide_l = 0;
+    if (blockIdx.x == 0) {                                          // columns
+        const Axis ax(d.box_w, d.resized_w);
+        for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
+            int xmin, cnt;
+            double center;
+            ax.bounds(d.win_left + xo, xmin, cnt, center);
+            const double ww = ax.norm(xmin, cnt, center);
+            for (int x = 0; x < ksx; ++x) {
+                const int k = x < cnt ? ax.fixed(x, xmin, center, ww) : 0;
+                t[L.xk() + (int64_t)x * out_w + xo] = k;
+                wide_l |= needs_wide(k);
+            }
+            t[L.x0() + xo] = xmin;
+            t[L.xcnt() + xo] = cnt;
+        }
+    } else {                                                        // rows
+        const Axis ay(d.box_h, d.resized_h);
+        for (int yo = threadIdx.x; yo < out_h; yo += blockDim.x) {
+            int ymin, cnt;
+            double center;
+            ay.bounds(d.win_top + yo, ymin, cnt, center);
+            const double ww = ay.norm(ymin, cnt, center);
+            for (int y = 0; y < ksy; ++y) {
+                const int k = y < cnt ? ay.fixed(y, ymin, center, ww) : 0;
+                t[L.yk() + (int64_t)yo * ksy + y] = k;
+                wide_l |= needs_wide(k);
+            }
+            t[L.y0() + yo] = ymin - d.row0;                         // row of the intermediate
+            t[L.ycnt() + yo] = cnt;
+        }
+    }
+    const int wide = __syncthreads_or(wide_l);
+    if (threadIdx.x == 0) t[L.meta() + blockIdx.x] = wide != 0;
+}
+
 // ---- H ---------------------------------------------------------------------------------------------------------------------------
 // R box rows at a time: the rows are staged as one aligned 4-byte word per pixel (R | G << 8 | B << 16, scattered byte-wise from
 // aligned 4-byte global loads), a thread owns one output column of ALL R rows — a tap is one coefficient read and R pixel reads
@@ -120,7 +184,8 @@ __device__ __forceinline__ int clip8(int v) {
 constexpr int H_ITER = 4;
 template <int R>
 __global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restrict__ tmp, const uint8_t* __restrict__ pixels,
-                                                               const Dev* __restrict__ descs, int out_w, int ks_max, int box_w_max)
+                                                               const Dev* __restrict__ descs, const int* __restrict__ tabs, int out_h,
+                                                               int out_w, int ks_max, int ksy, int box_w_max)
 {
     // LDS sized by the launch for the batch's largest table / widest box (typically 25-40 KB: four to six workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) int hlds[];
@@ -133,23 +198,16 @@ __global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restri
     const Dev d = descs[blockIdx.y];
     const int first = blockIdx.x * (R * H_ITER);
     if (first >= d.nrows) return;
-    const Axis ax(d.box_w, d.resized_w);
-    const int ks = ax.ksize();
-    int wide_l = 0;
+    const TabLayout L(ks_max, ksy, out_h, out_w);
+    const int* t = tabs + (int64_t)blockIdx.y * L.stride;
+    for (int i = threadIdx.x; i < (ks_max * out_w) >> 2; i += blockDim.x)           // the image's column table: L2 -> LDS
+        reinterpret_cast<u32x4*>(ktab)[i] = reinterpret_cast<const u32x4*>(t + L.xk())[i];
     for (int xo = threadIdx.x; xo < out_w; xo += blockDim.x) {
-        int xmin, cnt;
-        double center;
-        ax.bounds(d.win_left + xo, xmin, cnt, center);
-        const double ww = ax.norm(xmin, cnt, center);
-        for (int x = 0; x < ks; ++x) {
-            const int k = x < cnt ? ax.fixed(x, xmin, center, ww) : 0;
-            ktab[x * out_w + xo] = k;
-            wide_l |= needs_wide(k);
-        }
-        x0s[xo] = (unsigned short)xmin;
-        cnts[xo] = (unsigned char)cnt;
+        x0s[xo] = (unsigned short)t[L.x0() + xo];
+        cnts[xo] = (unsigned char)t[L.xcnt() + xo];
     }
-    const bool wide = __syncthreads_or(wide_l) != 0;                // (also: table ready)
+    const bool wide = t[L.meta()] != 0;
+    __syncthreads();
     const int seg_bytes = d.box_w * 3;
     const int last = min(first + R * H_ITER, d.nrows);
     const int ow_dwords = (out_w * 3) >> 2;
@@ -228,60 +286,31 @@ __global__ __launch_bounds__(256) void image_resample_h_kernel(uint8_t* __restri
 
 // ---- V + ToTensor + Normalize ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict__ out, const uint8_t* __restrict__ tmp,
-                                                               const Dev* __restrict__ descs, int out_h, int out_w, int V_ROWS,
-                                                               float m0, float m1, float m2, float s0, float s1, float s2)
+                                                               const Dev* __restrict__ descs, const int* __restrict__ tabs, int out_h,
+                                                               int out_w, int V_ROWS, int ksx, int ksy, float m0, float m1, float m2,
+                                                               float s0, float s1, float s2)
 {
-    // LDS: weights [V_ROWS][ks] (double) | their sums [V_ROWS] (double) | coefficients [V_ROWS][ks] | y0, cnt [V_ROWS]
-    extern __shared__ __attribute__((aligned(16))) double vlds[];
     const Dev d = descs[blockIdx.y];
-    const Axis ay(d.box_h, d.resized_h);
-    const int ks = ay.ksize();
-    double* wtmp = vlds;
-    double* wws = wtmp + V_ROWS * ks;
-    int* ky = reinterpret_cast<int*>(wws + V_ROWS);
-    int* y0s = ky + V_ROWS * ks;
-    int* cnts = y0s + V_ROWS;
+    const TabLayout L(ksx, ksy, out_h, out_w);
+    const int* t = tabs + (int64_t)blockIdx.y * L.stride;
+    const bool wide = t[L.meta() + 1] != 0;
     const int yo0 = blockIdx.x * V_ROWS;
-    // the coefficient rows of this workgroup's output rows: the weights (and, below, their divisions) by all threads, the SUM of a
-    // row's weights by one thread in Pillow's order (ww += w for x = 0, 1, ...: the rounding of that sum is part of the result)
-    for (int i = threadIdx.x; i < V_ROWS * ks; i += blockDim.x) {
-        const int j = i / ks, y = i - j * ks;
-        int ymin, cnt;
-        double center;
-        ay.bounds(d.win_top + min(yo0 + j, out_h - 1), ymin, cnt, center);
-        wtmp[i] = y < cnt ? ay.weight(y, ymin, center) : 0.0;
-        if (y == 0) { y0s[j] = ymin - d.row0; cnts[j] = cnt; }      // (row of the intermediate)
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < V_ROWS) {
-        const int j = threadIdx.x, cnt = cnts[j];
-        double ww = 0.0;
-        for (int y = 0; y < cnt; ++y) ww += wtmp[j * ks + y];
-        wws[j] = ww;
-    }
-    __syncthreads();
-    int wide_l = 0;
-    for (int i = threadIdx.x; i < V_ROWS * ks; i += blockDim.x) {
-        const int j = i / ks, y = i - j * ks;
-        const int k = y < cnts[j] ? Axis::fixed_of(wtmp[i], wws[j]) : 0;
-        ky[i] = k;
-        wide_l |= needs_wide(k);
-    }
-    const bool wide = __syncthreads_or(wide_l) != 0;
     const int groups = out_w >> 2;                                  // 4 output columns per thread
     const int j = threadIdx.x / groups, gx = threadIdx.x - j * groups;
     if (j >= V_ROWS || yo0 + j >= out_h) return;
     const int row_bytes = out_w * 3;
-    const uint8_t* base = tmp + d.tmp_off + (int64_t)y0s[j] * row_bytes + gx * 12;
+    const int yo = yo0 + j;
+    const int* ky = t + L.yk() + (int64_t)yo * ksy;                 // this row's coefficients: the same address for the row's threads
+    const uint8_t* base = tmp + d.tmp_off + (int64_t)t[L.y0() + yo] * row_bytes + gx * 12;
     int acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
-    const int cnt = cnts[j];
+    const int cnt = t[L.ycnt() + yo];
     auto col_pass = [&](auto W) {
         constexpr bool WIDE = decltype(W)::value;
 #pragma unroll 4
         for (int y = 0; y < cnt; ++y) {
-            const int k = ky[j * ks + y];
+            const int k = ky[y];
             const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (int64_t)y * row_bytes);
             const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
 #pragma unroll
@@ -296,7 +325,6 @@ __global__ __launch_bounds__(256) void image_resample_v_kernel(float* __restrict
     else col_pass(std::false_type{});
     // torchvision F.to_tensor: float(v) / 255; F.normalize: (x - mean) / std — two IEEE float32 divisions, no contraction
     const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
-    const int yo = yo0 + j;
     float* ob = out + (int64_t)blockIdx.y * 3 * out_h * out_w + (int64_t)yo * out_w;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -332,15 +360,13 @@ int64_t h_lds_bytes(int ks, int box_w, int out_w, int R = 1) {
     return (int64_t)ks * out_w * 4 + (int64_t)R * pad4(box_w) * 4 + (int64_t)R * out_w * 3 + (int64_t)out_w * 2 + out_w;
 }
 template <int R>
-int launch_h(uint8_t* tmp, const uint8_t* pixels, const cream_image_desc* dd, int B, int out_w, int max_rows, int ks, int box_w,
-             hipStream_t st) {
+int launch_h(uint8_t* tmp, const uint8_t* pixels, const cream_image_desc* dd, const int* tabs, int B, int out_h, int out_w, int max_rows,
+             int ks, int ksy, int box_w, hipStream_t st) {
     const int per_wg = R * H_ITER;
     hipLaunchKernelGGL(image_resample_h_kernel<R>, dim3((max_rows + per_wg - 1) / per_wg, B), dim3(256),
-                       (size_t)h_lds_bytes(ks, box_w, out_w, R), st, tmp, pixels, dd, out_w, ks, pad4(box_w));
+                       (size_t)h_lds_bytes(ks, box_w, out_w, R), st, tmp, pixels, dd, tabs, out_h, out_w, ks, ksy, pad4(box_w));
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }
-
-int64_t v_lds_bytes(int vr, int ks) { return (int64_t)vr * ks * 12 + (int64_t)vr * 16; }
 
 int v_rows(int out_w) {
     const int r = 256 / (out_w / 4);
@@ -362,26 +388,48 @@ int check(const cream_image_desc& d, int out_h, int out_w, int64_t pixels_bytes)
     const Axis ax(d.box_w, d.resized_w), ay(d.box_h, d.resized_h);
     if (ax.ksize() > 255 || d.box_w * 3 + 6 > LDS_ROW_BYTES || d.box_w > 65535 || h_lds_bytes(ax.ksize(), d.box_w, out_w) > LDS_H_BYTES)
         return CREAM_ERR_TOO_LARGE;
-    if (v_lds_bytes(v_rows(out_w), ay.ksize()) > 60 * 1024) return CREAM_ERR_TOO_LARGE;
+    if (ay.ksize() > 4096) return CREAM_ERR_TOO_LARGE;
     return CREAM_OK;
 }
 
 int64_t align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
 bool shape_ok(int B, int out_h, int out_w) { return B > 0 && out_h > 0 && out_w >= 4 && out_w % 4 == 0 && out_w <= 1024; }
+
+// What a batch needs beyond the descriptors themselves.  `fill`: write row0 / nrows / tmp_off (plan); otherwise they must match.
+struct Batch {
+    int max_rows = 0, ksx = 0, ksy = 0, box_w = 0;
+    int64_t tab_bytes = 0, tmp_bytes = 0;
+};
+int survey(cream_image_desc* descs, const cream_image_desc* cdescs, int B, int out_h, int out_w, int64_t pixels_bytes, Batch& bt) {
+    int64_t off = 0;
+    for (int b = 0; b < B; ++b) {
+        const cream_image_desc& d = cdescs[b];
+        const int rc = check(d, out_h, out_w, pixels_bytes);
+        if (rc != CREAM_OK) return rc;
+        int row0, nrows;
+        window_rows(d, out_h, row0, nrows);
+        if (descs) { descs[b].row0 = row0; descs[b].nrows = nrows; descs[b].tmp_off = off; }
+        else if (d.row0 != row0 || d.nrows != nrows || d.tmp_off != off) return CREAM_ERR_BAD_ARG;     // a stale or hand-made plan
+        off += align16((int64_t)nrows * out_w * 3);
+        if (nrows > bt.max_rows) bt.max_rows = nrows;
+        const int ksy = Axis(d.box_h, d.resized_h).ksize(), ksx = Axis(d.box_w, d.resized_w).ksize();
+        if (ksy > bt.ksy) bt.ksy = ksy;
+        if (ksx > bt.ksx) bt.ksx = ksx;
+        if (d.box_w > bt.box_w) bt.box_w = d.box_w;
+    }
+    if (h_lds_bytes(bt.ksx, bt.box_w, out_w) > LDS_H_BYTES) return CREAM_ERR_TOO_LARGE;      // (largest table and widest box in ONE batch)
+    bt.tab_bytes = align16(TabLayout(bt.ksx, bt.ksy, out_h, out_w).stride * 4 * B);
+    bt.tmp_bytes = off;
+    return CREAM_OK;
+}
 }  // namespace
 
 extern "C" int64_t cream_image_batch_plan(cream_image_desc* descs, int B, int out_h, int out_w)
 {
     if (!descs || !shape_ok(B, out_h, out_w)) return CREAM_ERR_BAD_ARG;
-    int64_t off = 0;
-    for (int b = 0; b < B; ++b) {
-        const int rc = check(descs[b], out_h, out_w, INT64_MAX);
-        if (rc != CREAM_OK) return rc;
-        window_rows(descs[b], out_h, descs[b].row0, descs[b].nrows);
-        descs[b].tmp_off = off;
-        off += align16((int64_t)descs[b].nrows * out_w * 3);
-    }
-    return off;
+    Batch bt;
+    const int rc = survey(descs, descs, B, out_h, out_w, INT64_MAX, bt);
+    return rc != CREAM_OK ? rc : bt.tab_bytes + bt.tmp_bytes;        // [coefficient tables of the B images | intermediate rows]
 }
 
 extern "C" int cream_image_batch_transform(float* out, const uint8_t* pixels, int64_t pixels_bytes, const cream_image_desc* descs,
@@ -392,37 +440,28 @@ extern "C" int cream_image_batch_transform(float* out, const uint8_t* pixels, in
     if (!out || !pixels || !descs || !descs_dev || !mean || !stdev || !workspace || !shape_ok(B, out_h, out_w)) return CREAM_ERR_BAD_ARG;
     if (((uintptr_t)out) % 16 || ((uintptr_t)pixels) % 4 || ((uintptr_t)workspace) % 16 || ((uintptr_t)descs_dev) % 8 || pixels_bytes % 4)
         return CREAM_ERR_BAD_ARG;
-    int64_t off = 0;
-    int max_rows = 0, max_ks = 0, max_ksx = 0, max_box_w = 0;
-    for (int b = 0; b < B; ++b) {                                  // the plan is re-derived: a stale or hand-made one is an error, not a fault
-        const cream_image_desc& d = descs[b];
-        const int rc = check(d, out_h, out_w, pixels_bytes);
-        if (rc != CREAM_OK) return rc;
-        int row0, nrows;
-        window_rows(d, out_h, row0, nrows);
-        if (d.row0 != row0 || d.nrows != nrows || d.tmp_off != off) return CREAM_ERR_BAD_ARG;
-        off += align16((int64_t)nrows * out_w * 3);
-        if (nrows > max_rows) max_rows = nrows;
-        const int ks = Axis(d.box_h, d.resized_h).ksize();
-        if (ks > max_ks) max_ks = ks;
-        const int ksx = Axis(d.box_w, d.resized_w).ksize();
-        if (ksx > max_ksx) max_ksx = ksx;
-        if (d.box_w > max_box_w) max_box_w = d.box_w;
-    }
-    if (workspace_bytes < off) return CREAM_ERR_BAD_ARG;
-    if (h_lds_bytes(max_ksx, max_box_w, out_w) > LDS_H_BYTES) return CREAM_ERR_TOO_LARGE;      // (largest table and widest box in ONE batch)
-    hipStream_t st = (hipStream_t)stream;
-    uint8_t* tmp = reinterpret_cast<uint8_t*>(workspace);
-    // rows per step of the horizontal pass: eight where the batch's largest table and widest box leave room for them
-    int rc;
-    if (h_lds_bytes(max_ksx, max_box_w, out_w, 8) <= 40 * 1024) rc = launch_h<8>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
-    else if (h_lds_bytes(max_ksx, max_box_w, out_w, 4) <= LDS_H_BYTES) rc = launch_h<4>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
-    else if (h_lds_bytes(max_ksx, max_box_w, out_w, 2) <= LDS_H_BYTES) rc = launch_h<2>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
-    else rc = launch_h<1>(tmp, pixels, descs_dev, B, out_w, max_rows, max_ksx, max_box_w, st);
+    Batch bt;
+    int rc = survey(nullptr, descs, B, out_h, out_w, pixels_bytes, bt);
     if (rc != CREAM_OK) return rc;
+    if (workspace_bytes < bt.tab_bytes + bt.tmp_bytes) return CREAM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int* tabs = reinterpret_cast<int*>(workspace);
+    uint8_t* tmp = reinterpret_cast<uint8_t*>(workspace) + bt.tab_bytes;
+    // 1. the fixed-point coefficient tables of both axes, once per image
+    hipLaunchKernelGGL(image_coeff_kernel, dim3(2, B), dim3(256), 0, st, tabs, descs_dev, out_h, out_w, bt.ksx, bt.ksy);
+    if (hipGetLastError() != hipSuccess) return CREAM_ERR_LAUNCH;
+    // 2. horizontal pass; rows per step: eight where the batch's largest table and widest box leave room for them
+    if (h_lds_bytes(bt.ksx, bt.box_w, out_w, 8) <= 40 * 1024)
+        rc = launch_h<8>(tmp, pixels, descs_dev, tabs, B, out_h, out_w, bt.max_rows, bt.ksx, bt.ksy, bt.box_w, st);
+    else if (h_lds_bytes(bt.ksx, bt.box_w, out_w, 4) <= LDS_H_BYTES)
+        rc = launch_h<4>(tmp, pixels, descs_dev, tabs, B, out_h, out_w, bt.max_rows, bt.ksx, bt.ksy, bt.box_w, st);
+    else if (h_lds_bytes(bt.ksx, bt.box_w, out_w, 2) <= LDS_H_BYTES)
+        rc = launch_h<2>(tmp, pixels, descs_dev, tabs, B, out_h, out_w, bt.max_rows, bt.ksx, bt.ksy, bt.box_w, st);
+    else rc = launch_h<1>(tmp, pixels, descs_dev, tabs, B, out_h, out_w, bt.max_rows, bt.ksx, bt.ksy, bt.box_w, st);
+    if (rc != CREAM_OK) return rc;
+    // 3. vertical pass + ToTensor + Normalize (+ mirror, RandomErasing)
     const int vr = v_rows(out_w);
-    const size_t lds = (size_t)v_lds_bytes(vr, max_ks);
-    hipLaunchKernelGGL(image_resample_v_kernel, dim3((out_h + vr - 1) / vr, B), dim3(256), lds, st, out, tmp, descs_dev, out_h, out_w, vr,
-                       mean[0], mean[1], mean[2], stdev[0], stdev[1], stdev[2]);
+    hipLaunchKernelGGL(image_resample_v_kernel, dim3((out_h + vr - 1) / vr, B), dim3(256), 0, st, out, tmp, descs_dev, tabs, out_h, out_w,
+                       vr, bt.ksx, bt.ksy, mean[0], mean[1], mean[2], stdev[0], stdev[1], stdev[2]);
     return hipGetLastError() == hipSuccess ? CREAM_OK : CREAM_ERR_LAUNCH;
 }

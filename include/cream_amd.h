@@ -534,7 +534,7 @@ int cream_grad_finalize(const cream_grad_job* jobs, int njobs, void* stream);
  * vertical pass reads) and tmp_off, and returns the workspace size in bytes (>= 0) or an error code (< 0): CREAM_ERR_TOO_LARGE when
  * a crop is wider than 4776 pixels or shrinks by more than (40960 / (4 out_w) - 1) / 4 (x 11 at out_w = 224).
  * cream_image_batch_transform takes the planned descriptors twice — the host array (validated again, sizes the grids) and a copy
- * of it in device memory (the caller uploads it as it likes: one async copy from pinned memory) — and enqueues two launches on
+ * of it in device memory (the caller uploads it as it likes: one async copy from pinned memory) — and enqueues three launches (coefficient tables, horizontal pass, vertical pass + float tail) on
  * `stream`: out (B, 3, out_h, out_w) fp32.  pixels: 4-byte aligned, pixels_bytes a multiple of 4 (rows are staged with aligned
  * 4-byte loads); out, workspace: 16-byte aligned; out_w % 4 == 0, out_w <= 1024. */
 typedef struct cream_image_desc {
