@@ -147,3 +147,50 @@ def test_evaluate_runs_from_decoded_frames_through_the_device_transform():
         host.append((x.to(DEV), torch.tensor(labels, device=DEV)))
     want = engine.evaluate(host, model, amp_dtype=torch.float32, mode="retrain", retrain_config=cfg)
     assert got["loss"] == want["loss"] and got["acc1"] == want["acc1"] and got["acc5"] == want["acc5"]
+
+
+def test_fuzz_ragged_layouts_against_the_oracle():
+    """Random frames (1 x 1 up to 90 x 130), random boxes, resized sizes and windows, frames at ARBITRARY byte offsets with padded row
+    strides, straight through the C ABI — every output bit for bit the oracle's."""
+    import ctypes
+    from cream_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(123)
+    for out in (4, 16, 32):
+        B = 24
+        descs = (_lib.ImageDesc * B)()
+        frames, chunks, off = [], [], 0
+        for d in descs:
+            h, w = int(rng.integers(1, 91)), int(rng.integers(1, 131))
+            stride = 3 * w + int(rng.integers(0, 8))
+            f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            pad = int(rng.integers(0, 5))                          # frames start at any byte
+            buf = np.zeros(pad + h * stride, dtype=np.uint8)
+            for r in range(h):
+                buf[pad + r * stride: pad + r * stride + 3 * w] = f[r].reshape(-1)
+            bh, bw = int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1))
+            bt, bl = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
+            rh, rw = out + int(rng.integers(0, 20)), out + int(rng.integers(0, 20))
+            d.offset, d.height, d.width, d.row_stride = off + pad, h, w, stride
+            d.box_top, d.box_left, d.box_h, d.box_w = bt, bl, bh, bw
+            d.resized_h, d.resized_w = rh, rw
+            d.win_top, d.win_left = int(rng.integers(0, rh - out + 1)), int(rng.integers(0, rw - out + 1))
+            d.flip = int(rng.integers(0, 2))
+            frames.append(f)
+            chunks.append(buf)
+            off += buf.size
+        packed = np.concatenate(chunks + [np.zeros((-off) % 4, dtype=np.uint8)])
+        ws = lib.cream_image_batch_plan(descs, B, out, out)
+        assert ws > 0
+        pix = torch.from_numpy(packed).to(DEV)
+        dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(DEV)
+        wsb = torch.empty(ws, dtype=torch.uint8, device=DEV)
+        o = torch.empty(B, 3, out, out, device=DEV)
+        mean = (ctypes.c_float * 3)(*O.IMAGENET_DEFAULT_MEAN)
+        std = (ctypes.c_float * 3)(*O.IMAGENET_DEFAULT_STD)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        assert lib.cream_image_batch_transform(p(o), p(pix), packed.size, descs, p(dd), B, out, out, mean, std, p(wsb), ws, None) == 0
+        o = o.cpu()
+        for b, (d, f) in enumerate(zip(descs, frames)):
+            want = _ref(f, (d.box_top, d.box_left, d.box_h, d.box_w), (d.resized_h, d.resized_w), (d.win_top, d.win_left), out, bool(d.flip))
+            assert torch.equal(o[b], want), (out, b)
