@@ -92,3 +92,17 @@ def test_random_erasing_params_gate_and_ranges():
         T.plan([(300, 400)], [D.eval_crop_params(300, 400) + (False, (200, 10, 40, 40, 1))])
     n = D.erase_noise_reference(7, 3, 64, 64)
     assert n.shape == (3, 64, 64) and abs(float(n.mean())) < 0.05 and abs(float(n.var()) - 1) < 0.08
+
+
+def test_tinyclip_crop_params():
+    from cream_amd.tinyclip import transform as CT
+    import torch
+    assert CT.val_crop_params(375, 500) == ((0, 0, 375, 500), (224, 298), (0, 37), False)
+    assert CT.val_crop_params(375, 500, keep_ratio=False) == ((0, 0, 375, 500), (224, 224), (0, 0), False)
+    g = torch.Generator().manual_seed(5)
+    a = [CT.train_crop_params(375, 500, generator=g) for _ in range(50)]
+    g = torch.Generator().manual_seed(5)
+    assert a == [CT.train_crop_params(375, 500, generator=g) for _ in range(50)]        # torch's generator replays the crops
+    for (t, l, h, w), resized, window, flip in a:
+        assert 0 <= t and 0 <= l and t + h <= 375 and l + w <= 500 and resized == (224, 224) and not flip
+        assert h * w >= 0.9 * 375 * 500 * 0.97                      # scale (0.9, 1.0)

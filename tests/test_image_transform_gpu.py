@@ -194,3 +194,20 @@ def test_fuzz_ragged_layouts_against_the_oracle():
         for b, (d, f) in enumerate(zip(descs, frames)):
             want = _ref(f, (d.box_top, d.box_left, d.box_h, d.box_w), (d.resized_h, d.resized_w), (d.win_top, d.win_left), out, bool(d.flip))
             assert torch.equal(o[b], want), (out, b)
+
+
+def test_tinyclip_pipelines_end_to_end_on_the_device():
+    """open_clip's image_transform (TinyCLIP/src/open_clip/transform.py:71-122), train and val, with CLIP's statistics: bit for bit
+    what Pillow's resize + torch's float ops give on the host."""
+    from cream_amd.tinyclip import transform as CT
+    rng = np.random.default_rng(21)
+    g = torch.Generator().manual_seed(1)
+    shapes = [(375, 500), (640, 480), (224, 224), (180, 320)]
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    T = CT.device_transform(224, device=DEV)
+    for params in ([CT.train_crop_params(h, w, generator=g) for h, w in shapes], [CT.val_crop_params(h, w) for h, w in shapes],
+                   [CT.val_crop_params(h, w, keep_ratio=False) for h, w in shapes]):
+        out = T(frames, params).cpu()
+        for o, f, (box, resized, window, flip) in zip(out, frames, params):
+            want = O.to_tensor_normalize(O.resized_window(f, box, resized, window, (224, 224), flip), CT.OPENAI_DATASET_MEAN, CT.OPENAI_DATASET_STD)
+            assert torch.equal(o, want)
