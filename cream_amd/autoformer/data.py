@@ -331,3 +331,53 @@ class DeviceBatches:
             shapes = [tuple(f.shape[:2]) for f in frames]
             samples = self.transform(frames, self.params_for(shapes))
             yield samples, torch.as_tensor(labels, dtype=torch.int64).to(samples.device, non_blocking=True)
+
+
+# ---- the dataset / loader either side of the device transform (lib/datasets.py:152-187, supernet_train.py:222-243) ----------------
+IMG_EXTENSIONS = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')    # torchvision.datasets.folder
+
+
+class ImageFolderFrames(torch.utils.data.Dataset):
+    """`datasets.ImageFolder(root)` of the reference's `build_dataset` (data_set 'IMNET' / 'EVO_IMNET': lib/datasets.py:170-177)
+    with the transform moved behind the loader: class = sub-directory (sorted names -> indices), samples = the image files below
+    it in sorted walk order (torchvision's `make_dataset`), `__getitem__` = the DECODED frame (`default_loader`: PIL open +
+    convert('RGB')) as an (H, W, 3) uint8 array and the class index.  Decoding is host work for the loader's worker processes
+    (out of scope for the device); everything after it is `DeviceTransform`."""
+
+    def __init__(self, root):
+        import os
+        self.root = root
+        self.classes = sorted(e.name for e in os.scandir(root) if e.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
+        self.class_to_idx = {c: i for i, c in enumerate(self.classes)}
+        self.samples = []
+        for c in self.classes:
+            for base, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(base, f), self.class_to_idx[c]))
+        self.targets = [t for _, t in self.samples]
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        import numpy as np
+        from PIL import Image
+        path, target = self.samples[i]
+        with open(path, 'rb') as fh:
+            frame = np.asarray(Image.open(fh).convert('RGB'))
+        return frame, target
+
+
+def collate_frames(batch):
+    """Frames have different sizes: a batch is (list of frames, list of labels) — what `DeviceBatches` takes."""
+    return [b[0] for b in batch], [b[1] for b in batch]
+
+
+def frame_loader(dataset, batch_size, sampler=None, num_workers=0, drop_last=False):
+    """The `DataLoader` of supernet_train.py:231-243 over a dataset of decoded frames (pin_memory is `DeviceTransform`'s job:
+    it packs the frames into ONE pinned buffer per batch)."""
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                                       drop_last=drop_last, collate_fn=collate_frames)

@@ -106,3 +106,30 @@ def test_tinyclip_crop_params():
     for (t, l, h, w), resized, window, flip in a:
         assert 0 <= t and 0 <= l and t + h <= 375 and l + w <= 500 and resized == (224, 224) and not flip
         assert h * w >= 0.9 * 375 * 500 * 0.97                      # scale (0.9, 1.0)
+
+
+def test_image_folder_frames_lists_and_decodes_like_image_folder(tmp_path):
+    """Class indices from the sorted sub-directories, samples in sorted order, frames decoded through PIL's RGB conversion, ragged
+    batches through the loader with the reference's samplers (RASampler over it: three repeats per sample)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    truth = {}
+    for cls, names in (("n02", ["b.png", "a.png"]), ("n01", ["x.png"]), ("n03", ["k.PNG", "notes.txt"])):
+        (tmp_path / cls).mkdir()
+        for n in names:
+            if n.endswith("txt"):
+                (tmp_path / cls / n).write_text("not an image")
+                continue
+            arr = rng.integers(0, 256, (int(rng.integers(8, 20)), int(rng.integers(8, 20)), 3), dtype=np.uint8)
+            Image.fromarray(arr).save(tmp_path / cls / n)          # PNG: lossless
+            truth[(cls, n)] = arr
+    ds = D.ImageFolderFrames(str(tmp_path))
+    assert ds.classes == ["n01", "n02", "n03"] and ds.class_to_idx == {"n01": 0, "n02": 1, "n03": 2}
+    assert [(p.rsplit("/", 2)[1], p.rsplit("/", 1)[1], t) for p, t in ds.samples] == \
+        [("n01", "x.png", 0), ("n02", "a.png", 1), ("n02", "b.png", 1), ("n03", "k.PNG", 2)]
+    frame, target = ds[2]
+    assert target == 1 and np.array_equal(frame, truth[("n02", "b.png")])
+    batches = list(D.frame_loader(ds, batch_size=3))
+    assert [len(b[0]) for b in batches] == [3, 1] and batches[0][1] == [0, 1, 1] and batches[1][1] == [2]
+    sampler = D.RASampler(ds, num_replicas=1, rank=0, shuffle=False)
+    assert len(list(iter(sampler))) == sampler.num_selected_samples

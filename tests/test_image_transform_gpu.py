@@ -211,3 +211,29 @@ def test_tinyclip_pipelines_end_to_end_on_the_device():
         for o, f, (box, resized, window, flip) in zip(out, frames, params):
             want = O.to_tensor_normalize(O.resized_window(f, box, resized, window, (224, 224), flip), CT.OPENAI_DATASET_MEAN, CT.OPENAI_DATASET_STD)
             assert torch.equal(o, want)
+
+
+def test_image_folder_to_device_batches(tmp_path):
+    """Files on disk -> ImageFolderFrames -> frame_loader -> DeviceBatches: the batches are what the reference's
+    DataLoader(ImageFolder(root, transform=build_transform(False, args))) yields, bit for bit (Pillow decode + resize on the host
+    side of the comparison)."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for cls in ("a", "b"):
+        (tmp_path / cls).mkdir()
+        for i in range(3):
+            arr = rng.integers(0, 256, (int(rng.integers(240, 400)), int(rng.integers(240, 400)), 3), dtype=np.uint8)
+            Image.fromarray(arr).save(tmp_path / cls / f"{i}.png")
+    ds = D.ImageFolderFrames(str(tmp_path))
+    got = list(D.DeviceBatches(D.frame_loader(ds, batch_size=4), D.DeviceTransform(224, device=DEV), "eval"))
+    assert [tuple(x.shape) for x, _ in got] == [(4, 3, 224, 224), (2, 3, 224, 224)]
+    assert torch.cat([y for _, y in got]).tolist() == [0, 0, 0, 1, 1, 1]
+    k = 0
+    for x, _ in got:
+        for o in x.cpu():
+            im = Image.open(ds.samples[k][0]).convert("RGB")
+            w, h = im.size
+            box, resized, window = D.eval_crop_params(h, w)
+            im = im.resize((resized[1], resized[0]), Image.BICUBIC).crop((window[1], window[0], window[1] + 224, window[0] + 224))
+            assert torch.equal(o, O.to_tensor_normalize(np.asarray(im)))
+            k += 1
