@@ -237,3 +237,13 @@ def test_image_folder_to_device_batches(tmp_path):
             im = im.resize((resized[1], resized[0]), Image.BICUBIC).crop((window[1], window[0], window[1] + 224, window[0] + 224))
             assert torch.equal(o, O.to_tensor_normalize(np.asarray(im)))
             k += 1
+
+
+@pytest.mark.parametrize("out,width", [(224, 2000), (384, 2500), (224, 3000)])
+def test_very_wide_frames_take_the_narrow_row_groups(out, width):
+    """Wide boxes with large tables leave LDS for only two rows / one row per step of the horizontal pass (R = 2 / 1): same bytes."""
+    rng = np.random.default_rng(width)
+    f = rng.integers(0, 256, (40, width, 3), dtype=np.uint8)
+    prm = ((0, 0, 40, width), (out, out), (0, 0), True)
+    o = D.DeviceTransform(out, device=DEV)([f], [prm]).cpu()[0]
+    assert torch.equal(o, _ref(f, *prm[:3], out, True))
