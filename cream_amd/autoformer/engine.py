@@ -254,21 +254,40 @@ class SupernetTrainer:
         return loss
 
 
+class PendingEval:
+    """An evaluation whose kernels are enqueued and whose statistics still live on the device: `result()` is the ONE host
+    synchronisation.  A sweep over many sub-networks (evolution search) keeps the device busy across candidates by resolving a
+    whole population at once instead of one candidate at a time."""
+
+    def __init__(self, tot, n_total, config, params):
+        self._tot, self._n, self._config, self._params, self._done = tot, n_total, config, params, None
+
+    def result(self):
+        if self._done is None:
+            loss_sum, h1, h5 = self._tot.tolist()
+            n = max(float(self._n), 1.0)
+            self._done = dict(loss=loss_sum / n, acc1=100.0 * h1 / n, acc5=100.0 * h5 / n, config=self._config, params=self._params)
+            self._tot = None
+        return self._done
+
+
 @torch.no_grad()
-def evaluate(batches, model, amp_dtype=torch.bfloat16, choices=None, mode='super', retrain_config=None):
+def evaluate(batches, model, amp_dtype=torch.bfloat16, choices=None, mode='super', retrain_config=None, defer=False):
     """Sub-network evaluation — host-side mirror of `evaluate` in AutoFormer/supernet_engine.py:113-160
     (the inner loop of the evolution search, evolution.py:22-290, and of the validation pass):
     eval mode, ONE sub-network (sampled from `choices` when mode == 'super', else `retrain_config`),
     cross entropy + top-1 / top-5 accuracy averaged over the samples of `batches` (an iterable of
     (images, labels) already on the model's device).  The statistics are accumulated on the device:
     one host synchronisation at the end instead of the reference's three `.item()` per batch.
-    Returns {'loss', 'acc1', 'acc5', 'config', 'params'}."""
+    Returns {'loss', 'acc1', 'acc5', 'config', 'params'} — or, with defer=True, a `PendingEval` whose `result()` is that dictionary
+    (no synchronisation here at all)."""
     model.eval()
     config = sample_configs(choices) if mode == 'super' else retrain_config
     model.set_sample_config(config)
     params = model.get_sampled_params_numel(config)
     dev = next(model.parameters()).device
-    tot = torch.zeros(4, dtype=torch.float64, device=dev)        # loss*n, top1 hits, top5 hits, n
+    tot = torch.zeros(3, dtype=torch.float64, device=dev)        # loss*n, top1 hits, top5 hits (n is host arithmetic: a per-batch
+    n_total = 0                                                   # host scalar -> device tensor would be a pageable copy, i.e. a sync)
     use_amp = amp_dtype is not None and amp_dtype != torch.float32 and dev.type == 'cuda'
     for images, labels in batches:
         with torch.autocast(device_type=dev.type, dtype=amp_dtype if use_amp else torch.bfloat16, enabled=use_amp):
@@ -278,11 +297,10 @@ def evaluate(batches, model, amp_dtype=torch.bfloat16, choices=None, mode='super
         loss = F.cross_entropy(out, labels, reduction='sum')
         top5 = out.topk(min(5, out.shape[1]), dim=1).indices
         hit = top5.eq(labels.view(-1, 1))
-        tot += torch.stack([loss.double(), hit[:, 0].sum().double(), hit.any(dim=1).sum().double(),
-                            torch.tensor(float(n), dtype=torch.float64, device=dev)])
-    loss_sum, h1, h5, n = tot.tolist()
-    n = max(n, 1.0)
-    return dict(loss=loss_sum / n, acc1=100.0 * h1 / n, acc5=100.0 * h5 / n, config=config, params=params)
+        tot += torch.stack([loss.double(), hit[:, 0].sum().double(), hit.any(dim=1).sum().double()])
+        n_total += n
+    pending = PendingEval(tot, n_total, config, params)
+    return pending if defer else pending.result()
 
 
 # ---- checkpoints: the on-disk format either side of the path ---------------------------

@@ -56,10 +56,28 @@ class EvolutionSearcher:
         self.epoch = 0
         self.candidates, self.top_accuracies = [], []
         self.evaluated = 0
+        self._pending = []                     # (info, key, PendingEval): accuracies still on the device
 
     # ---- the hot part ------------------------------------------------------------------------
     def _evaluate_native(self, batches, config):
-        return engine.evaluate(batches, self.model, amp_dtype=self.amp_dtype, mode='retrain', retrain_config=config)
+        # deferred: the accuracy of a candidate is first READ when its population is ranked (update_top_k), so the candidates of a
+        # phase are enqueued back to back and resolved together — the device never waits for the host between candidates
+        return engine.evaluate(batches, self.model, amp_dtype=self.amp_dtype, mode='retrain', retrain_config=config, defer=True)
+
+    def _record(self, info, key, res):
+        if not isinstance(res, dict) and hasattr(res, 'result'):             # engine.PendingEval (a custom `evaluate` may return the dict)
+            info[key] = None
+            self._pending.append((info, key, res))
+            if len(self._pending) >= 256:                                     # (a bound on what is outstanding, far above a population)
+                self.resolve()
+        else:
+            info[key] = res['acc1']
+
+    def resolve(self):
+        """Bring every outstanding accuracy to the host (one wait for the device, then plain reads)."""
+        for info, key, res in self._pending:
+            info[key] = res.result()['acc1']
+        self._pending = []
 
     def is_legal(self, cand):
         assert isinstance(cand, tuple)
@@ -70,8 +88,8 @@ class EvolutionSearcher:
         info['params'] = self.model.get_sampled_params_numel(config) / 10. ** 6
         if info['params'] > self.parameters_limits or info['params'] < self.min_parameters_limits:
             return False
-        info['acc'] = self._evaluate(self.val_batches, config)['acc1']
-        info['test_acc'] = self._evaluate(self.test_batches, config)['acc1']
+        self._record(info, 'acc', self._evaluate(self.val_batches, config))
+        self._record(info, 'test_acc', self._evaluate(self.test_batches, config))
         info['visited'] = True
         self.evaluated += 1
         return True
@@ -143,6 +161,7 @@ class EvolutionSearcher:
         return self._collect(lambda: self._child(k), crossover_num)
 
     def update_top_k(self, candidates, k, key, reverse=True):
+        self.resolve()
         t = self.keep_top_k[k]
         t += candidates
         t.sort(key=key, reverse=reverse)
@@ -150,6 +169,7 @@ class EvolutionSearcher:
 
     # ---- checkpoints: evolution.py:51-75 ('checkpoint-{epoch}.pth.tar') ----------------------------
     def state(self):
+        self.resolve()
         return dict(top_accuracies=self.top_accuracies, memory=self.memory, candidates=self.candidates,
                     vis_dict=self.vis_dict, keep_top_k=self.keep_top_k, epoch=self.epoch)
 
@@ -187,4 +207,5 @@ class EvolutionSearcher:
             self.get_random(self.population_num)
             self.epoch += 1
             self.save_checkpoint()
+        self.resolve()
         return self.keep_top_k[50]

@@ -26,6 +26,17 @@ for _ in range(n_sub):
     r = engine.evaluate(batches, m, choices=ch, mode="super")
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+# the same sweep as the evolution search runs it: statistics left on the device, one synchronisation per population
+random.seed(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+pend = [engine.evaluate(batches, m, choices=ch, mode="super", defer=True) for _ in range(n_sub)]
+rd = [p.result() for p in pend]
+torch.cuda.synchronize()
+dt_d = time.perf_counter() - t0
 print(json.dumps(dict(workload="supernet-S sub-network evaluation sweep (eval forward, bf16, batch 128, 2 batches per sub-network)",
                       subnets=n_sub, images_per_sec=round(n_sub * 2 * 128 / dt, 1), ms_per_batch=round(dt / (n_sub * 2) * 1e3, 3),
-                      subnets_per_sec=round(n_sub / dt, 2), last=dict(loss=r["loss"], params=r["params"]))))
+                      subnets_per_sec=round(n_sub / dt, 2), last=dict(loss=r["loss"], params=r["params"]),
+                      deferred=dict(note="statistics resolved once per population (engine.evaluate(defer=True), evolution.py)",
+                                    images_per_sec=round(n_sub * 2 * 128 / dt_d, 1), ms_per_batch=round(dt_d / (n_sub * 2) * 1e3, 3),
+                                    subnets_per_sec=round(n_sub / dt_d, 2)))))
