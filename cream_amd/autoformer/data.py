@@ -245,6 +245,8 @@ class DeviceTransform:
         self._mean = (ctypes.c_float * 3)(*mean)
         self._std = (ctypes.c_float * 3)(*std)
         self._ws = None
+        self._pool = None                      # packing threads (numpy's large copies release the GIL)
+        self.pack_threads = 8
 
     def plan(self, shapes, params):
         """shapes: [(H, W)], params: [(box, resized, window[, flip[, erase]])] with erase = None | (top, left, h, w, seed)
@@ -278,9 +280,20 @@ class DeviceTransform:
         descs, nbytes, ws_bytes = self.plan(shapes, params)
         packed = torch.empty(nbytes, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
         pk = packed.numpy()
-        for d, f in zip(descs, frames):
+
+        def put(i):
+            f = frames[i]
             a = np.ascontiguousarray(f.numpy() if isinstance(f, torch.Tensor) else f, dtype=np.uint8)
-            pk[d.offset:d.offset + a.size] = a.reshape(-1)
+            pk[descs[i].offset:descs[i].offset + a.size] = a.reshape(-1)
+
+        if B >= 16 and self.pack_threads > 1:   # one copy per frame into the pinned buffer, spread over a few threads
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.pack_threads)
+            list(self._pool.map(put, range(B)))
+        else:
+            for i in range(B):
+                put(i)
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         if self.device.type == "cuda":
             raw = raw.pin_memory()
