@@ -247,3 +247,27 @@ def test_very_wide_frames_take_the_narrow_row_groups(out, width):
     prm = ((0, 0, 40, width), (out, out), (0, 0), True)
     o = D.DeviceTransform(out, device=DEV)([f], [prm]).cpu()[0]
     assert torch.equal(o, _ref(f, *prm[:3], out, True))
+
+
+def test_device_batches_train_mode_matches_the_same_draws_on_the_host():
+    """DeviceBatches in training mode: crop, flip and RandomErasing parameters drawn per image in the recipe's order from one
+    random.Random; the same draws replayed on the host give the same tensors outside the erased boxes (bit for bit) and noise inside."""
+    rng = np.random.default_rng(6)
+    shapes = [(300, 400), (260, 260), (500, 333), (240, 320)] * 4
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    loader = [(frames, list(range(16)))]
+    T = D.DeviceTransform(224, device=DEV)
+    (x, y), = list(D.DeviceBatches(loader, T, "train", rng=random.Random(11), reprob=0.5))
+    assert y.tolist() == list(range(16)) and tuple(x.shape) == (16, 3, 224, 224)
+    replay = D.DeviceBatches(loader, T, "train", rng=random.Random(11), reprob=0.5).params_for(shapes)
+    erased = 0
+    for o, f, (box, resized, window, flip, erase) in zip(x.cpu(), frames, replay):
+        want = _ref(f, box, resized, window, 224, flip)
+        keep = torch.ones(224, 224, dtype=torch.bool)
+        if erase is not None:
+            t, l, h, w, _ = erase
+            keep[t:t + h, l:l + w] = False
+            erased += 1
+            assert not torch.equal(o[:, ~keep], want[:, ~keep])
+        assert torch.equal(o[:, keep], want[:, keep])
+    assert 2 <= erased <= 14
